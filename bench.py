@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of the PFHub BM1 Cahn-Hilliard hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--variant V]
+
+A "step" is one explicit FD Cahn-Hilliard update of the whole grid (the fused HIP kernel of
+pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
+  bm1_fd_512c   (default, BASELINE.json config 3)  512^3 per GPU, fp64, BM1 initial condition extruded in z;
+                N > 1: each rank owns a 512 x 512 x 512 slab of a 512 x 512 x (512 N) periodic box (weak scaling),
+                ghost planes exchanged over RCCL (torch.distributed "nccl") overlapped with the interior kernel.
+  bm1_fd_1024c  1024^3 on 1 GPU, or 1024 x 1024 x (1024/N) slabs on N GPUs (BASELINE.json config 4, strong)
+  bm1_fd_512s   512^2 2-D (launch-latency bound; reported for completeness)
+Prints ONE JSON line (rank 0).  `value` counts the cell updates of all ranks; inputs are resident in HBM before the
+timed region.  roofline.achieved = 16 B/cell-update x cells per launch / average kernel time from HIP events
+recorded inside libpfhip around every step launch.  cpu_baseline = the CPU oracle (oracle/ch_fd.c, OpenMP) timed on
+this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_CELL_UPDATE = 16.0     # read c^n once + write c^{n+1} once, fp64
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
+
+
+def cpu_baseline(nx, ny, nz_sample, dt, steps):
+    """The oracle (port of the same algorithm) on the host cores: bounded sample = an nx x ny x nz_sample periodic
+    block of the same initial condition."""
+    import numpy as np
+    from oracle import ch_fd
+    ch_fd.load()
+    c = ch_fd.ic(nx, ny, 1)
+    c = np.repeat(c, nz_sample, 0)
+    c = ch_fd.fd_step(c, dt)          # warm-up (page faults, OpenMP pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c = ch_fd.fd_step(c, dt)
+    el = time.perf_counter() - t0
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": nx * ny * nz_sample * steps / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
+            "sample": "%dx%dx%d periodic block of the BM1 IC, %d steps, oracle/ch_fd.c (gcc -O2 -fopenmp), %.1f s"
+                      % (nx, ny, nz_sample, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s"])
+    ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
+    ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from pfhubbenchmarks_amd import lib as L
+    from pfhubbenchmarks_amd.solver import HipSlabEngine, PhaseFieldSolver, SlabSolver
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (a.gpus, a.gpus))
+        sys.exit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    lib = L.load()                      # raises if the HIP extension is missing: no fallback
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    if a.variant >= 0:
+        lib.pfk_set_tuning(0, a.variant)
+
+    h = 1.0
+    if a.workload == "bm1_fd_512s":
+        dim, gn, scaling = 2, (512, 512, 1), "weak"
+        dt = 1e-3
+    elif a.workload == "bm1_fd_512c":
+        dim, gn, scaling = 3, (512, 512, 512 * world), "weak"
+        dt = 5e-4
+    else:
+        dim, gn, scaling = 3, (1024, 1024, 1024), "strong"
+        dt = 5e-4
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        eng = HipSlabEngine(gn, h, world, rank, local_rank)
+        eng.set_ic_bm1(0.5, 0.05)
+        solver = SlabSolver(eng)
+        timer = eng
+        local_cells = gn[0] * gn[1] * eng.nz
+
+        def run(k):
+            solver.step(dt, k)
+
+        def sync():
+            eng.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        n = gn[:dim]
+        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank)
+        s.set_ic_bm1(0.5, 0.05)
+        solver = timer = s
+        local_cells = gn[0] * gn[1] * gn[2]
+
+        def run(k):
+            s.step(dt, k)
+
+        def sync():
+            s.sync()
+            torch.cuda.synchronize()
+
+    F0, C0, _ = solver.diagnostics()
+    run(a.warmup)
+    sync()
+    timer.timing(True)
+    t0 = time.perf_counter()
+    run(a.steps)
+    sync()
+    el = time.perf_counter() - t0
+    k_ms, k_launches = timer.timing_read()
+    timer.timing(False)
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    F1, C1, _ = solver.diagnostics()
+
+    total_cells = gn[0] * gn[1] * gn[2]
+    value = total_cells * a.steps / el
+    # dominant kernel: all step launches of this rank (1 per step on one GPU; interior + 2 boundary launches per
+    # step in slab mode, summed)
+    kernel_s_per_step = k_ms * 1e-3 * k_launches / max(a.steps, 1)
+    achieved = BYTES_PER_CELL_UPDATE * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+    out = {
+        "metric": "cell-updates/sec on PFHub BM1 Cahn-Hilliard (explicit FD, fused HIP stencil)",
+        "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit",
+                   "kernel": a.kernel, "variant": a.variant, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
+                   "parallelism": "slab%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms_per_step": kernel_s_per_step * 1e3, "launches_per_step": k_launches / max(a.steps, 1),
+                     "bytes_per_cell_update": BYTES_PER_CELL_UPDATE},
+        "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        if dim == 3:
+            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 32, dt, 6)
+        else:
+            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 1, dt, 400)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

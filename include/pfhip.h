@@ -1,0 +1,176 @@
+/* pfhip.h -- C ABI of libpfhip: MI355X (gfx950) phase-field hot path for PFHub BM1 / BM6.
+ *
+ * This is the drop-in boundary for the time-stepping path of the reference's dolfin/bench1.py and
+ * dolfin/bench6.py (paths below are relative to the reference tree).  The reference has no FFI of its own:
+ * its "interface" is the handful of FEniCS calls the driver scripts make per step.  Each entry point here
+ * names the reference call it replaces.
+ *
+ *   reference                                               | libpfhip
+ *   --------------------------------------------------------+-----------------------------------------------
+ *   mesh/space/params block   dolfin/bench1.py:21-69        | pf_create(const pf_config*, pf_handle**)
+ *   w.interpolate(w_ic)       dolfin/bench1.py:134-135      | pf_set_ic_bm1 / pf_set_ic_bm6 / pf_set_field
+ *     InitialConditionsBench1 dolfin/pfbase.py:177-193      |
+ *     InitialConditionsBench6 dolfin/pfbase.py:322-339      |
+ *   w0.assign(w); solver.solve() -> (niters, converged)     | pf_step(h, dt, nsteps, &info)   (info.ok ~ converged)
+ *                             dolfin/bench1.py:158-162      |
+ *   w.assign(w0) on failure   dolfin/bench1.py:171-173      | pf_rollback(h)
+ *   total_solute / total_free_energy (df.assemble)          | pf_diagnostics(h, out[3])
+ *                             dolfin/bench1.py:121-125,     |
+ *                             dolfin/bench6.py:155-165      |
+ *   w.split() / outfile.write dolfin/bench1.py:188-191      | pf_get_field(h, field, host, n)
+ *   implicit PETSc ghost scatter inside solver.solve()      | pf_step_begin / pf_step_finish + pf_halo_layout:
+ *     (dolfinx/pfbase/pde_problems.py:69,87 shows it)       |   the caller exchanges ghost planes in between
+ *   implicit MPI_Allreduce inside df.assemble               | pf_diagnostics_local (caller all-reduces 3 doubles)
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative pf_status; no C++
+ * exception crosses the boundary; pf_last_error() gives a human-readable message.  A handle is not
+ * thread-safe (one caller thread per handle, like one Python thread per MPI rank in the reference).
+ * All field data is IEEE fp64, x fastest: index = (z*ny + y)*nx + x.
+ */
+#ifndef PFHIP_H
+#define PFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFHIP_VERSION 100 /* 0.1.0 */
+
+typedef enum pf_status {
+  PF_OK = 0,
+  PF_ERR_INVALID = -1,     /* bad argument / config (programmer error) */
+  PF_ERR_UNSUPPORTED = -2, /* valid request this build cannot do */
+  PF_ERR_HIP = -3,         /* HIP runtime / hipFFT error (message in pf_last_error) */
+  PF_ERR_STATE = -4,       /* call sequence error (e.g. rollback with nothing to roll back) */
+  PF_ERR_NOMEM = -5
+} pf_status;
+
+enum { PF_BC_PERIODIC = 0, PF_BC_MIRROR = 1 };           /* mirror = natural no-flux BC (bench1.py:69) */
+enum { PF_SCHEME_FD_EXPLICIT = 0, PF_SCHEME_SPECTRAL_SI = 1 };
+enum { PF_MODEL_BM1 = 1, PF_MODEL_BM6 = 6 };
+enum { PF_FIELD_C = 0, PF_FIELD_MU = 1, PF_FIELD_PHI = 2 };
+enum { PF_KERNEL_AUTO = 0, PF_KERNEL_FUSED = 1, PF_KERNEL_TWOPASS = 2 }; /* FD step implementation */
+
+/* Model + discretisation.  Defaults of the reference: dolfin/bench1.py:32-36, dolfin/bench6.py:38-39. */
+typedef struct pf_config {
+  int32_t struct_bytes; /* = sizeof(pf_config); guards against ABI drift */
+  int32_t dim;          /* 2 or 3 */
+  int32_t n[3];         /* PERIODIC: lattice points per axis (n[2] = 1 in 2-D).
+                           MIRROR:   nodes of the physical no-flux domain per axis, i.e. intervals+1; the library
+                                     runs on the even extension (2*(n-1) periodic points per axis). */
+  int32_t bc;           /* PF_BC_* */
+  int32_t scheme;       /* PF_SCHEME_* */
+  int32_t model;        /* PF_MODEL_* */
+  int32_t kernel;       /* PF_KERNEL_* (FD scheme only) */
+  int32_t device;       /* HIP device ordinal */
+  int32_t nranks;       /* slab decomposition along the slowest axis (z in 3-D, y in 2-D); 1 = whole domain */
+  int32_t rank;
+  int32_t reserved0;
+  double h;             /* grid spacing (same on every axis) */
+  double rho_s, c_alpha, c_beta, kappa, M; /* bench1.py:32-36 */
+  double k, eps_r;                         /* bench6.py:38-39 (BM6 only) */
+  void* stream;         /* hipStream_t to launch on; NULL = library creates its own */
+  double* ext_c[2];     /* optional caller-owned DEVICE buffers for the two c time levels, each
+                           pf_field_elems_with_ghosts() doubles; NULL = library allocates (hipMalloc) */
+} pf_config;
+
+typedef struct pf_step_info {
+  int32_t ok;        /* 1 if the state after the step(s) is finite and inside the guard band c in [-1, 2] */
+  int32_t nsteps;    /* steps actually taken */
+  double cmin, cmax; /* global extrema after the last step (local extrema in slab mode) */
+} pf_step_info;
+
+/* Ghost-plane layout of one rank's c buffer in slab mode (element offsets into the CURRENT c buffer). */
+typedef struct pf_halo_layout {
+  double* base;            /* device pointer of the current c buffer */
+  int64_t plane_elems;     /* doubles per plane of the slab axis */
+  int32_t ghost;           /* ghost planes per side (2) */
+  int32_t n_local;         /* owned planes */
+  int64_t send_lo_off, send_hi_off; /* first / last `ghost` owned planes */
+  int64_t recv_lo_off, recv_hi_off; /* ghost planes below / above */
+  int32_t rank_lo, rank_hi;         /* neighbour ranks (periodic ring) */
+  int32_t cur_index;                /* which of the two c buffers (cfg.ext_c[cur_index]) is current */
+  int32_t reserved0;
+} pf_halo_layout;
+
+typedef struct pf_handle pf_handle;
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int pf_version(void);
+/* message of the last failure on this handle (NULL handle: last failure of a pf_create on this thread) */
+const char* pf_last_error(const pf_handle* h);
+/* number of HIP devices visible, or <0; touches the HIP runtime */
+int pf_device_count(void);
+/* fill *cfg with the reference's BM1 constants for an n^dim periodic grid (pure host, no HIP call) */
+int pf_config_default(pf_config* cfg, int dim, int n, double h);
+
+/* ---- pure-host helpers (no HIP call; usable without a GPU) ------------------------------------------- */
+/* planes [*first, *first + *count) of `n_planes` owned by `rank` of `nranks` (remainder to the low ranks) */
+int pf_slab_partition(int n_planes, int nranks, int rank, int* first, int* count);
+/* doubles a caller must provide per ext_c buffer for this config (owned + ghost planes) */
+int64_t pf_field_elems_with_ghosts(const pf_config* cfg);
+/* doubles of one rank's owned part of a field (what pf_set_field / pf_get_field move) */
+int64_t pf_field_elems(const pf_config* cfg);
+
+/* ---- life cycle ------------------------------------------------------------------------------------- */
+int pf_create(const pf_config* cfg, pf_handle** out);
+int pf_destroy(pf_handle* h);
+
+/* ---- state ------------------------------------------------------------------------------------------ */
+int pf_set_ic_bm1(pf_handle* h, double c0, double eps);  /* pfbase.py:187-189; z-extruded in 3-D (b13d.py:55) */
+int pf_set_ic_bm6(pf_handle* h, double c0, double c1);   /* pfbase.py:332-334 */
+int pf_set_field(pf_handle* h, int field, const double* host, size_t n); /* caller-owned host buffer, copied */
+int pf_get_field(pf_handle* h, int field, double* host, size_t n);
+
+/* ---- time stepping ---------------------------------------------------------------------------------- */
+/* nranks == 1: advance nsteps steps of size dt.  Asynchronous on the handle's stream unless info != NULL
+ * (then the guard reduction is read back).  The state before the LAST step stays available to pf_rollback. */
+int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info);
+int pf_rollback(pf_handle* h);
+int pf_sync(pf_handle* h);
+
+/* slab mode (nranks > 1), one step:  begin (interior planes; needs no ghosts) -> caller exchanges the ghost
+ * planes described by pf_halo_layout on its own stream and makes the handle's stream wait for it ->
+ * finish (boundary planes + buffer swap). */
+int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
+int pf_step_begin(pf_handle* h, double dt);
+int pf_step_finish(pf_handle* h);
+
+/* ---- diagnostics (bench1.py:121-125, bench6.py:155-165) ---------------------------------------------- */
+/* out = {total_free_energy, total_solute, f_elec part}; synchronises.  nranks > 1: use the _local variant
+ * and sum the 3 doubles over ranks. */
+int pf_diagnostics(pf_handle* h, double out[3]);
+int pf_diagnostics_local(pf_handle* h, double out[3]);
+
+/* ---- measurement hooks ------------------------------------------------------------------------------- */
+/* average device time (ms) of the dominant step kernel over the launches since the last call, measured with
+ * HIP events on the handle's stream; enable with pf_timing_enable(h, 1). */
+int pf_timing_enable(pf_handle* h, int on);
+int pf_timing_read(pf_handle* h, double* avg_ms, int64_t* launches);
+
+/* ---- kernel-level entry points (stateless; caller-owned device pointers) ------------------------------ */
+typedef struct pfk_ch_params {
+  double c_alpha, c_beta, two_rho; /* f'(c) = two_rho (c-ca)(cb-c)((cb-c)-(c-ca)) */
+  double kappa_over_h2;            /* kappa / h^2 */
+  double dtM_over_h2;              /* dt * M / h^2 */
+  double k_phi;                    /* BM6 coupling k (0 for BM1) */
+} pfk_ch_params;
+
+/* One explicit FD Cahn-Hilliard step on planes [zlo, zhi) of a slab:
+ *   mu = f'(c) - kappa lap_h c (+ k phi);  c_out = c_in + dt M lap_h mu      (7-point lap_h, 5-point when nz == 1)
+ * c_in / c_out: (nz + 2*ghost) planes of ny*nx doubles, owned planes start at plane `ghost`.
+ * zwrap != 0: the slab axis is periodic inside this buffer (ghost planes unused); else planes -2..nz+1 are read
+ * from the ghost planes.  phi may be NULL (BM1).  impl: PF_KERNEL_*. */
+int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx, int ny, int nz, int ghost,
+                   int zwrap, int zlo, int zhi, const pfk_ch_params* p, int impl, void* stream);
+
+/* tuning hook for benchmarks: key 0 = fused-kernel variant (0: 8 waves x 2 rows, 1: 4 waves x 4 rows) */
+int pfk_set_tuning(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFHIP_H */

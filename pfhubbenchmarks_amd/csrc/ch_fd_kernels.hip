@@ -1,0 +1,438 @@
+// Explicit finite-difference Cahn-Hilliard step for gfx950 (MI355X), fp64.
+//
+//   mu   = f'(c) - kappa lap_h c (+ k phi)         dolfin/pfbase.py:361-383 (cahn_hilliard_weak_form),
+//   cnew = c + dt M lap_h mu                       dolfin/bench1.py:63-65 (f_chem, dfdc), bench6.py:68 (+ k phi)
+//
+// The operation order is fixed (and restated in oracle/ch_fd.c, against which this file is bit-compared):
+//   Lxy = fma(-4, c, (c[x-1] + c[x+1]) + (c[y-1] + c[y+1]));  Lz = fma(-2, c, c[z-1] + c[z+1])
+//   a = c - ca; b = cb - c; fp = two_rho * ((a*b) * (b-a));   mu = fma(-kappa/h^2, Lxy + Lz, fp)
+//   cnew = fma(dt M/h^2, Mxy + Mz, c)   with Mxy, Mz the same stencils on mu.
+// Compile with -ffp-contract=off so nothing else is fused.
+//
+// Fused kernel (the hot path): one workgroup owns a 128 x TY (x,y) tile and streams through z ("2.5-D").
+//   * a lane owns 2 x-adjacent cells -> every global access is a 16-byte double2, 1 KiB per wave instruction
+//   * plane z arrives in registers (prefetched one plane ahead), is written once to the LDS c-tile
+//     (halo 2 in y, one 16-byte halo pair per side in x); xy-neighbours come from LDS, z-neighbours from registers
+//   * mu is computed exactly once per cell (+ the 1-cell ring around the tile) and staged in a second LDS tile
+//   * algorithmic HBM traffic: 8 B read + 8 B written per cell update; halo re-reads are L2/MALL hits when
+//     neighbouring tiles run on the same XCD, hence the XCD-aware tile order below.
+// Roles inside a workgroup (NW >= 4 waves, S interior rows per wave, TY = NW*S):
+//   every wave:  S interior rows (own the cell: compute mu and the update)
+//   wave 0 / 1:  the mu-only halo row above / below the tile
+//   wave 2:      the two x-halo columns (loads the 16-byte halo pairs, computes mu on x0-1 and x0+w)
+//   wave 3:      loads the two outermost y-halo rows (LDS only)
+#include "pfhip_internal.h"
+
+namespace pfhip {
+namespace {
+
+constexpr int TXW = 128;        // tile width in cells = 64 lanes x 2
+constexpr int PITCH = TXW + 4;  // LDS row pitch in doubles: columns x0-2 .. x0+129
+
+struct KArgs {
+  FdArgs f;
+  int ntx, nty, nchunk, zchunk, ntiles;
+};
+
+__device__ __forceinline__ int wrapi(int i, int n) {
+  i %= n;
+  return i < 0 ? i + n : i;
+}
+
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
+// (a plain __syncthreads() drains vmcnt as well, which would serialise the plane prefetch with the compute).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+
+__device__ __forceinline__ double fprime(double c, double ca, double cb, double two_rho) {
+  const double a = c - ca, b = cb - c;
+  return two_rho * ((a * b) * (b - a));
+}
+
+// xy part of the 5/7-point Laplacian for a cell pair stored at row r, column col of an LDS tile;
+// v = the pair's own values (kept in registers)
+__device__ __forceinline__ double2 lap_xy_pair(const double* T, int r, int col, double2 v) {
+  const double2 up = ld2(T + (r - 1) * PITCH + col);
+  const double2 dn = ld2(T + (r + 1) * PITCH + col);
+  const double lf = T[r * PITCH + col - 1];
+  const double rt = T[r * PITCH + col + 2];
+  double2 o;
+  o.x = fma(-4.0, v.x, (lf + v.y) + (up.x + dn.x));
+  o.y = fma(-4.0, v.y, (v.x + rt) + (up.y + dn.y));
+  return o;
+}
+
+// same, with the row above / below supplied from registers (adjacent rows owned by the same lane)
+__device__ __forceinline__ double2 lap_xy_pair_ud(const double* T, int r, int col, double2 v, double2 up, double2 dn) {
+  const double lf = T[r * PITCH + col - 1];
+  const double rt = T[r * PITCH + col + 2];
+  double2 o;
+  o.x = fma(-4.0, v.x, (lf + v.y) + (up.x + dn.x));
+  o.y = fma(-4.0, v.y, (v.x + rt) + (up.y + dn.y));
+  return o;
+}
+
+// Global memory goes through raw buffer instructions: one 128-bit descriptor per plane (wave-uniform, SGPRs) plus
+// a 32-bit per-lane byte offset.  The hardware range check makes predication branch-free: an inactive lane gets
+// the offset OOB (>= num_records), its load returns 0 and its store is dropped.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0x80000000u;
+
+__device__ __forceinline__ auto plane_rsrc(const double* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, (int)bytes, 0x00020000);
+}
+template <class R>
+__device__ __forceinline__ double2 bld2(R rs, uint32_t boff) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff, 0, 0));
+}
+template <class R>
+__device__ __forceinline__ void bst2(R rs, uint32_t boff, double2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)boff, 0, 0);
+}
+
+// NW waves x S rows per wave; DEPTH = planes prefetched ahead in registers (bytes in flight per workgroup =
+// DEPTH x (TY+4) KiB: what hides the HBM latency when only one or two workgroups fit on a CU).
+template <int NW, int S, int DEPTH, bool HAS_PHI>
+__global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
+  static_assert(NW >= 4, "roles of waves 0..3");
+  constexpr int TY = NW * S;
+  static_assert(2 * (TY + 2) <= 64, "x-halo column task must fit one wave");
+  constexpr int MOFF = (TY + 4) * PITCH;       // mu tile starts here (indices relative to Cb)
+  constexpr int DUMMY = 2 * (TY + 4) * PITCH;  // scratch row: LDS writes of inactive lanes land here
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Cb = reinterpret_cast<double*>(smem_raw);  // c tile:  rows y0-2 .. y0+TY+1
+  double* Mb = Cb + MOFF;                            // mu tile: same indexing (rows 1 .. TY+2 used)
+
+  const FdArgs& a = k.f;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one contiguous run of
+  // tiles (x fastest, then y, then z-chunk) so that tiles sharing halos hit the same L2.  Speed only.
+  const int per = gridDim.x >> 3;
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (t >= k.ntiles) return;
+  const int tx = t % k.ntx;
+  const int ty = (t / k.ntx) % k.nty;
+  const int ch = t / (k.ntx * k.nty);
+  const int x0 = tx * TXW, y0 = ty * TY;
+  const int w = min(TXW, a.nx - x0);   // valid tile width (even)
+  const int hgt = min(TY, a.ny - y0);  // valid tile height
+  const int zs = a.zlo + ch * k.zchunk;
+  const int ze = min(a.zhi, zs + k.zchunk);
+  const int niter = (ze - zs) + 4;
+  const int64_t plane = (int64_t)a.nx * a.ny;
+  const uint32_t plane_bytes = (uint32_t)(plane * 8);
+  const bool lane_on = 2 * lane < w;
+  const int col = 2 + 2 * lane;
+
+  // ---- interior slots: a wave owns S ADJACENT rows (the y-neighbour between its own rows comes from registers).
+  // Rows past the tile (j >= hgt, partial tiles only) are NOT clamped: row j == hgt is the halo row below the
+  // tile, so the slot tracks exactly the values its upper neighbour needs from registers (c and mu), with the
+  // right LDS neighbours; rows beyond that compute garbage nobody reads.  Neither writes LDS nor global memory.
+  int rr[S], wr[S];
+  uint32_t off[S], soff[S];  // load / store byte offsets inside a plane (OOB when inactive)
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int j = wave * S + s;
+    const bool act = lane_on && j < hgt;
+    rr[s] = 2 + j;
+    wr[s] = act ? rr[s] * PITCH + col : DUMMY + col;
+    off[s] = lane_on ? (uint32_t)((wrapi(y0 + j, a.ny) * a.nx + x0 + 2 * lane) * 8) : OOB;
+    soff[s] = act ? off[s] : OOB;
+  }
+  // ---- extra slot (role by wave; the role code is a scalar branch, its loads are branch-free via OOB)
+  const bool role_mu_row = wave < 2, role_col = wave == 2;
+  bool e_mu = false;
+  int e_r = 1, e_cc = col;
+  int e_wr = DUMMY + col, e_wr2 = DUMMY + col;
+  uint32_t e_off = OOB, e_off2 = OOB;
+  bool e_pick_y = false;  // column task: centre is .y of the pair (left side) or .x (right side)
+  if (role_mu_row) {
+    e_r = wave == 0 ? 1 : hgt + 2;
+    const int y = wrapi(wave == 0 ? y0 - 1 : y0 + hgt, a.ny);
+    e_mu = lane_on;
+    if (lane_on) {
+      e_wr = e_r * PITCH + col;
+      e_off = (uint32_t)((y * a.nx + x0 + 2 * lane) * 8);
+    }
+  } else if (role_col) {
+    const int side = lane & 1, j = lane >> 1;
+    const bool on = j < hgt + 2;
+    const int jc = on ? j : 0;
+    e_r = 1 + jc;
+    const int y = wrapi(y0 - 1 + jc, a.ny);
+    const int xh = side ? wrapi(x0 + w, a.nx) : wrapi(x0 - 2, a.nx);
+    e_cc = side ? w + 2 : 1;
+    if (on) {
+      e_off = (uint32_t)((y * a.nx + xh) * 8);
+      e_wr = e_r * PITCH + (side ? w + 2 : 0);
+    }
+    e_pick_y = !side;
+    e_mu = on && j >= 1 && j <= hgt;
+  } else if (wave == 3) {
+    if (lane_on) {
+      e_wr = 0 * PITCH + col;
+      e_wr2 = (hgt + 3) * PITCH + col;
+      e_off = (uint32_t)((wrapi(y0 - 2, a.ny) * a.nx + x0 + 2 * lane) * 8);
+      e_off2 = (uint32_t)((wrapi(y0 + hgt + 1, a.ny) * a.nx + x0 + 2 * lane) * 8);
+    }
+  }
+
+  const double2 zero2 = make_double2(0.0, 0.0);
+  double2 ld[DEPTH][S], c1[S], c2[S], lxy1[S], mu2[S], mu3[S], mxy2[S];
+  double2 ph[DEPTH][S];
+  double2 eld[DEPTH], eld2[DEPTH], e_ph[DEPTH];
+#pragma unroll
+  for (int s = 0; s < S; ++s) c1[s] = c2[s] = lxy1[s] = mu2[s] = mu3[s] = mxy2[s] = zero2;
+  double2 e_c1 = zero2, e_c2 = zero2, e_lxy1 = zero2;
+
+  auto zmap = [&](int P) -> int64_t { return (int64_t)((a.zwrap ? wrapi(P, a.nz) : P) + a.ghost) * plane; };
+  // loads plane Pc of c into ring slot d (and, for BM6, the centre values of phi on plane Pc-1, used by the same
+  // iteration).  Planes past the chunk's last input plane (ze+1) are not read: their descriptor has 0 records.
+  auto load_all = [&](int d, int Pc) {
+    const bool valid = Pc <= ze + 1;
+    const int Pl = valid ? Pc : ze + 1;
+    const auto rc = plane_rsrc(a.cin + zmap(Pl), valid ? plane_bytes : 0u);
+#pragma unroll
+    for (int s = 0; s < S; ++s) ld[d][s] = bld2(rc, off[s]);
+    eld[d] = bld2(rc, e_off);
+    eld2[d] = bld2(rc, e_off2);
+    if constexpr (HAS_PHI) {
+      const auto rp = plane_rsrc(a.phi + zmap(Pl - 1), valid ? plane_bytes : 0u);
+#pragma unroll
+      for (int s = 0; s < S; ++s) ph[d][s] = bld2(rp, off[s]);
+      e_ph[d] = bld2(rp, e_mu ? e_off : OOB);
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s) ph[d][s] = zero2;
+      e_ph[d] = zero2;
+    }
+  };
+
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_all(d, zs - 2 + d);
+
+  // niter is padded to a multiple of DEPTH so the ring index is a compile-time constant; the padding iterations
+  // compute on zeros and store nothing.
+  const int niter_pad = ((niter + DEPTH - 1) / DEPTH) * DEPTH;
+  for (int i0 = 0; i0 < niter_pad; i0 += DEPTH) {
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int i = i0 + d;
+    const int P = zs - 2 + i;
+    // ---- A: plane P from registers into the LDS c tile
+    double2 cP[S], phP[S];
+    const double2 e_cP = eld[d], e_phP = e_ph[d];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      cP[s] = ld[d][s];
+      phP[s] = ph[d][s];
+      st2(Cb + wr[s], cP[s]);
+    }
+    st2(Cb + e_wr, eld[d]);
+    st2(Cb + e_wr2, eld2[d]);
+    load_all(d, P + DEPTH);  // prefetch DEPTH planes ahead: stays in flight across the barriers
+    lds_barrier();
+
+    // ---- C: Lxy(P) from LDS, mu(P-1) = f'(c(P-1)) - kh2 (Lxy(P-1) + Lz(P-1)) into the LDS mu tile
+    double2 mu1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double2 up = s > 0 ? cP[s > 0 ? s - 1 : 0] : ld2(Cb + (rr[s] - 1) * PITCH + col);
+      const double2 dn = s + 1 < S ? cP[s + 1 < S ? s + 1 : 0] : ld2(Cb + (rr[s] + 1) * PITCH + col);
+      const double2 lxyP = lap_xy_pair_ud(Cb, rr[s], col, cP[s], up, dn);
+      double2 lz, m;
+      lz.x = fma(-2.0, c1[s].x, c2[s].x + cP[s].x);
+      lz.y = fma(-2.0, c1[s].y, c2[s].y + cP[s].y);
+      m.x = fma(-a.kh2, lxy1[s].x + lz.x, fprime(c1[s].x, a.ca, a.cb, a.two_rho));
+      m.y = fma(-a.kh2, lxy1[s].y + lz.y, fprime(c1[s].y, a.ca, a.cb, a.two_rho));
+      if constexpr (HAS_PHI) {
+        m.x = fma(a.kphi, phP[s].x, m.x);
+        m.y = fma(a.kphi, phP[s].y, m.y);
+      }
+      mu1[s] = m;
+      st2(Cb + wr[s] + (wr[s] < DUMMY ? MOFF : 0), m);
+      lxy1[s] = lxyP;
+    }
+    if (role_mu_row) {  // mu-only halo rows (pairs)
+      const double2 lxyP = lap_xy_pair(Cb, e_r, col, e_cP);
+      double2 lz, m;
+      lz.x = fma(-2.0, e_c1.x, e_c2.x + e_cP.x);
+      lz.y = fma(-2.0, e_c1.y, e_c2.y + e_cP.y);
+      m.x = fma(-a.kh2, e_lxy1.x + lz.x, fprime(e_c1.x, a.ca, a.cb, a.two_rho));
+      m.y = fma(-a.kh2, e_lxy1.y + lz.y, fprime(e_c1.y, a.ca, a.cb, a.two_rho));
+      if constexpr (HAS_PHI) {
+        m.x = fma(a.kphi, e_phP.x, m.x);
+        m.y = fma(a.kphi, e_phP.y, m.y);
+      }
+      st2(Cb + e_wr + (e_mu ? MOFF : 0), m);
+      e_lxy1 = lxyP;
+      e_c2 = e_c1;
+      e_c1 = e_cP;
+    } else if (role_col) {  // x-halo columns (single cells; state in .x)
+      const double cc = e_pick_y ? e_cP.y : e_cP.x;
+      const double* row = Cb + e_r * PITCH + e_cc;
+      const double lxyP = fma(-4.0, cc, (row[-1] + row[1]) + (row[-PITCH] + row[PITCH]));
+      const double lz = fma(-2.0, e_c1.x, e_c2.x + cc);
+      double m = fma(-a.kh2, e_lxy1.x + lz, fprime(e_c1.x, a.ca, a.cb, a.two_rho));
+      if constexpr (HAS_PHI) m = fma(a.kphi, e_pick_y ? e_phP.y : e_phP.x, m);  // phi(P-1), loaded with c(P)
+      Cb[e_mu ? MOFF + e_r * PITCH + e_cc : DUMMY + col] = m;
+      e_lxy1.x = lxyP;
+      e_c2.x = e_c1.x;
+      e_c1.x = cc;
+    }
+    lds_barrier();
+
+    // ---- E: Mxy(P-1) from LDS; out(P-2) = c(P-2) + amh2 (Mxy(P-2) + Mz(P-2))
+    const bool store_ok = i >= 4 && i < niter;  // the first 4 planes only fill the pipeline (stores go OOB)
+    const auto ro = plane_rsrc(a.cout + (int64_t)(P - 2 + a.ghost) * plane, store_ok ? plane_bytes : 0u);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double2 up = s > 0 ? mu1[s > 0 ? s - 1 : 0] : ld2(Mb + (rr[s] - 1) * PITCH + col);
+      const double2 dn = s + 1 < S ? mu1[s + 1 < S ? s + 1 : 0] : ld2(Mb + (rr[s] + 1) * PITCH + col);
+      const double2 mxy1 = lap_xy_pair_ud(Mb, rr[s], col, mu1[s], up, dn);
+      double2 mz, o;
+      mz.x = fma(-2.0, mu2[s].x, mu3[s].x + mu1[s].x);
+      mz.y = fma(-2.0, mu2[s].y, mu3[s].y + mu1[s].y);
+      o.x = fma(a.amh2, mxy2[s].x + mz.x, c2[s].x);
+      o.y = fma(a.amh2, mxy2[s].y + mz.y, c2[s].y);
+      bst2(ro, soff[s], o);
+      mu3[s] = mu2[s];
+      mu2[s] = mu1[s];
+      mxy2[s] = mxy1;
+      c2[s] = c1[s];
+      c1[s] = cP[s];
+    }
+  }
+  }
+}
+
+// ---- two-pass reference implementation (any nx, ny, nz; 40 B/cell of traffic) ------------------------------
+__global__ __launch_bounds__(256) void ch_fd_mu_kernel(const FdArgs a, double* __restrict__ mu) {
+  // mu on planes zlo-1 .. zhi  -> scratch plane index (z - (zlo-1))
+  const int64_t plane = (int64_t)a.nx * a.ny;
+  const int64_t total = plane * (a.zhi - a.zlo + 2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.nx);
+    const int y = (int)((i / a.nx) % a.ny);
+    const int zr = (int)(i / plane);
+    const int z = a.zlo - 1 + zr;
+    auto pl = [&](int P) {
+      const int zz = a.zwrap ? wrapi(P, a.nz) : P;
+      return a.cin + (int64_t)(zz + a.ghost) * plane;
+    };
+    const double* p0 = pl(z);
+    const double* pm = pl(z - 1);
+    const double* pp = pl(z + 1);
+    const int xm = wrapi(x - 1, a.nx), xp = wrapi(x + 1, a.nx);
+    const int ym = wrapi(y - 1, a.ny), yp = wrapi(y + 1, a.ny);
+    const double c = p0[(int64_t)y * a.nx + x];
+    const double sx = p0[(int64_t)y * a.nx + xm] + p0[(int64_t)y * a.nx + xp];
+    const double sy = p0[(int64_t)ym * a.nx + x] + p0[(int64_t)yp * a.nx + x];
+    const double lxy = fma(-4.0, c, sx + sy);
+    const double lz = fma(-2.0, c, pm[(int64_t)y * a.nx + x] + pp[(int64_t)y * a.nx + x]);
+    double m = fma(-a.kh2, lxy + lz, fprime(c, a.ca, a.cb, a.two_rho));
+    if (a.phi) {
+      const int zz = a.zwrap ? wrapi(z, a.nz) : z;
+      m = fma(a.kphi, a.phi[(int64_t)(zz + a.ghost) * plane + (int64_t)y * a.nx + x], m);
+    }
+    mu[i] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void ch_fd_update_kernel(const FdArgs a, const double* __restrict__ mu) {
+  const int64_t plane = (int64_t)a.nx * a.ny;
+  const int64_t total = plane * (a.zhi - a.zlo);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % a.nx);
+    const int y = (int)((i / a.nx) % a.ny);
+    const int zr = (int)(i / plane);  // output plane zlo + zr -> mu scratch plane zr + 1
+    const double* m0 = mu + (int64_t)(zr + 1) * plane;
+    const double* mm = m0 - plane;
+    const double* mp = m0 + plane;
+    const int xm = wrapi(x - 1, a.nx), xp = wrapi(x + 1, a.nx);
+    const int ym = wrapi(y - 1, a.ny), yp = wrapi(y + 1, a.ny);
+    const double m = m0[(int64_t)y * a.nx + x];
+    const double sx = m0[(int64_t)y * a.nx + xm] + m0[(int64_t)y * a.nx + xp];
+    const double sy = m0[(int64_t)ym * a.nx + x] + m0[(int64_t)yp * a.nx + x];
+    const double mxy = fma(-4.0, m, sx + sy);
+    const double mz = fma(-2.0, m, mm[(int64_t)y * a.nx + x] + mp[(int64_t)y * a.nx + x]);
+    const int64_t g = (int64_t)(a.zlo + zr + a.ghost) * plane + (int64_t)y * a.nx + x;
+    a.cout[g] = fma(a.amh2, mxy + mz, a.cin[g]);
+  }
+}
+
+template <int NW, int S, int DEPTH>
+hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
+  constexpr int TY = NW * S;
+  KArgs k;
+  k.f = a;
+  k.ntx = (a.nx + TXW - 1) / TXW;
+  k.nty = (a.ny + TY - 1) / TY;
+  const int nzr = a.zhi - a.zlo;
+  // z-chunks: enough workgroups to fill 256 CUs a few times over, but keep the 4-plane pipeline fill < ~12 %
+  const int xy = k.ntx * k.nty;
+  int nchunk = (2048 + xy - 1) / xy;
+  const int max_chunks = nzr >= 32 ? nzr / 32 : 1;
+  if (nchunk > max_chunks) nchunk = max_chunks;
+  if (nchunk < 1) nchunk = 1;
+  k.zchunk = (nzr + nchunk - 1) / nchunk;
+  k.nchunk = (nzr + k.zchunk - 1) / k.zchunk;
+  k.ntiles = xy * k.nchunk;
+  const int grid = ((k.ntiles + 7) / 8) * 8;
+  const size_t lds = sizeof(double) * (2 * (TY + 4) + 1) * PITCH;  // + dummy row
+  if (a.phi)
+    hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, true>), dim3(grid), dim3(64 * NW), lds, stream, k);
+  else
+    hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, false>), dim3(grid), dim3(64 * NW), lds, stream, k);
+  return hipGetLastError();
+}
+
+int g_fused_variant = 0;  // tuning hook (pfk_set_tuning key 0): index into the variant table below
+
+}  // namespace
+
+bool ch_fd_fused_supported(const FdArgs& a) {
+  // pairs need even nx and 16-byte aligned rows; buffers come from hipMalloc / torch (>= 256-byte aligned)
+  if ((int64_t)a.nx * a.ny * 8 > (int64_t)0x7FFFFFF0) return false;  // 32-bit in-plane byte offsets, OOB = 2^31
+  return (a.nx % 2 == 0) && a.nx >= 2 && ((reinterpret_cast<uintptr_t>(a.cin) & 15) == 0) &&
+         ((reinterpret_cast<uintptr_t>(a.cout) & 15) == 0) &&
+         (a.phi == nullptr || (reinterpret_cast<uintptr_t>(a.phi) & 15) == 0);
+}
+
+hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream) {
+  if (a.zhi <= a.zlo) return hipSuccess;
+  switch (g_fused_variant) {
+    case 1: return launch_fused_t<8, 2, 1>(a, stream);
+    case 2: return launch_fused_t<8, 2, 3>(a, stream);
+    case 3: return launch_fused_t<16, 1, 1>(a, stream);
+    case 4: return launch_fused_t<16, 1, 2>(a, stream);
+    case 5: return launch_fused_t<16, 1, 3>(a, stream);
+    case 6: return launch_fused_t<4, 4, 1>(a, stream);
+    default: return launch_fused_t<8, 2, 2>(a, stream);
+  }
+}
+
+hipError_t launch_ch_fd_twopass(const FdArgs& a, double* mu_scratch, hipStream_t stream) {
+  if (a.zhi <= a.zlo) return hipSuccess;
+  const int64_t plane = (int64_t)a.nx * a.ny;
+  const int64_t n1 = plane * (a.zhi - a.zlo + 2), n2 = plane * (a.zhi - a.zlo);
+  auto grid_for = [](int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : g);
+  };
+  hipLaunchKernelGGL(ch_fd_mu_kernel, dim3(grid_for(n1)), dim3(256), 0, stream, a, mu_scratch);
+  hipLaunchKernelGGL(ch_fd_update_kernel, dim3(grid_for(n2)), dim3(256), 0, stream, a, (const double*)mu_scratch);
+  return hipGetLastError();
+}
+
+void set_fused_variant(int v) { g_fused_variant = v; }
+
+}  // namespace pfhip

@@ -1,0 +1,150 @@
+// Diagnostics reductions and the initial-condition kernel (fp64, gfx950).
+//
+//   total_solute       = int c dx                                   dolfin/bench1.py:121-122
+//   total_free_energy  = int f_chem + kappa/2 |grad c|^2 (+ k c phi/2) dx   dolfin/bench1.py:124-125, bench6.py:155-165
+//   IC                 = pfbase.py:187-189 (BM1), :332-334 (BM6); extruded along z as in dolfin/b13d.py:55
+//
+// The kernel produces RAW sums {sum c, sum f_chem, sum of squared forward differences, sum c*phi, min c, max c};
+// the host scales them (h^d, kappa/(2 h^2), k/2).  Two-stage, fixed-order reduction (wave shuffles -> LDS ->
+// per-block partials -> one final block): no float atomics, so results are bitwise reproducible run to run.
+#include "pfhip_internal.h"
+
+namespace pfhip {
+namespace {
+
+constexpr int DIAG_BLOCK = 256;
+constexpr int DIAG_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ int wrapi(int i, int n) {
+  i %= n;
+  return i < 0 ? i + n : i;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_down(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// reduce 6 values over a 256-thread block; result valid in thread 0
+__device__ __forceinline__ void block_reduce6(double v[6], double* sh /* 4 waves x 6 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double r[6];
+  r[0] = wave_sum(v[0]);
+  r[1] = wave_sum(v[1]);
+  r[2] = wave_sum(v[2]);
+  r[3] = wave_sum(v[3]);
+  r[4] = wave_min(v[4]);
+  r[5] = wave_max(v[5]);
+  if (lane == 0)
+    for (int q = 0; q < 6; ++q) sh[wave * 6 + q] = r[q];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 4; ++q) v[q] = ((sh[q] + sh[6 + q]) + (sh[12 + q] + sh[18 + q]));
+    v[4] = fmin(fmin(sh[4], sh[10]), fmin(sh[16], sh[22]));
+    v[5] = fmax(fmax(sh[5], sh[11]), fmax(sh[17], sh[23]));
+  }
+}
+
+__global__ __launch_bounds__(DIAG_BLOCK) void diag_partial_kernel(const double* __restrict__ c,
+                                                                 const double* __restrict__ phi, int nx, int ny,
+                                                                 int nz, int ghost, int zwrap, double rho, double ca,
+                                                                 double cb, double* __restrict__ partials) {
+  __shared__ double sh[24];
+  const int64_t plane = (int64_t)nx * ny;
+  const int64_t total = plane * nz;
+  double v[6] = {0.0, 0.0, 0.0, 0.0, INFINITY, -INFINITY};
+  for (int64_t i = (int64_t)blockIdx.x * DIAG_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * DIAG_BLOCK) {
+    const int x = (int)(i % nx);
+    const int y = (int)((i / nx) % ny);
+    const int z = (int)(i / plane);
+    const int zp = zwrap ? wrapi(z + 1, nz) : z + 1;
+    const double* p0 = c + (int64_t)(z + ghost) * plane;
+    const double* pp = c + (int64_t)(zp + ghost) * plane;
+    const int xp = x + 1 == nx ? 0 : x + 1;
+    const int yp = y + 1 == ny ? 0 : y + 1;
+    const double w = p0[(int64_t)y * nx + x];
+    const double a = w - ca, b = cb - w, ab = a * b;
+    const double dx = p0[(int64_t)y * nx + xp] - w;
+    const double dy = p0[(int64_t)yp * nx + x] - w;
+    const double dz = pp[(int64_t)y * nx + x] - w;
+    v[0] += w;
+    v[1] += rho * (ab * ab);
+    v[2] += (dx * dx + dy * dy) + dz * dz;
+    if (phi) v[3] += w * phi[(int64_t)(z + ghost) * plane + (int64_t)y * nx + x];
+    v[4] = fmin(v[4], w);
+    v[5] = fmax(v[5], w);
+  }
+  block_reduce6(v, sh);
+  if (threadIdx.x == 0)
+    for (int q = 0; q < 6; ++q) partials[(int64_t)blockIdx.x * 6 + q] = v[q];
+}
+
+__global__ __launch_bounds__(DIAG_BLOCK) void diag_final_kernel(const double* __restrict__ partials, int nblocks,
+                                                               double* __restrict__ out6) {
+  __shared__ double sh[24];
+  double v[6] = {0.0, 0.0, 0.0, 0.0, INFINITY, -INFINITY};
+  for (int b = threadIdx.x; b < nblocks; b += DIAG_BLOCK) {
+    for (int q = 0; q < 4; ++q) v[q] += partials[(int64_t)b * 6 + q];
+    v[4] = fmin(v[4], partials[(int64_t)b * 6 + 4]);
+    v[5] = fmax(v[5], partials[(int64_t)b * 6 + 5]);
+  }
+  block_reduce6(v, sh);
+  if (threadIdx.x == 0)
+    for (int q = 0; q < 6; ++q) out6[q] = v[q];
+}
+
+// mnx / mny > 0: the lattice is the even (mirror) extension of a no-flux domain with mnx x mny nodes:
+// lattice index i >= mn maps to node 2 (mn - 1) - i.
+__global__ __launch_bounds__(256) void ic_kernel(double* __restrict__ c, int nx, int ny, int nz, int ghost, double h,
+                                                 double c0, double amp, double w0, int mnx, int mny) {
+  const int64_t plane = (int64_t)nx * ny;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % nx), y = (int)(i / nx);
+    const int xe = (mnx > 0 && x >= mnx) ? 2 * (mnx - 1) - x : x;
+    const int ye = (mny > 0 && y >= mny) ? 2 * (mny - 1) - y : y;
+    const double X = xe * h, Y = ye * h;
+    const double t2 = cos(0.13 * X) * cos(0.087 * Y);
+    const double v =
+        c0 + amp * (cos(w0 * X) * cos(0.11 * Y) + t2 * t2 + cos(0.025 * X - 0.15 * Y) * cos(0.07 * X - 0.02 * Y));
+    for (int z = 0; z < nz; ++z) c[(int64_t)(z + ghost) * plane + i] = v;
+  }
+}
+
+}  // namespace
+
+int diag_partials_elems() { return DIAG_MAX_BLOCKS * 6; }
+
+hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, double rho,
+                       double ca, double cb, double* partials, double* out6, hipStream_t stream) {
+  const int64_t total = (int64_t)nx * ny * nz;
+  int64_t nb = (total + DIAG_BLOCK - 1) / DIAG_BLOCK;
+  if (nb > DIAG_MAX_BLOCKS) nb = DIAG_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(diag_partial_kernel, dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, c, phi, nx, ny, nz, ghost, zwrap,
+                     rho, ca, cb, partials);
+  hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(DIAG_BLOCK), 0, stream, (const double*)partials, (int)nb, out6);
+  return hipGetLastError();
+}
+
+hipError_t launch_ic(double* c, int nx, int ny, int nz, int ghost, double h, double c0, double amp, double w0,
+                     int mnx, int mny, hipStream_t stream) {
+  const int64_t plane = (int64_t)nx * ny;
+  int64_t nb = (plane + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(ic_kernel, dim3((int)nb), dim3(256), 0, stream, c, nx, ny, nz, ghost, h, c0, amp, w0, mnx,
+                     mny);
+  return hipGetLastError();
+}
+
+}  // namespace pfhip

@@ -1,0 +1,607 @@
+// C ABI of libpfhip (see include/pfhip.h for the reference call each entry point replaces).
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "pfhip_internal.h"
+
+using namespace pfhip;
+
+namespace {
+
+struct Geometry {
+  int dim;
+  int mirror;        // 1 if cfg.bc == PF_BC_MIRROR
+  int np[3];         // physical nodes per axis (mirror) or lattice points (periodic)
+  int nx, ny, nzg;   // computational (periodic) lattice
+  int z0, nz;        // owned planes of the slab axis
+  int ghost, zwrap;
+  int64_t plane;
+};
+
+thread_local std::string g_create_error;
+
+int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
+  auto bad = [&](const char* m) {
+    if (err) *err = m;
+    return (int)PF_ERR_INVALID;
+  };
+  if (!cfg) return bad("null config");
+  if (cfg->struct_bytes != (int32_t)sizeof(pf_config)) return bad("pf_config.struct_bytes != sizeof(pf_config)");
+  if (cfg->dim != 2 && cfg->dim != 3) return bad("dim must be 2 or 3");
+  if (cfg->bc != PF_BC_PERIODIC && cfg->bc != PF_BC_MIRROR) return bad("bad bc");
+  if (!(cfg->h > 0.0)) return bad("h must be > 0");
+  g->dim = cfg->dim;
+  g->mirror = cfg->bc == PF_BC_MIRROR;
+  for (int d = 0; d < 3; ++d) {
+    int n = d < cfg->dim ? cfg->n[d] : 1;
+    if (n < 1) return bad("n[d] must be >= 1");
+    if (g->mirror && d < cfg->dim && n < 2) return bad("mirror bc needs >= 2 nodes per axis");
+    g->np[d] = n;
+  }
+  auto ext = [&](int d) { return (g->mirror && d < cfg->dim) ? 2 * (g->np[d] - 1) : g->np[d]; };
+  g->nx = ext(0);
+  g->ny = ext(1);
+  g->nzg = ext(2);
+  g->plane = (int64_t)g->nx * g->ny;
+  if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return bad("bad nranks / rank");
+  if (cfg->nranks > 1) {
+    if (cfg->dim != 3) {
+      if (err) *err = "slab decomposition is implemented for dim == 3 only";
+      return (int)PF_ERR_UNSUPPORTED;
+    }
+    if (g->mirror) {
+      if (err) *err = "slab decomposition with mirror bc is not implemented";
+      return (int)PF_ERR_UNSUPPORTED;
+    }
+    if (g->nzg < 2 * cfg->nranks) return bad("need >= 2 planes per rank");
+    pf_slab_partition(g->nzg, cfg->nranks, cfg->rank, &g->z0, &g->nz);
+    g->ghost = 2;
+    g->zwrap = 0;
+  } else {
+    g->z0 = 0;
+    g->nz = g->nzg;
+    g->ghost = 0;
+    g->zwrap = 1;
+  }
+  return PF_OK;
+}
+
+}  // namespace
+
+struct pf_handle {
+  pf_config cfg;
+  Geometry g;
+  double* c[2] = {nullptr, nullptr};
+  bool own_c = false;
+  int cur = 0;
+  bool have_prev = false;
+  double* mu_scratch = nullptr;
+  int64_t mu_scratch_elems = 0;
+  double* partials = nullptr;
+  double* out6_dev = nullptr;
+  double* out6_host = nullptr;  // pinned
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool step_open = false;
+  double open_dt = 0.0;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t ev_used = 0;
+  double t_ms = 0.0;
+  int64_t t_launches = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(pf_handle* h, int code, const std::string& msg) {
+  if (h)
+    h->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define PF_HIP(h, expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess)                                                                                \
+      return fail(h, PF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+
+FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
+  const pf_config& c = h->cfg;
+  FdArgs a;
+  a.cin = h->c[h->cur];
+  a.cout = h->c[1 - h->cur];
+  a.phi = nullptr;
+  a.nx = h->g.nx;
+  a.ny = h->g.ny;
+  a.nz = h->g.nz;
+  a.ghost = h->g.ghost;
+  a.zwrap = h->g.zwrap;
+  a.zlo = zlo;
+  a.zhi = zhi;
+  a.ca = c.c_alpha;
+  a.cb = c.c_beta;
+  a.two_rho = 2.0 * c.rho_s;
+  a.kh2 = c.kappa / (c.h * c.h);
+  a.amh2 = dt * c.M / (c.h * c.h);
+  a.kphi = 0.0;
+  return a;
+}
+
+int ensure_mu_scratch(pf_handle* h, int64_t elems) {
+  if (h->mu_scratch_elems >= elems) return PF_OK;
+  if (h->mu_scratch) PF_HIP(h, hipFree(h->mu_scratch));
+  h->mu_scratch = nullptr;
+  h->mu_scratch_elems = 0;
+  PF_HIP(h, hipMalloc(&h->mu_scratch, sizeof(double) * elems));
+  h->mu_scratch_elems = elems;
+  return PF_OK;
+}
+
+int timing_flush(pf_handle* h) {
+  if (h->ev_used == 0) return PF_OK;
+  PF_HIP(h, hipEventSynchronize(h->ev[h->ev_used - 1].second));
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    PF_HIP(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
+    h->t_ms += ms;
+    h->t_launches += 1;
+  }
+  h->ev_used = 0;
+  return PF_OK;
+}
+
+// one FD step on planes [zlo, zhi) of the current buffer into the other buffer
+int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
+  if (zhi <= zlo) return PF_OK;
+  FdArgs a = make_args(h, dt, zlo, zhi);
+  int impl = h->cfg.kernel;
+  if (impl == PF_KERNEL_AUTO) impl = ch_fd_fused_supported(a) ? PF_KERNEL_FUSED : PF_KERNEL_TWOPASS;
+  if (impl == PF_KERNEL_FUSED && !ch_fd_fused_supported(a))
+    return fail(h, PF_ERR_UNSUPPORTED, "fused FD kernel needs even nx and 16-byte aligned buffers");
+  std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
+  if (h->timing) {
+    if (h->ev_used == h->ev.size()) {
+      int rc = timing_flush(h);
+      if (rc) return rc;
+    }
+    e = &h->ev[h->ev_used++];
+    PF_HIP(h, hipEventRecord(e->first, h->stream));
+  }
+  if (impl == PF_KERNEL_FUSED) {
+    PF_HIP(h, launch_ch_fd_fused(a, h->stream));
+  } else {
+    int rc = ensure_mu_scratch(h, h->g.plane * (int64_t)(zhi - zlo + 2));
+    if (rc) return rc;
+    PF_HIP(h, launch_ch_fd_twopass(a, h->mu_scratch, h->stream));
+  }
+  if (e) PF_HIP(h, hipEventRecord(e->second, h->stream));
+  return PF_OK;
+}
+
+int run_diag(pf_handle* h, double raw[6]) {
+  const pf_config& c = h->cfg;
+  PF_HIP(h, launch_diag(h->c[h->cur], nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
+                        c.c_beta, h->partials, h->out6_dev, h->stream));
+  PF_HIP(h, hipMemcpyAsync(h->out6_host, h->out6_dev, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PF_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 6; ++i) raw[i] = h->out6_host[i];
+  return PF_OK;
+}
+
+void scale_diag(const pf_handle* h, const double raw[6], double out[3]) {
+  const pf_config& c = h->cfg;
+  double vol = 1.0;
+  for (int d = 0; d < c.dim; ++d) vol *= c.h;
+  if (h->g.mirror)
+    for (int d = 0; d < c.dim; ++d) vol *= 0.5;  // even extension counts the domain 2^dim times
+  const double felec = 0.5 * c.k * raw[3];
+  out[0] = vol * (raw[1] + 0.5 * c.kappa / (c.h * c.h) * raw[2] + (c.model == PF_MODEL_BM6 ? felec : 0.0));
+  out[1] = vol * raw[0];
+  out[2] = c.model == PF_MODEL_BM6 ? vol * felec : 0.0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_version(void) { return PFHIP_VERSION; }
+
+const char* pf_last_error(const pf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pf_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return PF_ERR_HIP;
+  }
+  return n;
+}
+
+int pf_config_default(pf_config* cfg, int dim, int n, double h) {
+  if (!cfg || (dim != 2 && dim != 3) || n < 1 || !(h > 0.0)) return PF_ERR_INVALID;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_bytes = (int32_t)sizeof(pf_config);
+  cfg->dim = dim;
+  cfg->n[0] = n;
+  cfg->n[1] = n;
+  cfg->n[2] = dim == 3 ? n : 1;
+  cfg->bc = PF_BC_PERIODIC;
+  cfg->scheme = PF_SCHEME_FD_EXPLICIT;
+  cfg->model = PF_MODEL_BM1;
+  cfg->kernel = PF_KERNEL_AUTO;
+  cfg->device = 0;
+  cfg->nranks = 1;
+  cfg->rank = 0;
+  cfg->h = h;
+  cfg->rho_s = 5.0;  // dolfin/bench1.py:32-36
+  cfg->c_alpha = 0.3;
+  cfg->c_beta = 0.7;
+  cfg->kappa = 2.0;
+  cfg->M = 5.0;
+  cfg->k = 0.09;  // dolfin/bench6.py:38-39
+  cfg->eps_r = 90.0;
+  return PF_OK;
+}
+
+int pf_slab_partition(int n_planes, int nranks, int rank, int* first, int* count) {
+  if (n_planes < 1 || nranks < 1 || rank < 0 || rank >= nranks || !first || !count) return PF_ERR_INVALID;
+  const int base = n_planes / nranks, rem = n_planes % nranks;
+  *count = base + (rank < rem ? 1 : 0);
+  *first = rank * base + (rank < rem ? rank : rem);
+  return PF_OK;
+}
+
+int64_t pf_field_elems_with_ghosts(const pf_config* cfg) {
+  Geometry g;
+  if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
+  return g.plane * (int64_t)(g.nz + 2 * g.ghost);
+}
+
+int64_t pf_field_elems(const pf_config* cfg) {
+  Geometry g;
+  if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
+  if (g.mirror) return (int64_t)g.np[0] * g.np[1] * g.np[2];
+  return g.plane * (int64_t)g.nz;
+}
+
+int pf_create(const pf_config* cfg, pf_handle** out) {
+  if (!out) return fail(nullptr, PF_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  Geometry g;
+  std::string err;
+  int rc = resolve(cfg, &g, &err);
+  if (rc != PF_OK) return fail(nullptr, rc, err);
+  if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6) return fail(nullptr, PF_ERR_INVALID, "bad model");
+  if (cfg->scheme != PF_SCHEME_FD_EXPLICIT)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "only PF_SCHEME_FD_EXPLICIT is implemented in this build");
+  if (cfg->model != PF_MODEL_BM1) return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is not implemented in this build");
+  if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
+  if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
+    return fail(nullptr, PF_ERR_INVALID, "ext_c: give both buffers or none");
+
+  pf_handle* h = new (std::nothrow) pf_handle();
+  if (!h) return fail(nullptr, PF_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  h->g = g;
+  auto bail = [&](int code) {
+    g_create_error = h->err;
+    pf_destroy(h);
+    return code;
+  };
+#define PF_HIP_C(expr)                                                                \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      h->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+      return bail(PF_ERR_HIP);                                                        \
+    }                                                                                 \
+  } while (0)
+  PF_HIP_C(hipSetDevice(cfg->device));
+  if (cfg->stream) {
+    h->stream = reinterpret_cast<hipStream_t>(cfg->stream);
+  } else {
+    PF_HIP_C(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  const int64_t elems = g.plane * (int64_t)(g.nz + 2 * g.ghost);
+  if (cfg->ext_c[0]) {
+    h->c[0] = cfg->ext_c[0];
+    h->c[1] = cfg->ext_c[1];
+  } else {
+    h->own_c = true;
+    PF_HIP_C(hipMalloc(&h->c[0], sizeof(double) * elems));
+    PF_HIP_C(hipMalloc(&h->c[1], sizeof(double) * elems));
+  }
+  PF_HIP_C(hipMemsetAsync(h->c[0], 0, sizeof(double) * elems, h->stream));
+  PF_HIP_C(hipMemsetAsync(h->c[1], 0, sizeof(double) * elems, h->stream));
+  PF_HIP_C(hipMalloc(&h->partials, sizeof(double) * diag_partials_elems()));
+  PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 6));
+  PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 6, hipHostMallocDefault));
+  PF_HIP_C(hipStreamSynchronize(h->stream));
+#undef PF_HIP_C
+  *out = h;
+  return PF_OK;
+}
+
+int pf_destroy(pf_handle* h) {
+  if (!h) return PF_OK;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->ev) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  if (h->own_c) {
+    if (h->c[0]) (void)hipFree(h->c[0]);
+    if (h->c[1]) (void)hipFree(h->c[1]);
+  }
+  if (h->mu_scratch) (void)hipFree(h->mu_scratch);
+  if (h->partials) (void)hipFree(h->partials);
+  if (h->out6_dev) (void)hipFree(h->out6_dev);
+  if (h->out6_host) (void)hipHostFree(h->out6_host);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return PF_OK;
+}
+
+static int set_ic(pf_handle* h, double c0, double amp, double w0) {
+  if (!h) return PF_ERR_INVALID;
+  if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  const Geometry& g = h->g;
+  PF_HIP(h, launch_ic(h->c[h->cur], g.nx, g.ny, g.nz, g.ghost, h->cfg.h, c0, amp, w0, g.mirror ? g.np[0] : 0,
+                      g.mirror ? g.np[1] : 0, h->stream));
+  h->have_prev = false;
+  return PF_OK;
+}
+
+int pf_set_ic_bm1(pf_handle* h, double c0, double eps) { return set_ic(h, c0, eps, 0.105); }
+int pf_set_ic_bm6(pf_handle* h, double c0, double c1) { return set_ic(h, c0, c1, 0.2); }
+
+int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
+  if (!h || !host) return PF_ERR_INVALID;
+  if (field != PF_FIELD_C) return fail(h, PF_ERR_UNSUPPORTED, "only PF_FIELD_C can be set");
+  if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  const Geometry& g = h->g;
+  double* dst = h->c[h->cur] + (int64_t)g.ghost * g.plane;
+  if (!g.mirror) {
+    if ((int64_t)n != g.plane * g.nz) return fail(h, PF_ERR_INVALID, "pf_set_field: wrong element count");
+    PF_HIP(h, hipMemcpyAsync(dst, host, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+  } else {
+    if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+      return fail(h, PF_ERR_INVALID, "pf_set_field: wrong element count (mirror: nodes of the physical domain)");
+    std::vector<double> ext((size_t)(g.plane * g.nz));
+    auto refl = [](int i, int np) { return i < np ? i : 2 * (np - 1) - i; };
+    for (int z = 0; z < g.nz; ++z) {
+      const int zs = h->cfg.dim == 3 ? refl(z, g.np[2]) : 0;
+      for (int y = 0; y < g.ny; ++y) {
+        const int ys = refl(y, g.np[1]);
+        const double* src = host + ((int64_t)zs * g.np[1] + ys) * g.np[0];
+        double* d = ext.data() + ((int64_t)z * g.ny + y) * g.nx;
+        for (int x = 0; x < g.nx; ++x) d[x] = src[refl(x, g.np[0])];
+      }
+    }
+    PF_HIP(h, hipMemcpyAsync(dst, ext.data(), sizeof(double) * ext.size(), hipMemcpyHostToDevice, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  h->have_prev = false;
+  return PF_OK;
+}
+
+int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
+  if (!h || !host) return PF_ERR_INVALID;
+  if (field != PF_FIELD_C) return fail(h, PF_ERR_UNSUPPORTED, "only PF_FIELD_C can be read in this build");
+  const Geometry& g = h->g;
+  const double* src = h->c[h->cur] + (int64_t)g.ghost * g.plane;
+  if (!g.mirror) {
+    if ((int64_t)n != g.plane * g.nz) return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count");
+    PF_HIP(h, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+  } else {
+    if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+      return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count (mirror: nodes of the physical domain)");
+    std::vector<double> ext((size_t)(g.plane * g.nz));
+    PF_HIP(h, hipMemcpyAsync(ext.data(), src, sizeof(double) * ext.size(), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    for (int z = 0; z < g.np[2]; ++z)
+      for (int y = 0; y < g.np[1]; ++y)
+        std::memcpy(host + ((int64_t)z * g.np[1] + y) * g.np[0], ext.data() + ((int64_t)z * g.ny + y) * g.nx,
+                    sizeof(double) * g.np[0]);
+  }
+  return PF_OK;
+}
+
+int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
+  if (!h) return PF_ERR_INVALID;
+  if (nsteps < 0 || !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step: need dt > 0 and nsteps >= 0");
+  if (h->cfg.nranks != 1) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
+  for (int s = 0; s < nsteps; ++s) {
+    int rc = launch_step(h, dt, 0, h->g.nz);
+    if (rc) return rc;
+    h->cur ^= 1;
+    h->have_prev = true;
+  }
+  if (info) {
+    double raw[6];
+    int rc = run_diag(h, raw);
+    if (rc) return rc;
+    info->nsteps = nsteps;
+    info->cmin = raw[4];
+    info->cmax = raw[5];
+    info->ok = (std::isfinite(raw[0]) && std::isfinite(raw[1]) && raw[4] >= -1.0 && raw[5] <= 2.0) ? 1 : 0;
+  }
+  return PF_OK;
+}
+
+int pf_rollback(pf_handle* h) {
+  if (!h) return PF_ERR_INVALID;
+  if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (!h->have_prev) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
+  h->cur ^= 1;
+  h->have_prev = false;
+  return PF_OK;
+}
+
+int pf_sync(pf_handle* h) {
+  if (!h) return PF_ERR_INVALID;
+  PF_HIP(h, hipStreamSynchronize(h->stream));
+  return PF_OK;
+}
+
+int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out) {
+  if (!h || !out) return PF_ERR_INVALID;
+  const Geometry& g = h->g;
+  if (g.ghost == 0) return fail(h, PF_ERR_STATE, "no ghost planes (nranks == 1)");
+  out->base = h->c[h->cur];
+  out->plane_elems = g.plane;
+  out->ghost = g.ghost;
+  out->n_local = g.nz;
+  out->recv_lo_off = 0;
+  out->send_lo_off = (int64_t)g.ghost * g.plane;
+  out->send_hi_off = (int64_t)g.nz * g.plane;  // planes nz-ghost .. nz-1 live at buffer planes nz .. nz+ghost-1
+  out->recv_hi_off = (int64_t)(g.nz + g.ghost) * g.plane;
+  out->rank_lo = (h->cfg.rank + h->cfg.nranks - 1) % h->cfg.nranks;
+  out->rank_hi = (h->cfg.rank + 1) % h->cfg.nranks;
+  out->cur_index = h->cur;
+  out->reserved0 = 0;
+  return PF_OK;
+}
+
+int pf_step_begin(pf_handle* h, double dt) {
+  if (!h) return PF_ERR_INVALID;
+  if (!(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step_begin: need dt > 0");
+  if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_begin: not in slab mode");
+  if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
+  const int g = h->g.ghost, nz = h->g.nz;
+  int rc = launch_step(h, dt, g, nz - g);  // interior planes need owned data only
+  if (rc) return rc;
+  h->step_open = true;
+  h->open_dt = dt;
+  return PF_OK;
+}
+
+int pf_step_finish(pf_handle* h) {
+  if (!h) return PF_ERR_INVALID;
+  if (!h->step_open) return fail(h, PF_ERR_STATE, "pf_step_finish without pf_step_begin");
+  const int g = h->g.ghost, nz = h->g.nz;
+  int rc;
+  if (nz - g > g) {
+    rc = launch_step(h, h->open_dt, 0, g);
+    if (rc) return rc;
+    rc = launch_step(h, h->open_dt, nz - g, nz);
+    if (rc) return rc;
+  } else {
+    rc = launch_step(h, h->open_dt, 0, nz);
+    if (rc) return rc;
+  }
+  h->cur ^= 1;
+  h->have_prev = true;
+  h->step_open = false;
+  return PF_OK;
+}
+
+int pf_diagnostics_local(pf_handle* h, double out[3]) {
+  if (!h || !out) return PF_ERR_INVALID;
+  if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  double raw[6];
+  int rc = run_diag(h, raw);
+  if (rc) return rc;
+  scale_diag(h, raw, out);
+  return PF_OK;
+}
+
+int pf_diagnostics(pf_handle* h, double out[3]) {
+  if (!h || !out) return PF_ERR_INVALID;
+  if (h->cfg.nranks != 1)
+    return fail(h, PF_ERR_STATE, "pf_diagnostics: slab mode uses pf_diagnostics_local + a sum over ranks");
+  return pf_diagnostics_local(h, out);
+}
+
+int pf_timing_enable(pf_handle* h, int on) {
+  if (!h) return PF_ERR_INVALID;
+  if (on && h->ev.empty()) {
+    h->ev.resize(256);
+    for (auto& e : h->ev) {
+      PF_HIP(h, hipEventCreate(&e.first));
+      PF_HIP(h, hipEventCreate(&e.second));
+    }
+  }
+  if (!on) {
+    int rc = timing_flush(h);
+    if (rc) return rc;
+  }
+  h->timing = on != 0;
+  return PF_OK;
+}
+
+int pf_timing_read(pf_handle* h, double* avg_ms, int64_t* launches) {
+  if (!h || !avg_ms || !launches) return PF_ERR_INVALID;
+  int rc = timing_flush(h);
+  if (rc) return rc;
+  *launches = h->t_launches;
+  *avg_ms = h->t_launches ? h->t_ms / (double)h->t_launches : 0.0;
+  h->t_ms = 0.0;
+  h->t_launches = 0;
+  return PF_OK;
+}
+
+int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx, int ny, int nz, int ghost, int zwrap,
+                   int zlo, int zhi, const pfk_ch_params* p, int impl, void* stream) {
+  if (!c_in || !c_out || !p || nx < 1 || ny < 1 || nz < 1 || ghost < 0 || zlo < 0 || zhi > nz || zlo > zhi)
+    return fail(nullptr, PF_ERR_INVALID, "pfk_ch_fd_step: bad arguments");
+  if (!zwrap && ghost < 2) return fail(nullptr, PF_ERR_INVALID, "pfk_ch_fd_step: ghost >= 2 required without zwrap");
+  FdArgs a;
+  a.cin = c_in;
+  a.cout = c_out;
+  a.phi = phi;
+  a.nx = nx;
+  a.ny = ny;
+  a.nz = nz;
+  a.ghost = ghost;
+  a.zwrap = zwrap;
+  a.zlo = zlo;
+  a.zhi = zhi;
+  a.ca = p->c_alpha;
+  a.cb = p->c_beta;
+  a.two_rho = p->two_rho;
+  a.kh2 = p->kappa_over_h2;
+  a.amh2 = p->dtM_over_h2;
+  a.kphi = p->k_phi;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (impl == PF_KERNEL_AUTO) impl = ch_fd_fused_supported(a) ? PF_KERNEL_FUSED : PF_KERNEL_TWOPASS;
+  if (impl == PF_KERNEL_FUSED) {
+    if (!ch_fd_fused_supported(a))
+      return fail(nullptr, PF_ERR_UNSUPPORTED, "fused FD kernel needs even nx and 16-byte aligned buffers");
+    PF_HIP(nullptr, launch_ch_fd_fused(a, s));
+    return PF_OK;
+  }
+  if (impl != PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "pfk_ch_fd_step: bad impl");
+  // stateless entry point: scratch for mu is allocated per call (this is the slow reference path)
+  double* mu = nullptr;
+  const int64_t elems = (int64_t)nx * ny * (zhi - zlo + 2);
+  PF_HIP(nullptr, hipMalloc(&mu, sizeof(double) * elems));
+  hipError_t e = launch_ch_fd_twopass(a, mu, s);
+  hipError_t e2 = hipStreamSynchronize(s);
+  (void)hipFree(mu);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("twopass launch: ") + hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("twopass sync: ") + hipGetErrorString(e2));
+  return PF_OK;
+}
+
+int pfk_set_tuning(int key, int value) {
+  if (key == 0) {
+    set_fused_variant(value);
+    return PF_OK;
+  }
+  return PF_ERR_INVALID;
+}
+
+}  // extern "C"

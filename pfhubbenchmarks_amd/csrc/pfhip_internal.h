@@ -1,0 +1,43 @@
+// Internal declarations shared by the libpfhip translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "pfhip.h"
+
+namespace pfhip {
+
+// ---- arguments of the FD Cahn-Hilliard step launchers ---------------------------------------------------
+struct FdArgs {
+  const double* cin;
+  double* cout;
+  const double* phi;  // nullptr for BM1
+  int nx, ny, nz;     // owned extents (nz = planes of the slab axis)
+  int ghost;          // ghost planes per side present in the buffers
+  int zwrap;          // 1: periodic inside the buffer; 0: read ghost planes
+  int zlo, zhi;       // output plane range [zlo, zhi)
+  double ca, cb, two_rho, kh2, amh2, kphi;
+};
+
+// launchers (return hipError_t of the launch); all asynchronous on `stream`
+hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream);
+// mu_scratch: (zhi - zlo + 2) planes of nx*ny doubles
+hipError_t launch_ch_fd_twopass(const FdArgs& a, double* mu_scratch, hipStream_t stream);
+bool ch_fd_fused_supported(const FdArgs& a);
+
+// diagnostics: raw sums {sum c, sum f_chem, sum |fwd diff|^2, sum c*phi, min c, max c} -> out6 (device, 6 doubles)
+// partials: device scratch of diag_partials_elems() doubles
+int diag_partials_elems();
+hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, double rho,
+                       double ca, double cb, double* partials, double* out6, hipStream_t stream);
+
+// initial condition (pfbase.py:187-189 / :332-334), z-extruded; writes owned planes [0, nz) of a ghosted buffer
+// mnx, mny > 0: lattice is the even extension of a no-flux domain with mnx x mny nodes (index reflection)
+hipError_t launch_ic(double* c, int nx, int ny, int nz, int ghost, double h, double c0, double amp, double w0,
+                     int mnx, int mny, hipStream_t stream);
+void set_fused_variant(int v);
+
+}  // namespace pfhip

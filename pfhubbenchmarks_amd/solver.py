@@ -1,0 +1,310 @@
+"""Host-side solver objects over the libpfhip C ABI.
+
+`PhaseFieldSolver`  -- one GPU, whole domain (periodic or mirror/no-flux).  Replaces, for the reference's driver
+                       loop (dolfin/bench1.py:145-198), the FEniCS objects `problem`/`solver`/`w`/`w0` and the two
+                       `df.assemble` diagnostics.
+`SlabSolver`        -- one process per GPU, 1-D slab decomposition along z with ghost-plane exchange through
+                       torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+                       Replaces what DOLFIN/PETSc do implicitly under `mpirun -np N` (README.md:22): mesh
+                       partition + ghost scatter per operator application + MPI_Allreduce inside df.assemble.
+
+The compute engine behind `SlabSolver` is an object with the small interface of `HipSlabEngine`; the product
+engine is HIP-only (no CPU fallback).  tests/ inject an oracle-backed engine to exercise the exchange logic on CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def stable_dt(h, M=5.0, kappa=2.0, dim=2, safety=0.5):
+    """Forward-Euler limit of the fused FD step: the stiffest mode of dt*M*kappa*lap_h^2 is (4 dim / h^2)^2,
+    so dt < 2 h^4 / (16 dim^2 M kappa); `safety` scales it (the f'' term moves the limit slightly)."""
+    return safety * 2.0 * h ** 4 / (16.0 * dim * dim * M * kappa)
+
+
+class PhaseFieldSolver:
+    """Single-GPU solver handle (pf_create .. pf_destroy)."""
+
+    def __init__(self, dim=2, n=512, h=1.0, bc="periodic", scheme="fd", model="bm1", kernel="auto", device=0,
+                 stream=None, **params):
+        self._lib = _lib.load()
+        n3 = list(n) if isinstance(n, (tuple, list)) else [n] * dim
+        cfg = _lib.default_config(dim, int(n3[0]), float(h))
+        for d in range(dim):
+            cfg.n[d] = int(n3[d])
+        cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
+        cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI}[scheme]
+        cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6}[model]
+        cfg.kernel = {"auto": _lib.PF_KERNEL_AUTO, "fused": _lib.PF_KERNEL_FUSED,
+                      "twopass": _lib.PF_KERNEL_TWOPASS}[kernel]
+        cfg.device = int(device)
+        for k, v in params.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown model parameter %r" % k)
+            setattr(cfg, k, float(v))
+        if stream is not None:
+            cfg.stream = C.c_void_p(int(stream))
+        self.cfg = cfg
+        self.dim = dim
+        self.shape = tuple(int(cfg.n[d]) for d in reversed(range(dim)))  # numpy order (z, y, x) / (y, x)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        self.nelem = int(self._lib.pf_field_elems(C.byref(cfg)))
+        self.t = 0.0
+
+    # -- life cycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        return _lib.check(rc, self._h)
+
+    # -- state
+    def set_ic_bm1(self, c0=0.5, eps=0.05):
+        self._ck(self._lib.pf_set_ic_bm1(self._h, c0, eps))
+        self.t = 0.0
+
+    def set_ic_bm6(self, c0=0.5, c1=0.04):
+        self._ck(self._lib.pf_set_ic_bm6(self._h, c0, c1))
+        self.t = 0.0
+
+    def set_c(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a.size != self.nelem:
+            raise ValueError("set_c: expected %d values (shape %s), got %s" % (self.nelem, self.shape, a.shape))
+        self._ck(self._lib.pf_set_field(self._h, _lib.PF_FIELD_C, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_c(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        self._ck(self._lib.pf_get_field(self._h, _lib.PF_FIELD_C, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    # -- stepping
+    def step(self, dt, nsteps=1, check=False):
+        """Advance; with check=True returns (ok, cmin, cmax) like the reference's `converged` flag."""
+        if check:
+            info = _lib.PfStepInfo()
+            self._ck(self._lib.pf_step(self._h, float(dt), int(nsteps), C.byref(info)))
+            self.t += dt * nsteps
+            return bool(info.ok), info.cmin, info.cmax
+        self._ck(self._lib.pf_step(self._h, float(dt), int(nsteps), None))
+        self.t += dt * nsteps
+        return None
+
+    def rollback(self):
+        self._ck(self._lib.pf_rollback(self._h))
+
+    def sync(self):
+        self._ck(self._lib.pf_sync(self._h))
+
+    def diagnostics(self):
+        """(total_free_energy, total_solute, f_elec part) -- dolfin/bench1.py:121-125."""
+        out = (C.c_double * 3)()
+        self._ck(self._lib.pf_diagnostics(self._h, out))
+        return out[0], out[1], out[2]
+
+    # -- measurement
+    def timing(self, on=True):
+        self._ck(self._lib.pf_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._lib.pf_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def slab_partition(n_planes, nranks, rank):
+    """(first, count) of the planes a rank owns -- pf_slab_partition (pure host code in libpfhip)."""
+    lib = _lib.load()
+    f, c = C.c_int(), C.c_int()
+    rc = lib.pf_slab_partition(n_planes, nranks, rank, C.byref(f), C.byref(c))
+    if rc != 0:
+        raise ValueError("pf_slab_partition(%d, %d, %d) failed" % (n_planes, nranks, rank))
+    return f.value, c.value
+
+
+class HipSlabEngine:
+    """One rank's slab on one GPU.  Field storage is two torch CUDA tensors (nz_local + 4, ny, nx) handed to
+    libpfhip as raw device pointers (pf_config.ext_c), so torch.distributed can send / receive the ghost planes
+    in place.  Kernels run on `self.stream` (a torch stream)."""
+
+    ghost = 2
+
+    def __init__(self, n, h, nranks, rank, device, **params):
+        import torch
+        self.torch = torch
+        self._lib = _lib.load()
+        nx, ny, nz = (n, n, n) if isinstance(n, int) else n
+        cfg = _lib.default_config(3, int(nx), float(h))
+        cfg.n[0], cfg.n[1], cfg.n[2] = int(nx), int(ny), int(nz)
+        cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
+        for k, v in params.items():
+            setattr(cfg, k, float(v))
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.z0, self.nz = slab_partition(nz, nranks, rank)
+        self.nx, self.ny, self.nz_global = nx, ny, nz
+        elems = int(self._lib.pf_field_elems_with_ghosts(C.byref(cfg)))
+        assert elems == (self.nz + 2 * self.ghost) * ny * nx
+        self.buffers = [torch.zeros((self.nz + 2 * self.ghost, ny, nx), dtype=torch.float64, device=self.device)
+                        for _ in range(2)]
+        self.stream = torch.cuda.Stream(device=self.device)
+        cfg.stream = C.c_void_p(self.stream.cuda_stream)
+        cfg.ext_c[0] = C.c_void_p(self.buffers[0].data_ptr())
+        cfg.ext_c[1] = C.c_void_p(self.buffers[1].data_ptr())
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        self.rank_lo = (rank - 1) % nranks
+        self.rank_hi = (rank + 1) % nranks
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        return _lib.check(rc, self._h)
+
+    @property
+    def cur(self):
+        lay = _lib.PfHaloLayout()
+        self._ck(self._lib.pf_halo_layout_get(self._h, C.byref(lay)))
+        assert lay.base == self.buffers[lay.cur_index].data_ptr()
+        return lay.cur_index
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def set_ic_bm1(self, c0=0.5, eps=0.05):
+        self._ck(self._lib.pf_set_ic_bm1(self._h, c0, eps))
+
+    def set_local(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        self._ck(self._lib.pf_set_field(self._h, _lib.PF_FIELD_C, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get_local(self):
+        out = np.empty((self.nz, self.ny, self.nx), dtype=np.float64)
+        self._ck(self._lib.pf_get_field(self._h, _lib.PF_FIELD_C, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def step_begin(self, dt):
+        self._ck(self._lib.pf_step_begin(self._h, float(dt)))
+
+    def step_finish(self):
+        self._ck(self._lib.pf_step_finish(self._h))
+
+    def diag_local(self):
+        out = (C.c_double * 3)()
+        self._ck(self._lib.pf_diagnostics_local(self._h, out))
+        return [out[0], out[1], out[2]]
+
+    def sync(self):
+        self._ck(self._lib.pf_sync(self._h))
+
+    def timing(self, on=True):
+        self._ck(self._lib.pf_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._lib.pf_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class SlabSolver:
+    """Slab-decomposed stepping: exchange of the 2 ghost planes per side overlapped with the interior kernel.
+
+    per step:   post isend/irecv of the boundary planes of the CURRENT buffer  (RCCL's own stream / gloo threads)
+                pf_step_begin   -> interior planes [2, nz-2): need owned planes only, run meanwhile
+                wait for the exchange (the compute stream waits, not the host, on the nccl backend)
+                pf_step_finish  -> planes [0,2) and [nz-2,nz), buffer swap
+    """
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.engine = engine
+        self.group = group
+        self.ghosts_fresh = False
+        self.t = 0.0
+
+    def _post_exchange(self):
+        dist, e = self.dist, self.engine
+        g, nz = e.ghost, e.nz
+        buf = e.buffers[e.cur]
+        send_lo, send_hi = buf[g:2 * g], buf[nz:nz + g]
+        recv_lo, recv_hi = buf[0:g], buf[nz + g:nz + 2 * g]
+        # order matters when both neighbours are the same rank (world size 2): "up" message first on both sides
+        ops = [dist.P2POp(dist.isend, send_hi, e.rank_hi, self.group, 1),
+               dist.P2POp(dist.isend, send_lo, e.rank_lo, self.group, 2),
+               dist.P2POp(dist.irecv, recv_lo, e.rank_lo, self.group, 1),
+               dist.P2POp(dist.irecv, recv_hi, e.rank_hi, self.group, 2)]
+        return dist.batch_isend_irecv(ops)
+
+    def exchange(self):
+        """Blocking ghost refresh of the current buffer (used before diagnostics)."""
+        if self.ghosts_fresh:
+            return
+        with self.engine.stream_context():
+            for r in self._post_exchange():
+                r.wait()
+        self.ghosts_fresh = True
+
+    def step(self, dt, nsteps=1):
+        e = self.engine
+        for _ in range(nsteps):
+            with e.stream_context():
+                reqs = [] if self.ghosts_fresh else self._post_exchange()
+                e.step_begin(dt)
+                for r in reqs:
+                    r.wait()
+                e.step_finish()
+            self.ghosts_fresh = False
+            self.t += dt
+
+    def diagnostics(self):
+        """(total_free_energy, total_solute, f_elec) summed over ranks (the reference's implicit MPI_Allreduce)."""
+        import torch
+        self.exchange()
+        loc = self.engine.diag_local()
+        dev = self.engine.buffers[0].device
+        t = torch.tensor(loc, dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        v = t.cpu().tolist()
+        return v[0], v[1], v[2]
+
+    def gather_field(self):
+        """Whole field on every rank (testing / small runs only)."""
+        import torch
+        loc = torch.from_numpy(self.engine.get_local())
+        world = self.dist.get_world_size(self.group)
+        if self.dist.get_backend(self.group) == "nccl":
+            loc = loc.to(self.engine.buffers[0].device)
+        sizes = [slab_partition(self.engine.nz_global, world, r)[1] for r in range(world)]
+        parts = [torch.empty((s,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device) for s in sizes]
+        self.dist.all_gather(parts, loc, group=self.group)
+        return torch.cat(parts, 0).cpu().numpy()

@@ -1,0 +1,38 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-N gloo job (CPU) running SlabSolver over the
+oracle-backed engine.  Usage: python tests/dist_worker.py <out_prefix> <nsteps>   (env: RANK WORLD_SIZE MASTER_*)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch.distributed as dist
+    from oracle_engine import OracleSlabEngine
+    from pfhubbenchmarks_amd.solver import SlabSolver
+    out, nsteps = sys.argv[1], int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = (16, 10, 12)
+    eng = OracleSlabEngine(n, 1.0, world, rank)
+    rng = np.random.default_rng(3)
+    full = 0.5 + 0.1 * rng.standard_normal((n[2], n[1], n[0]))
+    eng.set_local(full[eng.z0:eng.z0 + eng.nz])
+    s = SlabSolver(eng)
+    d0 = s.diagnostics()
+    s.step(1e-3, nsteps)
+    d1 = s.diagnostics()
+    s.step(1e-3, 1)          # a step right after diagnostics re-uses the fresh ghosts
+    field = s.gather_field()
+    if rank == 0:
+        np.savez(out, field=field, d0=np.array(d0), d1=np.array(d1), full=full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""The FEM / backward-Euler oracle (oracle/fem_be.py) against the reference's committed result files.
+
+These are the golden vectors that pin parity: results/bench1_out.csv, results/bench6_out.csv,
+results/bench1/conc00000N.vtu and results/bench6/{conc,phi}00000N.vtu, decoded by tests/golden/make_golden.py.
+The CPU suite checks the leading rows (the full 73-row BM1 trajectory takes ~6 min: see oracle/logs/, all rows
+<= 4.98e-9 relative in F); set PF_ORACLE_FULL=1 to run everything here.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fem_be
+
+FULL = os.environ.get("PF_ORACLE_FULL", "0") == "1"
+
+
+def _csv(golden_dir, name):
+    return np.loadtxt(os.path.join(golden_dir, name), delimiter=",", skiprows=1)
+
+
+def test_mesh_numbering_matches_reference_vtu(golden_dir):
+    d = np.load(os.path.join(golden_dir, "bm1_fields.npz"))
+    m = fem_be.CrossedMesh(200.0, 100)
+    assert m.n == 20201 and m.ntri == 40000
+    np.testing.assert_array_equal(np.stack([m.x[:8], m.y[:8]], 1), d["points_head"][:, :2])
+    np.testing.assert_array_equal(np.stack([m.x[10201:10205], m.y[10201:10205]], 1), d["points_centre_head"][:, :2])
+    np.testing.assert_array_equal(m.tri[:8], d["conn_head"])
+
+
+def test_known_answers_at_t0():
+    # P1 / Strang-Fix functional of the interpolated BM1 initial condition (SURVEY.md 8c known-answer scalars)
+    s = fem_be.FemBE("bm1")
+    F, C = s.diagnostics()
+    assert abs(F - 297.6736899201) < 2e-9
+    assert abs(C - 20504.4690550850) < 2e-9
+    s6 = fem_be.FemBE("bm6")
+    assert abs(s6.diagnostics()[1] - 5096.8562678) < 1e-6
+
+
+def test_stiffness_and_mass_stencils():
+    # two-sublattice stencils on the crossed mesh at h = 2
+    m = fem_be.CrossedMesh(200.0, 100)
+    K, M = m.K.tocsr(), m.Mass.tocsr()
+    i = 50 + 101 * 50                      # interior corner node
+    assert abs(K[i, i] - 4.0) < 1e-12 and abs(K[i, i + 1]) < 1e-12
+    assert abs(M[i, i] - 4.0 / 3.0) < 1e-12 and abs(M[i, i + 1] - 1.0 / 6.0) < 1e-12
+    c = m.n_corner + 50 + 100 * 50         # a centre node
+    assert abs(K[c, c] - 4.0) < 1e-12 and abs(M[c, c] - 2.0 / 3.0) < 1e-12
+    assert abs(K.sum()) < 1e-9 and abs(M.sum() - 200.0 * 200.0) < 1e-6
+
+
+def test_bm1_trajectory_and_fields(golden_dir):
+    csv = _csv(golden_dir, "bench1_out.csv")
+    assert csv.shape == (73, 3)
+    fields = np.load(os.path.join(golden_dir, "bm1_fields.npz"))
+    nrows = 73 if FULL else 6
+    s = fem_be.FemBE("bm1")
+    frames = {}
+
+    def cb(solver, its):
+        for k, tf in enumerate(fields["times"]):
+            if abs(solver.t - tf) < 1e-9:
+                frames[k] = solver.c.copy()
+    rows = s.run_on_time_grid(csv[:nrows, 0], cb)
+    relF = np.abs(rows[:, 1] - csv[:nrows, 1]) / csv[:nrows, 1]
+    relC = np.abs(rows[:, 2] - csv[:nrows, 2]) / csv[:nrows, 2]
+    assert relF.max() < 1e-8, relF          # measured: <= 4.98e-9 over all 73 rows
+    assert relC.max() < 1e-9, relC          # the reference itself drifts 6e-10
+    assert len(frames) == 6
+    for k, c in frames.items():
+        assert np.abs(c - fields["c"][k]).max() < 5e-9      # measured 2.3e-9
+
+
+def test_bm6_trajectory_and_fields(golden_dir):
+    csv = _csv(golden_dir, "bench6_out.csv")
+    assert csv.shape == (14, 3)
+    fields = np.load(os.path.join(golden_dir, "bm6_fields.npz"))
+    nrows = 14 if FULL else 3
+    s = fem_be.FemBE("bm6")
+    frames = {}
+
+    def cb(solver, its):
+        for k, tf in enumerate(fields["times"]):
+            if abs(solver.t - tf) < 1e-9:
+                frames[k] = (solver.c.copy(), solver.phi.copy())
+    rows = s.run_on_time_grid(csv[:nrows, 0], cb)
+    relF = np.abs(rows[:, 1] - csv[:nrows, 1]) / csv[:nrows, 1]
+    relC = np.abs(rows[:, 2] - csv[:nrows, 2]) / csv[:nrows, 2]
+    assert relF.max() < 1e-6, relF          # measured: 6e-9 .. 5.6e-7 (the VTU run and the CSV run differ by 1e-7)
+    assert relC.max() < 1e-9, relC
+    for k, (c, phi) in frames.items():      # field frames come from a different reference run: ~1e-7 agreement
+        assert np.abs(c - fields["c"][k]).max() < 5e-6
+        assert np.abs(phi - fields["phi"][k]).max() < 5e-6
