@@ -34,6 +34,7 @@ def cpu_baseline(nx, ny, nz_sample, dt, steps):
     import numpy as np
     from oracle import ch_fd
     ch_fd.load()
+    threads = ch_fd.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")))   # default: the cores we really own
     c = ch_fd.ic(nx, ny, 1)
     c = np.repeat(c, nz_sample, 0)
     c = ch_fd.fd_step(c, dt)          # warm-up (page faults, OpenMP pool)
@@ -41,10 +42,43 @@ def cpu_baseline(nx, ny, nz_sample, dt, steps):
     for _ in range(steps):
         c = ch_fd.fd_step(c, dt)
     el = time.perf_counter() - t0
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": nx * ny * nz_sample * steps / el, "unit": "cell-updates/s", "cores": threads, "kind": "port",
             "sample": "%dx%dx%d periodic block of the BM1 IC, %d steps, oracle/ch_fd.c (gcc -O2 -fopenmp), %.1f s"
                       % (nx, ny, nz_sample, steps, el)}
+
+
+def cpu_baseline_spectral(n, dt, steps):
+    """numpy (pocketfft, one thread) restatement of the same semi-implicit spectral step on the same grid."""
+    from oracle import ch_fd, ch_spectral
+    c = ch_fd.ic(n[0], n[1], n[2] if len(n) == 3 else 1)
+    c = c if len(n) == 3 else c[0]
+    sp = ch_spectral.SpectralCH(c, h=1.0)
+    sp.step(dt, 2)
+    t0 = time.perf_counter()
+    sp.step(dt, steps)
+    el = time.perf_counter() - t0
+    cells = 1
+    for v in n:
+        cells *= v
+    return {"value": cells * steps / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": "%s grid, %d steps, oracle/ch_spectral.py (numpy pocketfft), %.1f s" % ("x".join(map(str, n)),
+                                                                                             steps, el)}
+
+
+def measured_traffic(workload, variant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
+    separate runs, FETCH_SIZE x2 per MI355X_MICROARCH.md) of THIS workload with the default kernel variant;
+    None when no such profile is committed."""
+    if variant >= 0:
+        return None
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, rnd, "summary_%s.json" % workload)
+        if os.path.exists(f):
+            with open(f) as fh:
+                best = json.load(fh)
+    return None if best is None else best.get("traffic_bytes_per_launch")
 
 
 def main():
@@ -52,9 +86,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s"])
+    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
+    ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
+    ap.add_argument("--min-chunk", type=int, default=0, help="pfk_set_tuning key 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -76,9 +112,22 @@ def main():
     torch.cuda.set_device(local_rank)
     if a.variant >= 0:
         lib.pfk_set_tuning(0, a.variant)
+    if a.target_wgs > 0:
+        lib.pfk_set_tuning(1, a.target_wgs)
+    if a.min_chunk > 0:
+        lib.pfk_set_tuning(2, a.min_chunk)
 
     h = 1.0
-    if a.workload == "bm1_fd_512s":
+    scheme, bytes_per_cell = "fd", BYTES_PER_CELL_UPDATE
+    if a.workload in ("bm1_spectral_512s", "bm1_spectral_256c"):
+        # BASELINE.json config 2: semi-implicit spectral; 72 B/cell-update = one-pass-per-transform idealisation
+        # (f' 16 + r2c 16 + k-space 24 + c2r 16) -- 512^2 is launch-latency bound, not HBM bound
+        scheme, bytes_per_cell = "spectral", 72.0
+        dim, gn, scaling = (2, (512, 512, 1), "weak") if a.workload.endswith("512s") else (3, (256, 256, 256), "weak")
+        dt = 1e-2
+        if world > 1:
+            sys.exit("the spectral scheme is single-GPU in this build")
+    elif a.workload == "bm1_fd_512s":
         dim, gn, scaling = 2, (512, 512, 1), "weak"
         dt = 1e-3
     elif a.workload == "bm1_fd_512c":
@@ -107,7 +156,7 @@ def main():
             dist.barrier()
     else:
         n = gn[:dim]
-        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank)
+        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank, scheme=scheme)
         s.set_ic_bm1(0.5, 0.05)
         solver = timer = s
         local_cells = gn[0] * gn[1] * gn[2]
@@ -140,26 +189,32 @@ def main():
     # dominant kernel: all step launches of this rank (1 per step on one GPU; interior + 2 boundary launches per
     # step in slab mode, summed)
     kernel_s_per_step = k_ms * 1e-3 * k_launches / max(a.steps, 1)
-    achieved = BYTES_PER_CELL_UPDATE * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+    achieved = bytes_per_cell * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
     out = {
-        "metric": "cell-updates/sec on PFHub BM1 Cahn-Hilliard (explicit FD, fused HIP stencil)",
+        "metric": "cell-updates/sec on PFHub BM1 Cahn-Hilliard (%s)" % (
+            "explicit FD, fused HIP stencil" if scheme == "fd" else "semi-implicit spectral, rocFFT + HIP k-space"),
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit",
-                   "kernel": a.kernel, "variant": a.variant, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
+        "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
+                   "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
                    "parallelism": "slab%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": measured_traffic(a.workload, a.variant) if world == 1 else None,
+                     "traffic_source": "profiles/r*/summary_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
+                                       "bytes per launch)" % a.workload,
                      "kernel_ms_per_step": kernel_s_per_step * 1e3, "launches_per_step": k_launches / max(a.steps, 1),
-                     "bytes_per_cell_update": BYTES_PER_CELL_UPDATE},
+                     "bytes_per_cell_update": bytes_per_cell},
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and scheme == "spectral":
+        out["cpu_baseline"] = cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8)
+    elif rank == 0 and world == 1 and not a.no_cpu_baseline:
         if dim == 3:
-            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 32, dt, 6)
+            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 64, dt, 80)
         else:
-            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 1, dt, 400)
+            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 1, dt, 4000)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -167,7 +167,8 @@ typedef struct pfk_ch_params {
 int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx, int ny, int nz, int ghost,
                    int zwrap, int zlo, int zhi, const pfk_ch_params* p, int impl, void* stream);
 
-/* tuning hook for benchmarks: key 0 = fused-kernel variant (0: 8 waves x 2 rows, 1: 4 waves x 4 rows) */
+/* tuning hooks for benchmarks: key 0 = fused-kernel variant (table in csrc/ch_fd_kernels.hip);
+ * key 1 = target number of workgroups for the z-chunk split; key 2 = minimum planes per z-chunk */
 int pfk_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -25,6 +25,20 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* number of OpenMP threads the step uses (0 = leave the runtime default); returns the count in effect */
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 typedef struct orc_ch_params {
   double c_alpha, c_beta, two_rho;

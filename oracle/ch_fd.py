@@ -50,10 +50,39 @@ def load():
     lib.orc_ch_diag.restype = C.c_int
     lib.orc_ch_diag.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                 C.c_double, C.POINTER(C.c_double)]
+    lib.orc_set_threads.restype = C.c_int
+    lib.orc_set_threads.argtypes = [C.c_int]
     lib.orc_ic.restype = C.c_int
     lib.orc_ic.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
     _lib = lib
     return lib
+
+
+def host_cores():
+    """CPU cores this process may really use: min(affinity, cgroup quota) -- os.cpu_count() over-reports on a
+    GPU box whose container owns a 16-core share of a 256-thread host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def set_threads(n=0):
+    """OpenMP threads for the C oracle; n = 0 -> host_cores().  Returns the count in effect."""
+    return load().orc_set_threads(int(n) if n > 0 else host_cores())
 
 
 def make_params(dt, h=1.0, rho_s=5.0, c_alpha=0.3, c_beta=0.7, kappa=2.0, M=5.0, k_phi=0.0):

@@ -1,0 +1,68 @@
+"""ORACLE (test infrastructure, not product code) -- numpy restatement of the semi-implicit Fourier-spectral
+Cahn-Hilliard step implemented by pfhubbenchmarks_amd/csrc/spectral.hip (BASELINE.json config 2).
+
+  c_t = M lap(f'(c) - kappa lap c)        dolfin/pfbase.py:361-383; f' = d/dc of dolfin/bench1.py:64
+  c^+_k = (c_k - dt M k^2 N_k) / (1 + dt M kappa k^4),  N = f'(c^n),  k = 2 pi m / (n h)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.  pocketfft (numpy) and rocFFT
+round differently, so the HIP path is compared at 1e-11 relative, not bitwise.  Physics check: this scheme at small dt
+converges to the same PDE solution as the reference's FEM backward Euler (tests/test_oracle_fd.py).
+"""
+import numpy as np
+
+
+def fprime(c, rho_s=5.0, c_alpha=0.3, c_beta=0.7):
+    a, b = c - c_alpha, c_beta - c
+    return (2.0 * rho_s) * ((a * b) * (b - a))
+
+
+def ksq(shape, h):
+    """k^2 on the half spectrum of np.fft.rfftn for a field of `shape` (last axis halved)."""
+    axes = []
+    for ax, n in enumerate(shape):
+        if ax == len(shape) - 1:
+            m = np.arange(n // 2 + 1)
+        else:
+            m = np.arange(n)
+            m = np.where(2 * m > n, m - n, m)
+        axes.append((2.0 * np.pi / (n * h)) * m)
+    k2 = np.zeros([len(a) for a in axes])
+    for ax, k in enumerate(axes):
+        sh = [1] * len(axes)
+        sh[ax] = len(k)
+        k2 = k2 + (k * k).reshape(sh)
+    return k2
+
+
+class SpectralCH:
+    """keeps c_k resident between steps exactly like the HIP path"""
+
+    def __init__(self, c, h=1.0, rho_s=5.0, c_alpha=0.3, c_beta=0.7, kappa=2.0, M=5.0):
+        self.c = np.array(c, dtype=np.float64)
+        self.h, self.kappa, self.M = h, kappa, M
+        self.model = dict(rho_s=rho_s, c_alpha=c_alpha, c_beta=c_beta)
+        self.k2 = ksq(self.c.shape, h)
+        self.chat = np.fft.rfftn(self.c)
+
+    def step(self, dt, nsteps=1):
+        for _ in range(nsteps):
+            ghat = np.fft.rfftn(fprime(self.c, **self.model))
+            self.chat = (self.chat - (dt * self.M) * self.k2 * ghat) / (1.0 + (dt * self.M * self.kappa) * self.k2 ** 2)
+            self.c = np.fft.irfftn(self.chat, s=self.c.shape, axes=tuple(range(self.c.ndim)))
+        return self.c
+
+    def diagnostics(self, mirror=False):
+        """(F, C): F = h^d [sum f_chem + kappa/2 * (1/N) sum_k k^2 |c_k|^2] (Parseval), C = h^d sum c."""
+        c = self.c
+        d = c.ndim
+        vol = self.h ** d * (0.5 ** d if mirror else 1.0)
+        m = self.model
+        f = m["rho_s"] * ((c - m["c_alpha"]) * (m["c_beta"] - c)) ** 2
+        chat = np.fft.rfftn(c)
+        n_last = c.shape[-1]
+        w = np.full(chat.shape[-1], 2.0)
+        w[0] = 1.0
+        if n_last % 2 == 0:
+            w[-1] = 1.0
+        grad2 = np.sum(w * self.k2 * np.abs(chat) ** 2) / c.size
+        return vol * (f.sum() + 0.5 * self.kappa * grad2), vol * c.sum()

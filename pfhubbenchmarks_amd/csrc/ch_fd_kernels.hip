@@ -369,6 +369,13 @@ __global__ __launch_bounds__(256) void ch_fd_update_kernel(const FdArgs a, const
   }
 }
 
+int g_fused_variant = 0;  // tuning hook (pfk_set_tuning key 0): index into the variant table below
+// z-chunking.  Measured on MI355X at 512^3 (profiles/r01/chunk_sweep_512c.log): the kernel is fastest when the grid
+// is exactly one workgroup per CU with long z-chunks (256 WGs: 5.5 TB/s; 2048 WGs: 4.7 TB/s; 128 WGs: 3.8 TB/s) --
+// every chunk pays 4 pipeline-fill planes and each extra "round" of workgroups a tail.
+int g_target_wgs = 0;  // key 1: split z into chunks until the grid has about this many workgroups (0 = #CUs)
+int g_min_chunk = 16;  // key 2: ... but never fewer than this many planes per chunk
+
 template <int NW, int S, int DEPTH>
 hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   constexpr int TY = NW * S;
@@ -379,8 +386,21 @@ hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   const int nzr = a.zhi - a.zlo;
   // z-chunks: enough workgroups to fill 256 CUs a few times over, but keep the 4-plane pipeline fill < ~12 %
   const int xy = k.ntx * k.nty;
-  int nchunk = (2048 + xy - 1) / xy;
-  const int max_chunks = nzr >= 32 ? nzr / 32 : 1;
+  int target = g_target_wgs;
+  if (target <= 0) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        n_cu = v;
+      else
+        n_cu = 256;
+    }
+    target = n_cu;
+  }
+  int nchunk = target / xy;  // floor: never more workgroups than the target
+  const int max_chunks = nzr >= g_min_chunk ? nzr / g_min_chunk : 1;
   if (nchunk > max_chunks) nchunk = max_chunks;
   if (nchunk < 1) nchunk = 1;
   k.zchunk = (nzr + nchunk - 1) / nchunk;
@@ -395,7 +415,6 @@ hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-int g_fused_variant = 0;  // tuning hook (pfk_set_tuning key 0): index into the variant table below
 
 }  // namespace
 
@@ -434,5 +453,9 @@ hipError_t launch_ch_fd_twopass(const FdArgs& a, double* mu_scratch, hipStream_t
 }
 
 void set_fused_variant(int v) { g_fused_variant = v; }
+void set_fused_chunking(int target_wgs, int min_chunk) {
+  if (target_wgs > 0) g_target_wgs = target_wgs;
+  if (min_chunk > 0) g_min_chunk = min_chunk;
+}
 
 }  // namespace pfhip

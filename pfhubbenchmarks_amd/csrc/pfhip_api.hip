@@ -82,7 +82,8 @@ struct pf_handle {
   int64_t mu_scratch_elems = 0;
   double* partials = nullptr;
   double* out6_dev = nullptr;
-  double* out6_host = nullptr;  // pinned
+  double* out6_host = nullptr;  // pinned (8 doubles: 6 raw sums + spectral gradient energy)
+  Spectral* sp = nullptr;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool step_open = false;
@@ -158,7 +159,25 @@ int timing_flush(pf_handle* h) {
 }
 
 // one FD step on planes [zlo, zhi) of the current buffer into the other buffer
+// (spectral scheme: one whole-domain semi-implicit step, zlo/zhi ignored)
 int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
+  if (h->sp) {
+    std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
+    if (h->timing) {
+      if (h->ev_used == h->ev.size()) {
+        int rc = timing_flush(h);
+        if (rc) return rc;
+      }
+      e = &h->ev[h->ev_used++];
+      PF_HIP(h, hipEventRecord(e->first, h->stream));
+    }
+    const pf_config& c = h->cfg;
+    if (spectral_step(h->sp, h->c[h->cur], h->c[1 - h->cur], dt, c.M, c.kappa, c.c_alpha, c.c_beta, 2.0 * c.rho_s,
+                      h->stream) != 0)
+      return fail(h, PF_ERR_HIP, spectral_error(h->sp));
+    if (e) PF_HIP(h, hipEventRecord(e->second, h->stream));
+    return PF_OK;
+  }
   if (zhi <= zlo) return PF_OK;
   FdArgs a = make_args(h, dt, zlo, zhi);
   int impl = h->cfg.kernel;
@@ -189,9 +208,19 @@ int run_diag(pf_handle* h, double raw[6]) {
   const pf_config& c = h->cfg;
   PF_HIP(h, launch_diag(h->c[h->cur], nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
                         c.c_beta, h->partials, h->out6_dev, h->stream));
-  PF_HIP(h, hipMemcpyAsync(h->out6_host, h->out6_dev, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (h->sp) {
+    // spectral scheme: |grad c|^2 summed in k-space (Parseval) instead of forward differences
+    if (spectral_grad_energy(h->sp, h->c[h->cur], h->out6_dev + 6, h->stream) != 0)
+      return fail(h, PF_ERR_HIP, spectral_error(h->sp));
+  }
+  PF_HIP(h, hipMemcpyAsync(h->out6_host, h->out6_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PF_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < 6; ++i) raw[i] = h->out6_host[i];
+  if (h->sp) {
+    // store as the equivalent "sum of squared differences / h^2 * h^2" so scale_diag's kappa/(2 h^2) factor applies
+    const int64_t n = h->g.plane * (int64_t)h->g.nz;
+    raw[2] = h->out6_host[6] / (double)n * (h->cfg.h * h->cfg.h);
+  }
   return PF_OK;
 }
 
@@ -280,8 +309,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   int rc = resolve(cfg, &g, &err);
   if (rc != PF_OK) return fail(nullptr, rc, err);
   if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6) return fail(nullptr, PF_ERR_INVALID, "bad model");
-  if (cfg->scheme != PF_SCHEME_FD_EXPLICIT)
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "only PF_SCHEME_FD_EXPLICIT is implemented in this build");
+  if (cfg->scheme != PF_SCHEME_FD_EXPLICIT && cfg->scheme != PF_SCHEME_SPECTRAL_SI)
+    return fail(nullptr, PF_ERR_INVALID, "bad scheme");
+  if (cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->nranks != 1)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "the spectral scheme is single-GPU in this build");
   if (cfg->model != PF_MODEL_BM1) return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is not implemented in this build");
   if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
   if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
@@ -323,8 +354,12 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   PF_HIP_C(hipMemsetAsync(h->c[0], 0, sizeof(double) * elems, h->stream));
   PF_HIP_C(hipMemsetAsync(h->c[1], 0, sizeof(double) * elems, h->stream));
   PF_HIP_C(hipMalloc(&h->partials, sizeof(double) * diag_partials_elems()));
-  PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 6));
-  PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 6, hipHostMallocDefault));
+  PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 8));
+  PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 8, hipHostMallocDefault));
+  if (cfg->scheme == PF_SCHEME_SPECTRAL_SI) {
+    int src = spectral_create(&h->sp, cfg->dim, g.nx, g.ny, g.nzg, cfg->h, h->stream, &h->err);
+    if (src != 0) return bail(PF_ERR_HIP);
+  }
   PF_HIP_C(hipStreamSynchronize(h->stream));
 #undef PF_HIP_C
   *out = h;
@@ -344,6 +379,7 @@ int pf_destroy(pf_handle* h) {
     if (h->c[1]) (void)hipFree(h->c[1]);
   }
   if (h->mu_scratch) (void)hipFree(h->mu_scratch);
+  if (h->sp) spectral_destroy(h->sp);
   if (h->partials) (void)hipFree(h->partials);
   if (h->out6_dev) (void)hipFree(h->out6_dev);
   if (h->out6_host) (void)hipHostFree(h->out6_host);
@@ -359,6 +395,7 @@ static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   PF_HIP(h, launch_ic(h->c[h->cur], g.nx, g.ny, g.nz, g.ghost, h->cfg.h, c0, amp, w0, g.mirror ? g.np[0] : 0,
                       g.mirror ? g.np[1] : 0, h->stream));
   h->have_prev = false;
+  if (h->sp) spectral_invalidate(h->sp);
   return PF_OK;
 }
 
@@ -393,6 +430,7 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
     PF_HIP(h, hipStreamSynchronize(h->stream));
   }
   h->have_prev = false;
+  if (h->sp) spectral_invalidate(h->sp);
   return PF_OK;
 }
 
@@ -447,6 +485,7 @@ int pf_rollback(pf_handle* h) {
   if (!h->have_prev) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
   h->cur ^= 1;
   h->have_prev = false;
+  if (h->sp) spectral_invalidate(h->sp);
   return PF_OK;
 }
 
@@ -599,6 +638,14 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
 int pfk_set_tuning(int key, int value) {
   if (key == 0) {
     set_fused_variant(value);
+    return PF_OK;
+  }
+  if (key == 1 && value > 0) {
+    set_fused_chunking(value, 0);
+    return PF_OK;
+  }
+  if (key == 2 && value > 0) {
+    set_fused_chunking(0, value);
     return PF_OK;
   }
   return PF_ERR_INVALID;

@@ -39,5 +39,17 @@ hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int n
 hipError_t launch_ic(double* c, int nx, int ny, int nz, int ghost, double h, double c0, double amp, double w0,
                      int mnx, int mny, hipStream_t stream);
 void set_fused_variant(int v);
+void set_fused_chunking(int target_wgs, int min_chunk);
+
+// semi-implicit Fourier-spectral scheme (spectral.hip); functions return 0 or a negative pf_status, message in
+// spectral_error()
+struct Spectral;
+int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, hipStream_t stream, std::string* err);
+void spectral_destroy(Spectral* sp);
+void spectral_invalidate(Spectral* sp);  // call whenever the real-space field changed behind the scheme's back
+int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
+                  double cb, double two_rho, hipStream_t stream);
+int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
+const char* spectral_error(const Spectral* sp);
 
 }  // namespace pfhip

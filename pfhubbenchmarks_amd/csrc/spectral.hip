@@ -1,0 +1,256 @@
+// Semi-implicit Fourier-spectral Cahn-Hilliard step (BASELINE.json config 2: 512^2, fp64) on rocFFT (hipFFT API).
+//
+//   c_t = M lap( f'(c) - kappa lap c )        dolfin/pfbase.py:361-383, f' from dolfin/bench1.py:63-65
+//   (c^+_k - c_k)/dt = -M k^2 N_k - M kappa k^4 c^+_k,   N = f'(c^n)   (stiff term implicit, nonlinearity explicit)
+//   =>  c^+_k = (c_k - dt M k^2 N_k) / (1 + dt M kappa k^4)
+//
+// Per step: [HIP] g = f'(c)  ->  rocFFT r2c(g)  ->  [HIP] k-space update (c_k stays resident; also emits c_k/N for
+// the inverse)  ->  rocFFT c2r.  The inverse transform's input is a scratch copy because multi-dimensional c2r
+// may overwrite its input.  The same pointwise f' as the FD kernel: a = c-ca; b = cb-c; 2 rho ((a b)(b-a)).
+#include <hipfft/hipfft.h>
+
+#include "pfhip_internal.h"
+
+namespace pfhip {
+
+namespace {
+
+constexpr double TWO_PI = 6.283185307179586476925286766559;
+
+__global__ __launch_bounds__(256) void dfdc_kernel(const double* __restrict__ c, double* __restrict__ g, int64_t n,
+                                                   double ca, double cb, double two_rho) {
+  // n is even whenever nx is; handle pairs with 16-byte accesses, tail scalar
+  const int64_t npair = n >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npair; i += (int64_t)gridDim.x * 256) {
+    const double2 v = reinterpret_cast<const double2*>(c)[i];
+    double2 o;
+    double a = v.x - ca, b = cb - v.x;
+    o.x = two_rho * ((a * b) * (b - a));
+    a = v.y - ca;
+    b = cb - v.y;
+    o.y = two_rho * ((a * b) * (b - a));
+    reinterpret_cast<double2*>(g)[i] = o;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double w = c[n - 1];
+    const double a = w - ca, b = cb - w;
+    g[n - 1] = two_rho * ((a * b) * (b - a));
+  }
+}
+
+struct KsArgs {
+  int nxh, ny, nz;   // half-spectrum extents (x fastest)
+  int nx;            // full x extent
+  double kx0, ky0, kz0;  // 2 pi / (n h) per axis
+  double dtM, dtMkappa, inv_n;
+};
+
+__device__ __forceinline__ double ksq(const KsArgs& a, int64_t idx) {
+  const int mx = (int)(idx % a.nxh);
+  const int64_t r = idx / a.nxh;
+  int my = (int)(r % a.ny);
+  int mz = (int)(r / a.ny);
+  if (2 * my > a.ny) my -= a.ny;
+  if (2 * mz > a.nz) mz -= a.nz;
+  const double kx = a.kx0 * mx, ky = a.ky0 * my, kz = a.kz0 * mz;
+  return (kx * kx + ky * ky) + kz * kz;
+}
+
+// chat <- (chat - dtM k^2 ghat) / (1 + dtM kappa k^4);  scratch <- chat / N
+__global__ __launch_bounds__(256) void kspace_update_kernel(double2* __restrict__ chat, const double2* __restrict__ ghat,
+                                                            double2* __restrict__ scratch, int64_t nh, const KsArgs a) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (int64_t)gridDim.x * 256) {
+    const double k2 = ksq(a, i);
+    const double num = a.dtM * k2;
+    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+    const double2 ch = chat[i], gh = ghat[i];
+    double2 o;
+    o.x = fma(-num, gh.x, ch.x) * den;
+    o.y = fma(-num, gh.y, ch.y) * den;
+    chat[i] = o;
+    scratch[i] = make_double2(o.x * a.inv_n, o.y * a.inv_n);
+  }
+}
+
+// sum_k w_k k^2 |chat_k|^2 over the half spectrum (w = 1 on the self-conjugate x-columns mx = 0 and mx = nx/2,
+// 2 elsewhere) -> per-block partials -> final (fixed order, deterministic)
+__global__ __launch_bounds__(256) void kspace_grad_energy_kernel(const double2* __restrict__ chat, int64_t nh,
+                                                                 const KsArgs a, double* __restrict__ partials) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (int64_t)gridDim.x * 256) {
+    const int mx = (int)(i % a.nxh);
+    const double w = (mx == 0 || 2 * mx == a.nx) ? 1.0 : 2.0;
+    const double2 ch = chat[i];
+    acc += w * ksq(a, i) * (ch.x * ch.x + ch.y * ch.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int n,
+                                                           double* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+const char* fft_err(hipfftResult r) {
+  switch (r) {
+    case HIPFFT_SUCCESS: return "HIPFFT_SUCCESS";
+    case HIPFFT_INVALID_PLAN: return "HIPFFT_INVALID_PLAN";
+    case HIPFFT_ALLOC_FAILED: return "HIPFFT_ALLOC_FAILED";
+    case HIPFFT_INVALID_VALUE: return "HIPFFT_INVALID_VALUE";
+    case HIPFFT_INTERNAL_ERROR: return "HIPFFT_INTERNAL_ERROR";
+    case HIPFFT_EXEC_FAILED: return "HIPFFT_EXEC_FAILED";
+    case HIPFFT_SETUP_FAILED: return "HIPFFT_SETUP_FAILED";
+    case HIPFFT_INVALID_SIZE: return "HIPFFT_INVALID_SIZE";
+    default: return "HIPFFT error";
+  }
+}
+
+}  // namespace
+
+struct Spectral {
+  int dim, nx, ny, nz;
+  int64_t n, nh;
+  hipfftHandle fwd = 0, inv = 0;
+  bool have_plans = false;
+  double2 *chat = nullptr, *ghat = nullptr, *scratch = nullptr;
+  double* g = nullptr;
+  double* partials = nullptr;  // 2048 + 1 doubles
+  bool chat_valid = false;
+  KsArgs ks;
+  std::string err;
+};
+
+#define SP_HIP(expr)                                                       \
+  do {                                                                     \
+    hipError_t e_ = (expr);                                                \
+    if (e_ != hipSuccess) {                                                \
+      sp->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+      return -3;                                                           \
+    }                                                                      \
+  } while (0)
+#define SP_FFT(expr)                                                       \
+  do {                                                                     \
+    hipfftResult r_ = (expr);                                              \
+    if (r_ != HIPFFT_SUCCESS) {                                            \
+      sp->err = std::string(#expr) + ": " + fft_err(r_);                   \
+      return -3;                                                           \
+    }                                                                      \
+  } while (0)
+
+const char* spectral_error(const Spectral* sp) { return sp->err.c_str(); }
+
+int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, hipStream_t stream, std::string* err) {
+  Spectral* sp = new Spectral();
+  *out = sp;
+  sp->dim = dim;
+  sp->nx = nx;
+  sp->ny = ny;
+  sp->nz = dim == 3 ? nz : 1;
+  sp->n = (int64_t)nx * ny * sp->nz;
+  const int nxh = nx / 2 + 1;
+  sp->nh = (int64_t)nxh * ny * sp->nz;
+  sp->ks.nxh = nxh;
+  sp->ks.ny = ny;
+  sp->ks.nz = sp->nz;
+  sp->ks.nx = nx;
+  sp->ks.kx0 = TWO_PI / (nx * h);
+  sp->ks.ky0 = TWO_PI / (ny * h);
+  sp->ks.kz0 = sp->nz > 1 ? TWO_PI / (sp->nz * h) : 0.0;
+  sp->ks.inv_n = 1.0 / (double)sp->n;
+  auto fail = [&](int rc) {
+    if (err) *err = sp->err;
+    return rc;
+  };
+  auto body = [&]() -> int {
+    if (dim == 2) {
+      SP_FFT(hipfftPlan2d(&sp->fwd, ny, nx, HIPFFT_D2Z));
+      SP_FFT(hipfftPlan2d(&sp->inv, ny, nx, HIPFFT_Z2D));
+    } else {
+      SP_FFT(hipfftPlan3d(&sp->fwd, sp->nz, ny, nx, HIPFFT_D2Z));
+      SP_FFT(hipfftPlan3d(&sp->inv, sp->nz, ny, nx, HIPFFT_Z2D));
+    }
+    sp->have_plans = true;
+    SP_FFT(hipfftSetStream(sp->fwd, stream));
+    SP_FFT(hipfftSetStream(sp->inv, stream));
+    SP_HIP(hipMalloc(&sp->chat, sizeof(double2) * sp->nh));
+    SP_HIP(hipMalloc(&sp->ghat, sizeof(double2) * sp->nh));
+    SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * sp->nh));
+    SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
+    SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 2049));
+    return 0;
+  };
+  return fail(body());
+}
+
+void spectral_destroy(Spectral* sp) {
+  if (!sp) return;
+  if (sp->have_plans) {
+    (void)hipfftDestroy(sp->fwd);
+    (void)hipfftDestroy(sp->inv);
+  }
+  if (sp->chat) (void)hipFree(sp->chat);
+  if (sp->ghat) (void)hipFree(sp->ghat);
+  if (sp->scratch) (void)hipFree(sp->scratch);
+  if (sp->g) (void)hipFree(sp->g);
+  if (sp->partials) (void)hipFree(sp->partials);
+  delete sp;
+}
+
+void spectral_invalidate(Spectral* sp) { sp->chat_valid = false; }
+
+static int ensure_chat(Spectral* sp, const double* c) {
+  if (sp->chat_valid) return 0;
+  SP_FFT(hipfftExecD2Z(sp->fwd, const_cast<double*>(c), reinterpret_cast<hipfftDoubleComplex*>(sp->chat)));
+  sp->chat_valid = true;
+  return 0;
+}
+
+// one semi-implicit step: reads c_in (real space), writes c_out (real space); c_k stays resident
+int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
+                  double cb, double two_rho, hipStream_t stream) {
+  int rc = ensure_chat(sp, c_in);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dfdc_kernel, dim3(grid_for(sp->n / 2)), dim3(256), 0, stream, c_in, sp->g, sp->n, ca, cb, two_rho);
+  SP_FFT(hipfftExecD2Z(sp->fwd, sp->g, reinterpret_cast<hipfftDoubleComplex*>(sp->ghat)));
+  KsArgs ks = sp->ks;
+  ks.dtM = dt * M;
+  ks.dtMkappa = dt * M * kappa;
+  hipLaunchKernelGGL(kspace_update_kernel, dim3(grid_for(sp->nh)), dim3(256), 0, stream, sp->chat,
+                     (const double2*)sp->ghat, sp->scratch, sp->nh, ks);
+  SP_FFT(hipfftExecZ2D(sp->inv, reinterpret_cast<hipfftDoubleComplex*>(sp->scratch), c_out));
+  SP_HIP(hipGetLastError());
+  return 0;
+}
+
+// sum_k w_k k^2 |c_k|^2 / N  (= sum over the lattice of |grad c|^2 by Parseval) -> out_dev[0]
+int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream) {
+  int rc = ensure_chat(sp, c);
+  if (rc) return rc;
+  const int nb = grid_for(sp->nh);
+  hipLaunchKernelGGL(kspace_grad_energy_kernel, dim3(nb), dim3(256), 0, stream, (const double2*)sp->chat, sp->nh,
+                     sp->ks, sp->partials);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const double*)sp->partials, nb, out_dev);
+  SP_HIP(hipGetLastError());
+  return 0;
+}
+
+double spectral_inv_n(const Spectral* sp) { return sp->ks.inv_n; }
+
+}  // namespace pfhip

@@ -228,3 +228,38 @@ def test_full_size_properties_512cubed(lib):
             np.testing.assert_array_equal(f3[z], f2)
         F2, C2, _ = s2.diagnostics()
         assert abs(F1 - n * F2) <= 1e-12 * abs(F1)             # F_3D = L_z F_2D
+
+
+@pytest.mark.parametrize("shape", [(512, 512), (96, 40), (34, 18, 10), (64, 64, 64)])
+def test_spectral_scheme_matches_numpy_oracle(lib, shape):
+    """BASELINE.json config 2 (512^2 semi-implicit spectral): rocFFT path vs pocketfft oracle, 1e-11 relative."""
+    from oracle import ch_spectral
+    dim = len(shape)
+    n = shape[::-1]                      # (nx, ny[, nz])
+    rng = np.random.default_rng(sum(shape))
+    if shape == (512, 512):
+        from oracle import ch_fd
+        c = ch_fd.ic(512, 512, 1)[0]
+    else:
+        c = 0.5 + 0.05 * rng.standard_normal(shape)
+    sp = ch_spectral.SpectralCH(c, h=1.0)
+    with PhaseFieldSolver(dim=dim, n=n, h=1.0, scheme="spectral") as s:
+        s.set_c(c)
+        F, Ctot, _ = s.diagnostics()
+        Fo, Co = sp.diagnostics()
+        assert abs(F - Fo) <= 1e-11 * abs(Fo) and abs(Ctot - Co) <= 1e-13 * abs(Co)
+        for k in (1, 9):
+            s.step(1e-2, k)
+            sp.step(1e-2, k)
+            got = s.get_c()
+            assert np.abs(got - sp.c).max() <= 1e-11 * np.abs(sp.c).max()
+        F, Ctot, _ = s.diagnostics()
+        Fo, Co = sp.diagnostics()
+        assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(Ctot - Co) <= 1e-12 * abs(Co)
+        # rollback drops the resident spectrum and restores the previous real-space field
+        s.step(1e-2)
+        s.rollback()
+        assert np.abs(s.get_c() - sp.c).max() <= 1e-11
+        s.step(1e-2)
+        sp.step(1e-2)
+        assert np.abs(s.get_c() - sp.c).max() <= 1e-11

@@ -75,3 +75,24 @@ def test_fd_scheme_tracks_the_reference_algorithm_at_early_time(orc, golden_dir)
     F, C, _ = orc.diagnostics(e, h=2.0, mirror=True)
     assert abs(F - csv[0, 1]) / csv[0, 1] < 3e-3
     assert abs(C - csv[0, 2]) / csv[0, 2] < 1e-4      # trapezoid vs P1 mass functional
+
+
+def test_spectral_oracle_conserves_mass_and_matches_fd_for_smooth_data():
+    """The two GPU schemes' oracles agree with each other on smooth periodic data (O(h^2) apart)."""
+    from oracle import ch_fd, ch_spectral
+    n = 64
+    x = np.arange(n) * (2 * np.pi / n)
+    c = 0.5 + 0.05 * np.cos(x)[None, :] * np.cos(2 * x)[:, None]
+    h = 1.0
+    sp = ch_spectral.SpectralCH(c, h=h)
+    F0, C0 = sp.diagnostics()
+    sp.step(1e-3, 50)
+    F1, C1 = sp.diagnostics()
+    assert abs(C1 - C0) < 1e-12 * abs(C0) and F1 < F0
+    ch_fd.load()
+    cf = c.copy()
+    for _ in range(50):
+        cf = ch_fd.fd_step(cf, 1e-3, h=h)
+    assert np.abs(cf - sp.c).max() < 2e-4          # FD's O(h^2) dispersion error on k = 1, 2 modes at n = 64
+    Ff, Cf, _ = ch_fd.diagnostics(cf, h=h)
+    assert abs(Ff - F1) / F1 < 1e-3
