@@ -84,6 +84,9 @@ struct pf_handle {
   double* out6_dev = nullptr;
   double* out6_host = nullptr;  // pinned (8 doubles: 6 raw sums + spectral gradient energy)
   Spectral* sp = nullptr;
+  Poisson* po = nullptr;   // BM6
+  double* phi = nullptr;   // BM6: phi on the lattice, consistent with c[cur] when phi_valid
+  bool phi_valid = false;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool step_open = false;
@@ -118,7 +121,7 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   FdArgs a;
   a.cin = h->c[h->cur];
   a.cout = h->c[1 - h->cur];
-  a.phi = nullptr;
+  a.phi = h->po ? h->phi : nullptr;
   a.nx = h->g.nx;
   a.ny = h->g.ny;
   a.nz = h->g.nz;
@@ -131,7 +134,7 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   a.two_rho = 2.0 * c.rho_s;
   a.kh2 = c.kappa / (c.h * c.h);
   a.amh2 = dt * c.M / (c.h * c.h);
-  a.kphi = 0.0;
+  a.kphi = h->po ? c.k : 0.0;
   return a;
 }
 
@@ -158,6 +161,14 @@ int timing_flush(pf_handle* h) {
   return PF_OK;
 }
 
+// BM6: phi = phi(c[cur]) (explicit coupling: the step uses phi^n; diagnostics recompute it for the new c)
+int ensure_phi(pf_handle* h) {
+  if (!h->po || h->phi_valid) return PF_OK;
+  if (poisson_solve(h->po, h->c[h->cur], h->phi, h->stream) != 0) return fail(h, PF_ERR_HIP, poisson_error(h->po));
+  h->phi_valid = true;
+  return PF_OK;
+}
+
 // one FD step on planes [zlo, zhi) of the current buffer into the other buffer
 // (spectral scheme: one whole-domain semi-implicit step, zlo/zhi ignored)
 int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
@@ -179,6 +190,10 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
     return PF_OK;
   }
   if (zhi <= zlo) return PF_OK;
+  {
+    int prc = ensure_phi(h);
+    if (prc) return prc;
+  }
   FdArgs a = make_args(h, dt, zlo, zhi);
   int impl = h->cfg.kernel;
   if (impl == PF_KERNEL_AUTO) impl = ch_fd_fused_supported(a) ? PF_KERNEL_FUSED : PF_KERNEL_TWOPASS;
@@ -206,7 +221,11 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
 
 int run_diag(pf_handle* h, double raw[6]) {
   const pf_config& c = h->cfg;
-  PF_HIP(h, launch_diag(h->c[h->cur], nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
+  {
+    int prc = ensure_phi(h);
+    if (prc) return prc;
+  }
+  PF_HIP(h, launch_diag(h->c[h->cur], h->po ? h->phi : nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
                         c.c_beta, h->partials, h->out6_dev, h->stream));
   if (h->sp) {
     // spectral scheme: |grad c|^2 summed in k-space (Parseval) instead of forward differences
@@ -313,7 +332,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     return fail(nullptr, PF_ERR_INVALID, "bad scheme");
   if (cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->nranks != 1)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "the spectral scheme is single-GPU in this build");
-  if (cfg->model != PF_MODEL_BM1) return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is not implemented in this build");
+  if (cfg->model == PF_MODEL_BM6 && (cfg->nranks != 1 || cfg->scheme != PF_SCHEME_FD_EXPLICIT))
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is implemented for the FD scheme on one GPU in this build");
   if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
   if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
     return fail(nullptr, PF_ERR_INVALID, "ext_c: give both buffers or none");
@@ -356,6 +376,13 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   PF_HIP_C(hipMalloc(&h->partials, sizeof(double) * diag_partials_elems()));
   PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 8));
   PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 8, hipHostMallocDefault));
+  if (cfg->model == PF_MODEL_BM6) {
+    PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
+    PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
+    int prc = poisson_create(&h->po, cfg->dim, g.nx, g.ny, g.nzg, g.mirror ? g.np[0] : 0, g.mirror ? g.np[1] : 0,
+                             cfg->h, cfg->k, cfg->eps_r, h->stream, &h->err);
+    if (prc != 0) return bail(PF_ERR_HIP);
+  }
   if (cfg->scheme == PF_SCHEME_SPECTRAL_SI) {
     int src = spectral_create(&h->sp, cfg->dim, g.nx, g.ny, g.nzg, cfg->h, h->stream, &h->err);
     if (src != 0) return bail(PF_ERR_HIP);
@@ -380,6 +407,8 @@ int pf_destroy(pf_handle* h) {
   }
   if (h->mu_scratch) (void)hipFree(h->mu_scratch);
   if (h->sp) spectral_destroy(h->sp);
+  if (h->po) poisson_destroy(h->po);
+  if (h->phi) (void)hipFree(h->phi);
   if (h->partials) (void)hipFree(h->partials);
   if (h->out6_dev) (void)hipFree(h->out6_dev);
   if (h->out6_host) (void)hipHostFree(h->out6_host);
@@ -396,6 +425,7 @@ static int set_ic(pf_handle* h, double c0, double amp, double w0) {
                       g.mirror ? g.np[1] : 0, h->stream));
   h->have_prev = false;
   if (h->sp) spectral_invalidate(h->sp);
+  h->phi_valid = false;
   return PF_OK;
 }
 
@@ -431,14 +461,20 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
   }
   h->have_prev = false;
   if (h->sp) spectral_invalidate(h->sp);
+  h->phi_valid = false;
   return PF_OK;
 }
 
 int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
-  if (field != PF_FIELD_C) return fail(h, PF_ERR_UNSUPPORTED, "only PF_FIELD_C can be read in this build");
+  if (field != PF_FIELD_C && !(field == PF_FIELD_PHI && h->po))
+    return fail(h, PF_ERR_UNSUPPORTED, "pf_get_field: PF_FIELD_C (or PF_FIELD_PHI for BM6) only; mu is never stored");
   const Geometry& g = h->g;
-  const double* src = h->c[h->cur] + (int64_t)g.ghost * g.plane;
+  if (field == PF_FIELD_PHI) {
+    int prc = ensure_phi(h);
+    if (prc) return prc;
+  }
+  const double* src = (field == PF_FIELD_PHI ? h->phi : h->c[h->cur]) + (int64_t)g.ghost * g.plane;
   if (!g.mirror) {
     if ((int64_t)n != g.plane * g.nz) return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count");
     PF_HIP(h, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
@@ -465,6 +501,7 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
     int rc = launch_step(h, dt, 0, h->g.nz);
     if (rc) return rc;
     h->cur ^= 1;
+  h->phi_valid = false;
     h->have_prev = true;
   }
   if (info) {
@@ -484,8 +521,10 @@ int pf_rollback(pf_handle* h) {
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
   if (!h->have_prev) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
   h->cur ^= 1;
+  h->phi_valid = false;
   h->have_prev = false;
   if (h->sp) spectral_invalidate(h->sp);
+  h->phi_valid = false;
   return PF_OK;
 }
 
@@ -542,6 +581,7 @@ int pf_step_finish(pf_handle* h) {
     if (rc) return rc;
   }
   h->cur ^= 1;
+  h->phi_valid = false;
   h->have_prev = true;
   h->step_open = false;
   return PF_OK;

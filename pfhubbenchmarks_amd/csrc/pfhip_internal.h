@@ -52,4 +52,13 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
 
+// Poisson solve of BM6 (poisson.hip): lap(phi) = -k c / eps on the lattice; npx, npy > 0 = the reference's
+// Dirichlet-x / no-flux-y boundary conditions on the even extension of an npx x npy-node domain, 0 = periodic box
+struct Poisson;
+int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int npy, double h, double k, double eps,
+                   hipStream_t stream, std::string* err);
+void poisson_destroy(Poisson* po);
+int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream);
+const char* poisson_error(const Poisson* po);
+
 }  // namespace pfhip

@@ -1,0 +1,152 @@
+"""Benchmark drivers: the counterparts of the reference's dolfin/bench1.py and dolfin/bench6.py scripts.
+
+Same contract (README.md:18-29): run from the repo root, hard-coded benchmark parameters (overridable by flags), rank-0
+writes `results/bench<N>_out.csv` with header `time,total_free_energy,total_solute` and `fmt='%1.10f'`
+(bench1.py:210-217; bench1 additionally writes results/bench1/stats.csv, the path today's bench1.py uses, and
+results/bench1_out.csv, the path stats.jl:4 and b13d.py:200 use).
+
+The time loop keeps the reference's shape (bench1.py:145-198): advance, on failure roll back and halve dt
+(bench1.py:164-177), then diagnostics, then append a row.  What differs is the integrator: the reference takes one
+backward-Euler step per row with dt adapted from the Newton iteration count; here each row is reached by explicit
+(or semi-implicit spectral) sub-steps of a stable size, and rows are emitted at the reference run's accepted times
+(pfhubbenchmarks_amd/data/bench<N>_times.txt) so the two CSVs line up row by row.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+
+from .solver import PhaseFieldSolver, stable_dt
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+CSV_HEADER = "time,total_free_energy,total_solute"
+
+
+def report_times(bench):
+    return np.loadtxt(os.path.join(_DATA, "%s_times.txt" % bench))
+
+
+def write_csv(path, rows):
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    np.savetxt(path, np.array(rows), fmt="%1.10f", header=CSV_HEADER, delimiter=",", comments="")
+
+
+def advance_to(solver, t_target, dt_sub, dt_min):
+    """Advance solver.t to t_target with sub-steps <= dt_sub; on a failed guard check restore the row's start state
+    and halve dt_sub (bench1.py:164-177).  Returns the dt_sub that worked."""
+    start_t = solver.t
+    snapshot = None
+    while True:
+        span = t_target - solver.t
+        if span <= 1e-14 * max(1.0, abs(t_target)):
+            return dt_sub
+        n = int(np.floor(span / dt_sub + 1e-12))
+        if n > 0:
+            if snapshot is None:
+                snapshot = solver.get_c()
+            ok, _, _ = solver.step(dt_sub, n, check=True)
+        else:
+            ok = True
+        rem = t_target - solver.t
+        if ok and rem > 1e-14 * max(1.0, abs(t_target)):
+            ok, _, _ = solver.step(rem, 1, check=True)
+        if ok:
+            solver.t = t_target
+            return dt_sub
+        if dt_sub <= dt_min:
+            raise RuntimeError("step failed at dt_min = %g (t = %g)" % (dt_min, solver.t))
+        dt_sub = max(0.5 * dt_sub, dt_min)
+        print("REPEATING row: t = %g, dt_sub -> %g" % (start_t, dt_sub))
+        solver.set_c(snapshot)
+        solver.t = start_t
+
+
+def run_bench1(intervals=200, L=200.0, scheme="fd", dt=None, end_time=1e3, times=None, out_dir="results",
+               save_solution=False, device=0, verbose=True):
+    """PFHub BM1 (dolfin/bench1.py): 200 x 200 no-flux square, c0 = 0.5, epsilon = 0.05 (bench1.py:48-49)."""
+    h = L / intervals
+    times = report_times("bench1") if times is None else np.asarray(times, dtype=float)
+    # bench1.py:145: loop while t < end_time (+eps): the last accepted step overshoots end_time
+    keep = [i for i, t in enumerate(times) if i == 0 or times[i - 1] < end_time + 1e-12]
+    times = times[keep]
+    if dt is None:
+        dt = stable_dt(h, dim=2, safety=0.4) if scheme == "fd" else 1e-2
+    dt_min = dt / 64.0
+    rows = []
+    t1 = time.time()
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=h, bc="mirror", scheme=scheme, device=device) as s:
+        s.set_ic_bm1(0.5, 0.05)
+        for it, tn in enumerate(times):
+            dt = advance_to(s, float(tn), dt, dt_min)
+            F, C, _ = s.diagnostics()
+            rows.append([float(tn), F, C])
+            if verbose:
+                print("Iteration #%d. Time: %g, C_total: %.10f, TFE: %.10f" % (it + 1, tn, C, F))
+            if save_solution:
+                os.makedirs(os.path.join(out_dir, "bench1"), exist_ok=True)
+                np.save(os.path.join(out_dir, "bench1", "conc%06d.npy" % it), s.get_c())
+    spent = time.time() - t1
+    print("Time spent is %s" % spent)
+    write_csv(os.path.join(out_dir, "bench1_out.csv"), rows)
+    write_csv(os.path.join(out_dir, "bench1", "stats.csv"), rows)
+    return np.array(rows), spent
+
+
+def run_bench6(intervals=100, L=100.0, dt=None, end_time=3.0, times=None, out_dir="results", save_solution=False,
+               device=0, verbose=True):
+    """PFHub BM6 (dolfin/bench6.py): 100 x 100 domain, c0 = 0.5, c1 = 0.04 (bench6.py:53-54), k = 0.09, eps = 90
+    (:38-39), phi = 0 / sin(y/7) on x = 0 / Lx (:77-90).  Explicit coupling: each sub-step solves the Poisson
+    problem for phi(c^n) (rocFFT) and takes one fused FD Cahn-Hilliard step with mu += k phi."""
+    h = L / intervals
+    times = report_times("bench6") if times is None else np.asarray(times, dtype=float)
+    keep = [i for i, t in enumerate(times) if i == 0 or times[i - 1] < end_time + 1e-12]
+    times = times[keep]
+    if dt is None:
+        dt = stable_dt(h, dim=2, safety=0.4)
+    dt_min = dt / 64.0
+    rows = []
+    t1 = time.time()
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=h, bc="mirror", model="bm6", device=device) as s:
+        s.set_ic_bm6(0.5, 0.04)
+        for it, tn in enumerate(times):
+            dt = advance_to(s, float(tn), dt, dt_min)
+            F, C, _ = s.diagnostics()
+            rows.append([float(tn), F, C])
+            if verbose:
+                print("Iteration #%d. Time: %g, C_total: %.10f, TFE: %.10f" % (it + 1, tn, C, F))
+            if save_solution:
+                os.makedirs(os.path.join(out_dir, "bench6"), exist_ok=True)
+                np.save(os.path.join(out_dir, "bench6", "conc%06d.npy" % it), s.get_c())
+                np.save(os.path.join(out_dir, "bench6", "phi%06d.npy" % it), s.get_phi())
+    spent = time.time() - t1
+    print("Time spent is %s" % spent)
+    write_csv(os.path.join(out_dir, "bench6_out.csv"), rows)
+    return np.array(rows), spent
+
+
+def main_bench6(argv=None):
+    ap = argparse.ArgumentParser(description="PFHub BM6 on MI355X (counterpart of dolfin/bench6.py)")
+    ap.add_argument("--intervals", type=int, default=100, help="grid intervals per side (h = 100/intervals)")
+    ap.add_argument("--dt", type=float, default=None)
+    ap.add_argument("--end-time", type=float, default=3.0)
+    ap.add_argument("--out-dir", default="results")
+    ap.add_argument("--save-solution", action="store_true")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args(argv)
+    run_bench6(a.intervals, 100.0, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)
+
+
+def main_bench1(argv=None):
+    ap = argparse.ArgumentParser(description="PFHub BM1 on MI355X (counterpart of dolfin/bench1.py)")
+    ap.add_argument("--intervals", type=int, default=200, help="grid intervals per side (h = 200/intervals)")
+    ap.add_argument("--scheme", default="fd", choices=["fd", "spectral"])
+    ap.add_argument("--dt", type=float, default=None)
+    ap.add_argument("--end-time", type=float, default=1e3)
+    ap.add_argument("--out-dir", default="results")
+    ap.add_argument("--save-solution", action="store_true")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args(argv)
+    run_bench1(a.intervals, 200.0, a.scheme, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)

@@ -97,6 +97,12 @@ class PhaseFieldSolver:
         self._ck(self._lib.pf_get_field(self._h, _lib.PF_FIELD_C, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
+    def get_phi(self):
+        """BM6 only: the electrostatic potential consistent with the current c (bench6.py:225 `phi`)."""
+        out = np.empty(self.shape, dtype=np.float64)
+        self._ck(self._lib.pf_get_field(self._h, _lib.PF_FIELD_PHI, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
     # -- stepping
     def step(self, dt, nsteps=1, check=False):
         """Advance; with check=True returns (ok, cmin, cmax) like the reference's `converged` flag."""

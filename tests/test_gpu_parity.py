@@ -263,3 +263,97 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape):
         s.step(1e-2)
         sp.step(1e-2)
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
+
+
+def test_bench1_driver_rows_against_fixture_and_oracle(lib, orc, golden_dir, tmp_path):
+    """bench1 driver end to end on the GPU (first rows): CSV format identical to the reference's, rows at the
+    fixture's times, values = the FD oracle's to 1e-12 and within the documented physical distance of the fixture."""
+    import os
+    from oracle import fem_be
+    from pfhubbenchmarks_amd.drivers import run_bench1
+    rows, _ = run_bench1(intervals=100, scheme="fd", dt=0.02, end_time=3.0, out_dir=str(tmp_path), verbose=False)
+    csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
+    assert rows.shape == (5, 3)                       # t = 0.1 .. 3.1: the first row past end_time is still emitted
+    np.testing.assert_allclose(rows[:, 0], csv[:5, 0], rtol=0, atol=1e-12)
+    text = open(os.path.join(str(tmp_path), "bench1_out.csv")).read().splitlines()
+    assert text[0] == "time,total_free_energy,total_solute" and len(text) == 6
+    assert text[1].split(",")[0] == "0.1000000000"
+    assert os.path.exists(os.path.join(str(tmp_path), "bench1", "stats.csv"))
+    # oracle replay of the same sub-stepping
+    x = np.arange(101) * 2.0
+    e = orc.even_extend(fem_be.ic_bm1(x[None, :], x[:, None]))
+    t = 0.0
+    for i, tn in enumerate(csv[:5, 0]):
+        n = int(np.floor((tn - t) / 0.02 + 1e-12))
+        for _ in range(n):
+            e = orc.fd_step(e, 0.02, h=2.0)
+        t += n * 0.02
+        if tn - t > 1e-14:
+            e = orc.fd_step(e, tn - t, h=2.0)
+        t = tn
+        F, C, _ = orc.diagnostics(e, h=2.0, mirror=True)
+        assert abs(rows[i, 1] - F) <= 1e-9 * abs(F)   # IC differs by ulps (device cos) -> not bitwise
+        assert abs(rows[i, 2] - C) <= 1e-12 * abs(C)
+    # physical distance to the reference's backward-Euler trajectory (SURVEY 7.0-5): grows with the reference's dt
+    rel = np.abs(rows[:, 1] - csv[:5, 1]) / csv[:5, 1]
+    assert rel[0] < 3e-3 and rel.max() < 3e-2
+
+
+def test_bm6_reference_boundary_conditions(lib, golden_dir):
+    """BM6 (bench6.py): Poisson solve with phi = 0 / sin(y/7) on x = 0 / Lx + coupled FD step vs the CPU restatement
+    (oracle/bm6_fd.py); then the physical distance to the reference's first CSV row."""
+    import os
+    from oracle import bm6_fd, ch_fd, fem_be
+    n, h = 101, 1.0
+    x = np.arange(n) * h
+    c = fem_be.ic_bm6(x[None, :], x[:, None])
+    o = bm6_fd.BM6FD(ch_fd.even_extend(c), h, (n, n))
+    with PhaseFieldSolver(dim=2, n=n, h=h, bc="mirror", model="bm6") as s:
+        s.set_ic_bm6(0.5, 0.04)
+        assert np.abs(s.get_c() - c).max() < 1e-14
+        s.set_c(c)
+        phi = s.get_phi()
+        pref = o.phi()[:n, :n]
+        assert np.abs(phi - pref).max() <= 1e-12
+        assert np.abs(phi[:, 0]).max() == 0.0 and np.abs(phi[:, -1] - np.sin(x / 7.0)).max() < 1e-15
+        F, C, E = s.diagnostics()
+        Fo, Co, Eo = o.diagnostics()
+        assert abs(F - Fo) <= 1e-12 * abs(Fo) and abs(C - Co) <= 1e-13 * abs(Co) and abs(E - Eo) <= 1e-11 * abs(Eo)
+        s.step(5e-4, 20)
+        o.step(5e-4, 20)
+        assert np.abs(s.get_c() - o.c[:n, :n]).max() <= 1e-12
+        F, C, E = s.diagnostics()
+        Fo, Co, Eo = o.diagnostics()
+        assert abs(F - Fo) <= 1e-12 * abs(Fo) and abs(C - Co) <= 1e-13 * abs(Co)
+        csv = np.loadtxt(os.path.join(golden_dir, "bench6_out.csv"), delimiter=",", skiprows=1)
+        assert abs(F - csv[0, 1]) / csv[0, 1] < 1e-3      # t = 0.01: two discretisations of the same PDE
+        assert abs(C - csv[0, 2]) / csv[0, 2] < 1e-4
+
+
+def test_bm6_periodic_box_3d(lib):
+    from oracle import bm6_fd
+    rng = np.random.default_rng(21)
+    shape = (12, 20, 128)
+    c = 0.5 + 0.04 * rng.standard_normal(shape)
+    o = bm6_fd.BM6FD(c, 1.0)
+    with PhaseFieldSolver(dim=3, n=shape[::-1], h=1.0, model="bm6") as s:
+        s.set_c(c)
+        assert np.abs(s.get_phi() - o.phi()).max() <= 1e-12
+        s.step(5e-4, 5)
+        o.step(5e-4, 5)
+        assert np.abs(s.get_c() - o.c).max() <= 1e-12
+        F, C, E = s.diagnostics()
+        Fo, Co, Eo = o.diagnostics()
+        assert abs(F - Fo) <= 1e-12 * abs(Fo) and abs(C - Co) <= 1e-13 * abs(Co)
+
+
+def test_bench6_driver(lib, golden_dir, tmp_path):
+    import os
+    from pfhubbenchmarks_amd.drivers import run_bench6
+    rows, _ = run_bench6(intervals=100, end_time=0.1, out_dir=str(tmp_path), verbose=False)
+    csv = np.loadtxt(os.path.join(golden_dir, "bench6_out.csv"), delimiter=",", skiprows=1)
+    assert rows.shape == (4, 3)
+    np.testing.assert_allclose(rows[:, 0], csv[:4, 0], atol=1e-12)
+    rel = np.abs(rows[:, 1] - csv[:4, 1]) / csv[:4, 1]
+    assert rel.max() < 1e-3
+    assert open(os.path.join(str(tmp_path), "bench6_out.csv")).readline().strip() == "time,total_free_energy,total_solute"
