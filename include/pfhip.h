@@ -49,7 +49,13 @@ typedef enum pf_status {
 } pf_status;
 
 enum { PF_BC_PERIODIC = 0, PF_BC_MIRROR = 1 };           /* mirror = natural no-flux BC (bench1.py:69) */
-enum { PF_SCHEME_FD_EXPLICIT = 0, PF_SCHEME_SPECTRAL_SI = 1 };
+enum {
+  PF_SCHEME_FD_EXPLICIT = 0, /* explicit finite differences, fused stencil kernel (the throughput path) */
+  PF_SCHEME_SPECTRAL_SI = 1, /* semi-implicit Fourier spectral (rocFFT) */
+  PF_SCHEME_FEM_BE = 2       /* BE-parity mode: the reference's own P1 'crossed'-mesh backward-Euler Newton solve
+                                (bench1.py:21-110) -- 2-D, PF_BC_MIRROR, n[0] == n[1] = corner nodes per side;
+                                fields are in the reference's node order: (n*n corners, then (n-1)*(n-1) centres) */
+};
 enum { PF_MODEL_BM1 = 1, PF_MODEL_BM6 = 6 };
 enum { PF_FIELD_C = 0, PF_FIELD_MU = 1, PF_FIELD_PHI = 2 };
 enum { PF_KERNEL_AUTO = 0, PF_KERNEL_FUSED = 1, PF_KERNEL_TWOPASS = 2 }; /* FD step implementation */
@@ -81,6 +87,8 @@ typedef struct pf_step_info {
   int32_t ok;        /* 1 if the state after the step(s) is finite and inside the guard band c in [-1, 2] */
   int32_t nsteps;    /* steps actually taken */
   double cmin, cmax; /* global extrema after the last step (local extrema in slab mode) */
+  int32_t iters;     /* PF_SCHEME_FEM_BE: Newton iterations of the last step (the reference's `niters`) */
+  int32_t reserved0;
 } pf_step_info;
 
 /* Ghost-plane layout of one rank's c buffer in slab mode (element offsets into the CURRENT c buffer). */

@@ -1,0 +1,624 @@
+// BE-parity mode: the reference's OWN discretisation and time integrator on the GPU.
+//
+//   mesh      RectangleMesh(..., N, N, 'crossed')                       dolfin/bench1.py:21-23, bench6.py:22-24
+//   space     P1 x P1 (c, mu) [x P1 (phi)]                              bench1.py:39-41, bench6.py:42-46
+//   form      backward Euler, monolithic: cahn_hilliard_weak_form       dolfin/pfbase.py:361-383
+//             (+ poisson_weak_form pfbase.py:410-421, dfdc += k phi, Dirichlet phi: bench6.py:61-90)
+//   quadrature degree 3 -> 6-point Strang-Fix rule for f'(c), f''(c), f(c)     bench1.py:14-16
+//   solver    Newton on ||R||_2 < 1e-6 (bench1.py:85-88), full steps; the reference's GMRES+SOR inner solve
+//             (bench1.py:98-99) is replaced by a DIRECT block-tridiagonal LU: with unknowns grouped by mesh row
+//             ({corner row j, centre row j}) the Jacobian is block tridiagonal with (2N+1) nf-sized blocks, factored
+//             by a block Thomas sweep (rocSOLVER getrf/getrs + rocBLAS gemm per block).  Robust at every dt of the
+//             reference run (0.1 .. 102.4), where unpreconditioned Krylov stalls.
+//   diagnostics  total_solute / total_free_energy with the same element quadrature     bench1.py:121-125
+//
+// Node numbering = the reference's (and its VTU files'): corners i + (N+1) j, then centres (N+1)^2 + i + N j.
+// CPU restatement (pinned against the reference's committed results to <= 5e-9): oracle/fem_be.py.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <type_traits>
+#include <vector>
+
+#include "pfhip_internal.h"
+
+namespace pfhip {
+
+namespace {
+
+// Strang-Fix 6-point rule: all permutations of (A, B, C), weights 1/6 -- same order as oracle/fem_be.py
+#define SFA 0.659027622374092
+#define SFB 0.231933368553031
+#define SFC 0.109039009072877
+__constant__ double LAM[6][3] = {{SFA, SFB, SFC}, {SFA, SFC, SFB}, {SFB, SFA, SFC},
+                                 {SFB, SFC, SFA}, {SFC, SFA, SFB}, {SFC, SFB, SFA}};
+
+constexpr int ELLW = 9;  // max row length of K / M on the crossed mesh (corner: self + 4 corners + 4 centres)
+
+struct FemParams {
+  int N, nn, ntri, nf, nb, ng;  // intervals, nodes, triangles, fields, block size, groups
+  double h, area;
+  double ca, cb, two_rho, rho, kappa, Mob, kq, k_over_eps;
+  double L;
+};
+
+__device__ __forceinline__ double d_fp(const FemParams& p, double c) {
+  const double a = c - p.ca, b = p.cb - c;
+  return p.two_rho * ((a * b) * (b - a));
+}
+__device__ __forceinline__ double d_fpp(const FemParams& p, double c) {
+  const double a = c - p.ca, b = p.cb - c;
+  return p.two_rho * ((b * b - 4.0 * (a * b)) + a * a);
+}
+__device__ __forceinline__ double d_f(const FemParams& p, double c) {
+  const double a = c - p.ca, b = p.cb - c;
+  return p.rho * ((a * a) * (b * b));
+}
+
+// node -> (group, local index inside the group's block)
+__device__ __forceinline__ void node_block(const FemParams& p, int n, int& g, int& l) {
+  const int n1 = p.N + 1;
+  if (n < n1 * n1) {
+    g = n / n1;
+    l = n % n1;
+  } else {
+    const int m = n - n1 * n1;
+    g = m / p.N;
+    l = n1 + m % p.N;
+  }
+}
+__device__ __forceinline__ bool is_dirichlet(const FemParams& p, int n) {  // phi rows, BM6: x = 0 or x = L corners
+  const int n1 = p.N + 1;
+  if (n >= n1 * n1) return false;
+  const int i = n % n1;
+  return i == 0 || i == p.N;
+}
+__device__ __forceinline__ double phi_bc(const FemParams& p, int n) {  // bench6.py:77-90
+  const int n1 = p.N + 1;
+  const int i = n % n1, j = n / n1;
+  return i == 0 ? 0.0 : sin((j * p.h) / 7.0);
+}
+
+// ---- residual (one thread per node; fixed summation order -> deterministic) ---------------------------------
+__global__ __launch_bounds__(256) void fem_residual_kernel(const FemParams p, const int* __restrict__ ell_col,
+                                                           const double* __restrict__ ell_K,
+                                                           const double* __restrict__ ell_M,
+                                                           const int* __restrict__ nt_ptr, const int* __restrict__ nt_tri,
+                                                           const int* __restrict__ nt_loc, const int* __restrict__ tri,
+                                                           const double* __restrict__ c, const double* __restrict__ mu,
+                                                           const double* __restrict__ phi, const double* __restrict__ c0,
+                                                           double inv_dt, double* __restrict__ rhs) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.nn) return;
+  double m_dc = 0.0, k_mu = 0.0, m_mu = 0.0, k_c = 0.0, m_phi = 0.0, k_phi = 0.0, m_c = 0.0;
+  for (int e = 0; e < ELLW; ++e) {
+    const int col = ell_col[n * ELLW + e];
+    if (col < 0) continue;
+    const double Kv = ell_K[n * ELLW + e], Mv = ell_M[n * ELLW + e];
+    m_dc += Mv * (c[col] - c0[col]);
+    k_mu += Kv * mu[col];
+    m_mu += Mv * mu[col];
+    k_c += Kv * c[col];
+    if (p.nf == 3) {
+      m_phi += Mv * phi[col];
+      k_phi += Kv * phi[col];
+      m_c += Mv * c[col];
+    }
+  }
+  double g = 0.0;
+  for (int t = nt_ptr[n]; t < nt_ptr[n + 1]; ++t) {
+    const int* tn = tri + 3 * nt_tri[t];
+    const int loc = nt_loc[t];
+    const double c0e = c[tn[0]], c1e = c[tn[1]], c2e = c[tn[2]];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double cq = (LAM[q][0] * c0e + LAM[q][1] * c1e) + LAM[q][2] * c2e;
+      acc += d_fp(p, cq) * LAM[q][loc];
+    }
+    g += acc * (p.area / 6.0);
+  }
+  const double Rc = m_dc * inv_dt + p.Mob * k_mu;
+  double Rmu = (m_mu - g) - p.kappa * k_c;
+  if (p.nf == 3) Rmu -= p.kq * m_phi;
+  int grp, loc;
+  node_block(p, n, grp, loc);
+  double* r = rhs + (int64_t)grp * p.nb + loc * p.nf;
+  r[0] = -Rc;
+  r[1] = -Rmu;
+  if (p.nf == 3) {
+    double Rphi = -k_phi + p.k_over_eps * m_c;
+    if (is_dirichlet(p, n)) Rphi = phi[n] - phi_bc(p, n);
+    r[2] = -Rphi;
+  }
+}
+
+// ---- Jacobian blocks (one thread per triangle, atomic adds into the dense blocks) ----------------------------
+__device__ __forceinline__ void jadd(const FemParams& p, double* D, double* Lo, double* Up, int ga, int la, int fa,
+                                     int gb, int lb, int fb, double v) {
+  const int64_t bs = (int64_t)p.nb * p.nb;
+  const int row = la * p.nf + fa, col = lb * p.nf + fb;
+  double* base = gb == ga ? D + ga * bs : (gb == ga - 1 ? Lo + ga * bs : Up + ga * bs);
+  atomicAdd(base + row + (int64_t)col * p.nb, v);
+}
+
+__global__ __launch_bounds__(256) void fem_jacobian_kernel(const FemParams p, const int* __restrict__ tri,
+                                                           const double* __restrict__ Ke, const double* __restrict__ c,
+                                                           double inv_dt, double* D, double* Lo, double* Up) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.ntri) return;
+  const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+  const double ce[3] = {c[n[0]], c[n[1]], c[n[2]]};
+  double G[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const double cq = (LAM[q][0] * ce[0] + LAM[q][1] * ce[1]) + LAM[q][2] * ce[2];
+    const double w = d_fpp(p, cq) * (p.area / 6.0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) G[i][j] += w * (LAM[q][i] * LAM[q][j]);
+  }
+  int g[3], l[3];
+  for (int i = 0; i < 3; ++i) node_block(p, n[i], g[i], l[i]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double Mij = p.area / 12.0 * (i == j ? 2.0 : 1.0);
+      const double Kij = Ke[9 * t + 3 * i + j];
+      jadd(p, D, Lo, Up, g[i], l[i], 0, g[j], l[j], 0, Mij * inv_dt);
+      jadd(p, D, Lo, Up, g[i], l[i], 0, g[j], l[j], 1, p.Mob * Kij);
+      jadd(p, D, Lo, Up, g[i], l[i], 1, g[j], l[j], 0, -(G[i][j] + p.kappa * Kij));
+      jadd(p, D, Lo, Up, g[i], l[i], 1, g[j], l[j], 1, Mij);
+      if (p.nf == 3) {
+        jadd(p, D, Lo, Up, g[i], l[i], 1, g[j], l[j], 2, -p.kq * Mij);
+        if (!is_dirichlet(p, n[i])) {
+          jadd(p, D, Lo, Up, g[i], l[i], 2, g[j], l[j], 0, p.k_over_eps * Mij);
+          jadd(p, D, Lo, Up, g[i], l[i], 2, g[j], l[j], 2, -Kij);
+        }
+      }
+    }
+}
+
+// identity rows: padding unknowns of the last group (it has no centre row) and Dirichlet phi rows
+__global__ __launch_bounds__(256) void fem_identity_kernel(const FemParams p, double* D) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int64_t bs = (int64_t)p.nb * p.nb;
+  const int n1 = p.N + 1;
+  const int npad = p.N * p.nf;  // padding unknowns in the last group
+  if (idx < npad) {
+    const int u = n1 * p.nf + idx;
+    D[(int64_t)(p.ng - 1) * bs + u + (int64_t)u * p.nb] = 1.0;
+  } else if (p.nf == 3 && idx < npad + 2 * n1) {
+    const int k = idx - npad;
+    const int j = k >> 1, i = (k & 1) ? p.N : 0;  // corner (i, j) on x = 0 / x = L
+    const int u = i * p.nf + 2;
+    D[(int64_t)j * bs + u + (int64_t)u * p.nb] = 1.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void fem_update_kernel(const FemParams p, const double* __restrict__ sol, double* c,
+                                                         double* mu, double* phi) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.nn) return;
+  int g, l;
+  node_block(p, n, g, l);
+  const double* s = sol + (int64_t)g * p.nb + l * p.nf;
+  c[n] += s[0];
+  mu[n] += s[1];
+  if (p.nf == 3) phi[n] += s[2];
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
+  // single block, fixed order -> deterministic; n is ~1e5
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += v[i] * v[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// diagnostics: per-triangle contributions, reduced per block then by a final block
+__global__ __launch_bounds__(256) void fem_diag_kernel(const FemParams p, const int* __restrict__ tri,
+                                                       const double* __restrict__ Ke, const double* __restrict__ c,
+                                                       const double* __restrict__ phi, double* __restrict__ partials) {
+  __shared__ double sh[3][4];
+  double sC = 0.0, sF = 0.0, sE = 0.0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < p.ntri; t += gridDim.x * 256) {
+    const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    const double ce[3] = {c[n[0]], c[n[1]], c[n[2]]};
+    sC += p.area * (((ce[0] + ce[1]) + ce[2]) / 3.0);
+    double fq = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) fq += d_f(p, (LAM[q][0] * ce[0] + LAM[q][1] * ce[1]) + LAM[q][2] * ce[2]);
+    double grad = 0.0;  // A |grad c|^2 = c_e^T K_e c_e
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) grad += ce[i] * Ke[9 * t + 3 * i + j] * ce[j];
+    sF += p.area * fq / 6.0 + 0.5 * p.kappa * grad;
+    if (p.nf == 3) {
+      const double pe[3] = {phi[n[0]], phi[n[1]], phi[n[2]]};
+      double cm = 0.0;  // c_e^T M_e phi_e, M_e = A/12 (1 + delta)
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) cm += ce[i] * (i == j ? 2.0 : 1.0) * pe[j];
+      sE += 0.5 * p.kq * (p.area / 12.0) * cm;
+    }
+  }
+  double v[3] = {sC, sF, sE};
+  for (int k = 0; k < 3; ++k) {
+    double a = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    partials[blockIdx.x * 3 + k] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+  }
+}
+
+__global__ void fem_diag_final_kernel(const double* __restrict__ partials, int nb, double* __restrict__ out3) {
+  if (threadIdx.x < 3) {
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += partials[b * 3 + threadIdx.x];
+    out3[threadIdx.x] = a;
+  }
+}
+
+// initial condition at the mesh nodes (pfbase.py:187-189 / :332-334); mu = 0, phi = boundary values only
+__global__ __launch_bounds__(256) void fem_ic_kernel(const FemParams p, double c0, double amp, double w0, double* c,
+                                                     double* mu, double* phi) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.nn) return;
+  const int n1 = p.N + 1;
+  double X, Y;
+  if (n < n1 * n1) {
+    X = (n % n1) * p.h;
+    Y = (n / n1) * p.h;
+  } else {
+    const int m = n - n1 * n1;
+    X = (m % p.N + 0.5) * p.h;
+    Y = (m / p.N + 0.5) * p.h;
+  }
+  const double t2 = cos(0.13 * X) * cos(0.087 * Y);
+  c[n] = c0 + amp * (cos(w0 * X) * cos(0.11 * Y) + t2 * t2 + cos(0.025 * X - 0.15 * Y) * cos(0.07 * X - 0.02 * Y));
+  mu[n] = 0.0;
+  if (p.nf == 3) phi[n] = is_dirichlet(p, n) ? phi_bc(p, n) : 0.0;
+}
+
+}  // namespace
+
+struct FemBE {
+  FemParams p;
+  hipStream_t stream = nullptr;
+  rocblas_handle bh = nullptr;
+  // mesh tables
+  int *tri = nullptr, *ell_col = nullptr, *nt_ptr = nullptr, *nt_tri = nullptr, *nt_loc = nullptr;
+  double *Ke = nullptr, *ell_K = nullptr, *ell_M = nullptr;
+  // state (node order) + previous accepted state
+  double *c = nullptr, *mu = nullptr, *phi = nullptr, *c0 = nullptr, *mu0 = nullptr, *phi0 = nullptr;
+  // linear system
+  double *D = nullptr, *Lo = nullptr, *Up = nullptr, *rhs = nullptr;
+  rocblas_int *piv = nullptr, *info = nullptr;
+  double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
+  double atol = 1e-6;
+  int max_newton = 100;
+  int last_iters = 0;
+  bool have_prev = false;
+  std::string err;
+};
+
+#define FB_HIP(expr)                                                       \
+  do {                                                                     \
+    hipError_t e_ = (expr);                                                \
+    if (e_ != hipSuccess) {                                                \
+      fb->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+      return -3;                                                           \
+    }                                                                      \
+  } while (0)
+#define FB_BLAS(expr)                                                      \
+  do {                                                                     \
+    rocblas_status s_ = (expr);                                            \
+    if (s_ != rocblas_status_success) {                                    \
+      fb->err = std::string(#expr) + ": rocblas status " + std::to_string((int)s_); \
+      return -3;                                                           \
+    }                                                                      \
+  } while (0)
+
+const char* fembe_error(const FemBE* fb) { return fb->err.c_str(); }
+int fembe_nodes(const FemBE* fb) { return fb->p.nn; }
+int fembe_last_iters(const FemBE* fb) { return fb->last_iters; }
+
+int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, double ca, double cb, double kappa,
+                 double Mob, double k, double eps, hipStream_t stream, std::string* err) {
+  FemBE* fb = new FemBE();
+  *out = fb;
+  FemParams& p = fb->p;
+  const int N = nodes_per_side - 1, n1 = N + 1;
+  p.N = N;
+  p.nn = n1 * n1 + N * N;
+  p.ntri = 4 * N * N;
+  p.nf = nf;
+  p.nb = (2 * N + 1) * nf;
+  p.ng = N + 1;
+  p.h = h;
+  p.area = h * h / 4.0;
+  p.ca = ca;
+  p.cb = cb;
+  p.two_rho = 2.0 * rho;
+  p.rho = rho;
+  p.kappa = kappa;
+  p.Mob = Mob;
+  p.kq = k;
+  p.k_over_eps = k / eps;
+  p.L = N * h;
+  fb->stream = stream;
+  auto body = [&]() -> int {
+    // ---- host tables
+    std::vector<double> X(p.nn), Y(p.nn);
+    for (int j = 0; j < n1; ++j)
+      for (int i = 0; i < n1; ++i) {
+        X[i + n1 * j] = i * h;
+        Y[i + n1 * j] = j * h;
+      }
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        X[n1 * n1 + i + N * j] = (i + 0.5) * h;
+        Y[n1 * n1 + i + N * j] = (j + 0.5) * h;
+      }
+    std::vector<int> tri(3 * (size_t)p.ntri);
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        const int sw = i + n1 * j, se = sw + 1, nw = sw + n1, ne = nw + 1, ct = n1 * n1 + i + N * j;
+        const int q = 4 * (i + N * j);
+        const int t4[4][3] = {{sw, se, ct}, {sw, nw, ct}, {se, ne, ct}, {nw, ne, ct}};  // order of the reference VTU
+        for (int a = 0; a < 4; ++a)
+          for (int b = 0; b < 3; ++b) tri[3 * (q + a) + b] = t4[a][b];
+      }
+    std::vector<double> Ke(9 * (size_t)p.ntri);
+    std::vector<std::vector<std::pair<int, std::pair<double, double>>>> rows(p.nn);  // col -> (K, M)
+    std::vector<std::vector<std::pair<int, int>>> ntl(p.nn);
+    for (int t = 0; t < p.ntri; ++t) {
+      const int* n = &tri[3 * t];
+      const double x0 = X[n[0]], x1 = X[n[1]], x2 = X[n[2]], y0 = Y[n[0]], y1 = Y[n[1]], y2 = Y[n[2]];
+      const double b[3] = {y1 - y2, y2 - y0, y0 - y1}, c[3] = {x2 - x1, x0 - x2, x1 - x0};
+      const double det = x0 * b[0] + x1 * b[1] + x2 * b[2];
+      const double area = 0.5 * std::fabs(det);
+      for (int i = 0; i < 3; ++i) {
+        ntl[n[i]].push_back({t, i});
+        for (int j = 0; j < 3; ++j) {
+          const double kij = area * ((b[i] / det) * (b[j] / det) + (c[i] / det) * (c[j] / det));
+          const double mij = area / 12.0 * (i == j ? 2.0 : 1.0);
+          Ke[9 * (size_t)t + 3 * i + j] = kij;
+          auto& row = rows[n[i]];
+          bool found = false;
+          for (auto& e : row)
+            if (e.first == n[j]) {
+              e.second.first += kij;
+              e.second.second += mij;
+              found = true;
+              break;
+            }
+          if (!found) row.push_back({n[j], {kij, mij}});
+        }
+      }
+    }
+    std::vector<int> ell_col((size_t)p.nn * ELLW, -1), nt_ptr(p.nn + 1, 0), nt_tri, nt_loc;
+    std::vector<double> ell_K((size_t)p.nn * ELLW, 0.0), ell_M((size_t)p.nn * ELLW, 0.0);
+    for (int n = 0; n < p.nn; ++n) {
+      if ((int)rows[n].size() > ELLW) {
+        fb->err = "ELL width exceeded";
+        return -1;
+      }
+      for (size_t e = 0; e < rows[n].size(); ++e) {
+        ell_col[(size_t)n * ELLW + e] = rows[n][e].first;
+        ell_K[(size_t)n * ELLW + e] = rows[n][e].second.first;
+        ell_M[(size_t)n * ELLW + e] = rows[n][e].second.second;
+      }
+      nt_ptr[n + 1] = nt_ptr[n] + (int)ntl[n].size();
+      for (auto& e : ntl[n]) {
+        nt_tri.push_back(e.first);
+        nt_loc.push_back(e.second);
+      }
+    }
+    // ---- device
+    auto up = [&](auto** dptr, const auto& v) -> hipError_t {
+      using T = typename std::remove_reference<decltype(v[0])>::type;
+      hipError_t e = hipMalloc(dptr, sizeof(T) * v.size());
+      if (e != hipSuccess) return e;
+      return hipMemcpy(*dptr, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    };
+    FB_HIP(up(&fb->tri, tri));
+    FB_HIP(up(&fb->Ke, Ke));
+    FB_HIP(up(&fb->ell_col, ell_col));
+    FB_HIP(up(&fb->ell_K, ell_K));
+    FB_HIP(up(&fb->ell_M, ell_M));
+    FB_HIP(up(&fb->nt_ptr, nt_ptr));
+    FB_HIP(up(&fb->nt_tri, nt_tri));
+    FB_HIP(up(&fb->nt_loc, nt_loc));
+    const size_t nb = sizeof(double) * p.nn;
+    for (double** f : {&fb->c, &fb->mu, &fb->phi, &fb->c0, &fb->mu0, &fb->phi0}) {
+      FB_HIP(hipMalloc(f, nb));
+      FB_HIP(hipMemset(*f, 0, nb));
+    }
+    const size_t bs = sizeof(double) * (size_t)p.nb * p.nb * p.ng;
+    FB_HIP(hipMalloc(&fb->D, bs));
+    FB_HIP(hipMalloc(&fb->Lo, bs));
+    FB_HIP(hipMalloc(&fb->Up, bs));
+    FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * (size_t)p.nb * p.ng));
+    FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
+    FB_HIP(hipMalloc(&fb->info, sizeof(rocblas_int) * p.ng));
+    FB_HIP(hipMalloc(&fb->scal, sizeof(double) * 4));
+    FB_HIP(hipMalloc(&fb->partials, sizeof(double) * 3 * 256));
+    FB_HIP(hipHostMalloc(&fb->scal_host, sizeof(double) * 4, hipHostMallocDefault));
+    FB_BLAS(rocblas_create_handle(&fb->bh));
+    FB_BLAS(rocblas_set_stream(fb->bh, stream));
+    FB_BLAS(rocblas_set_pointer_mode(fb->bh, rocblas_pointer_mode_host));
+    return 0;
+  };
+  int rc = body();
+  if (rc && err) *err = fb->err;
+  return rc;
+}
+
+void fembe_destroy(FemBE* fb) {
+  if (!fb) return;
+  if (fb->bh) (void)rocblas_destroy_handle(fb->bh);
+  for (void* q : {(void*)fb->tri, (void*)fb->Ke, (void*)fb->ell_col, (void*)fb->ell_K, (void*)fb->ell_M,
+                  (void*)fb->nt_ptr, (void*)fb->nt_tri, (void*)fb->nt_loc, (void*)fb->c, (void*)fb->mu, (void*)fb->phi,
+                  (void*)fb->c0, (void*)fb->mu0, (void*)fb->phi0, (void*)fb->D, (void*)fb->Lo, (void*)fb->Up,
+                  (void*)fb->rhs, (void*)fb->piv, (void*)fb->info, (void*)fb->scal, (void*)fb->partials})
+    if (q) (void)hipFree(q);
+  if (fb->scal_host) (void)hipHostFree(fb->scal_host);
+  delete fb;
+}
+
+int fembe_set_ic(FemBE* fb, double c0, double amp, double w0) {
+  const FemParams& p = fb->p;
+  hipLaunchKernelGGL(fem_ic_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, c0, amp, w0, fb->c, fb->mu,
+                     fb->phi);
+  FB_HIP(hipGetLastError());
+  fb->have_prev = false;
+  return 0;
+}
+
+// c (node order) from / to host; setting c resets mu = 0 and phi = boundary values (the reference's IC convention)
+int fembe_set_c(FemBE* fb, const double* host) {
+  const FemParams& p = fb->p;
+  FB_HIP(hipMemcpyAsync(fb->c, host, sizeof(double) * p.nn, hipMemcpyHostToDevice, fb->stream));
+  FB_HIP(hipMemsetAsync(fb->mu, 0, sizeof(double) * p.nn, fb->stream));
+  if (p.nf == 3) {
+    std::vector<double> ph(p.nn, 0.0);
+    const int n1 = p.N + 1;
+    for (int j = 0; j < n1; ++j) ph[p.N + n1 * j] = std::sin((j * p.h) / 7.0);
+    FB_HIP(hipMemcpyAsync(fb->phi, ph.data(), sizeof(double) * p.nn, hipMemcpyHostToDevice, fb->stream));
+  }
+  FB_HIP(hipStreamSynchronize(fb->stream));
+  fb->have_prev = false;
+  return 0;
+}
+
+int fembe_get(FemBE* fb, int field, double* host) {
+  const double* src = field == 0 ? fb->c : (field == 1 ? fb->mu : fb->phi);
+  FB_HIP(hipMemcpyAsync(host, src, sizeof(double) * fb->p.nn, hipMemcpyDeviceToHost, fb->stream));
+  FB_HIP(hipStreamSynchronize(fb->stream));
+  return 0;
+}
+
+static int residual_norm(FemBE* fb, double inv_dt, double* nrm) {
+  const FemParams& p = fb->p;
+  FB_HIP(hipMemsetAsync(fb->rhs, 0, sizeof(double) * (size_t)p.nb * p.ng, fb->stream));
+  hipLaunchKernelGGL(fem_residual_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->ell_col, fb->ell_K,
+                     fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
+                     fb->rhs);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, p.nb * p.ng, fb->scal);
+  FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, sizeof(double), hipMemcpyDeviceToHost, fb->stream));
+  FB_HIP(hipStreamSynchronize(fb->stream));
+  *nrm = std::sqrt(fb->scal_host[0]);
+  return 0;
+}
+
+// block Thomas: solves J x = rhs in place (rhs -> x); D, Lo, Up are destroyed
+static int block_solve(FemBE* fb) {
+  const FemParams& p = fb->p;
+  const int nb = p.nb, ng = p.ng;
+  const int64_t bs = (int64_t)nb * nb;
+  const double one = 1.0, mone = -1.0;
+  for (int g = 0; g < ng; ++g) {
+    double* Dg = fb->D + g * bs;
+    double* rg = fb->rhs + (int64_t)g * nb;
+    rocblas_int* pg = fb->piv + (int64_t)g * nb;
+    if (g > 0) {
+      // D_g -= Lo_g * X_{g-1} (X stored in Up_{g-1});  r_g -= Lo_g * y_{g-1}
+      FB_BLAS(rocblas_dgemm(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone, fb->Lo + g * bs,
+                            nb, fb->Up + (g - 1) * bs, nb, &one, Dg, nb));
+      FB_BLAS(rocblas_dgemv(fb->bh, rocblas_operation_none, nb, nb, &mone, fb->Lo + g * bs, nb, rg - nb, 1, &one, rg, 1));
+    }
+    FB_BLAS(rocsolver_dgetrf(fb->bh, nb, nb, Dg, nb, pg, fb->info + g));
+    if (g + 1 < ng) FB_BLAS(rocsolver_dgetrs(fb->bh, rocblas_operation_none, nb, nb, Dg, nb, pg, fb->Up + g * bs, nb));
+    FB_BLAS(rocsolver_dgetrs(fb->bh, rocblas_operation_none, nb, 1, Dg, nb, pg, rg, nb));
+  }
+  for (int g = ng - 2; g >= 0; --g) {
+    double* rg = fb->rhs + (int64_t)g * nb;
+    FB_BLAS(rocblas_dgemv(fb->bh, rocblas_operation_none, nb, nb, &mone, fb->Up + g * bs, nb, rg + nb, 1, &one, rg, 1));
+  }
+  return 0;
+}
+
+// one backward-Euler step; *converged = 0 leaves the state unchanged (bench1.py:164-177 then halves dt)
+int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
+  const FemParams& p = fb->p;
+  const size_t nbytes = sizeof(double) * p.nn;
+  FB_HIP(hipMemcpyAsync(fb->c0, fb->c, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  FB_HIP(hipMemcpyAsync(fb->mu0, fb->mu, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  FB_HIP(hipMemcpyAsync(fb->phi0, fb->phi, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  const double inv_dt = 1.0 / dt;
+  const size_t bsz = sizeof(double) * (size_t)p.nb * p.nb * p.ng;
+  *converged = 0;
+  int it = 0;
+  for (;; ++it) {
+    double nrm = 0.0;
+    int rc = residual_norm(fb, inv_dt, &nrm);
+    if (rc) return rc;
+    if (!(nrm == nrm)) break;  // NaN
+    if (nrm < fb->atol) {
+      *converged = 1;
+      break;
+    }
+    if (it == fb->max_newton) break;
+    FB_HIP(hipMemsetAsync(fb->D, 0, bsz, fb->stream));
+    FB_HIP(hipMemsetAsync(fb->Lo, 0, bsz, fb->stream));
+    FB_HIP(hipMemsetAsync(fb->Up, 0, bsz, fb->stream));
+    hipLaunchKernelGGL(fem_jacobian_kernel, dim3((p.ntri + 255) / 256), dim3(256), 0, fb->stream, p, fb->tri, fb->Ke,
+                       fb->c, inv_dt, fb->D, fb->Lo, fb->Up);
+    const int nid = p.N * p.nf + (p.nf == 3 ? 2 * (p.N + 1) : 0);
+    hipLaunchKernelGGL(fem_identity_kernel, dim3((nid + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
+    FB_HIP(hipGetLastError());
+    rc = block_solve(fb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fem_update_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
+                       (const double*)fb->rhs, fb->c, fb->mu, fb->phi);
+  }
+  *iters = it;
+  fb->last_iters = it;
+  if (*converged) {
+    fb->have_prev = true;
+  } else {
+    FB_HIP(hipMemcpyAsync(fb->c, fb->c0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+    FB_HIP(hipMemcpyAsync(fb->mu, fb->mu0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+    FB_HIP(hipMemcpyAsync(fb->phi, fb->phi0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+    fb->have_prev = false;
+  }
+  FB_HIP(hipStreamSynchronize(fb->stream));
+  return 0;
+}
+
+int fembe_rollback(FemBE* fb) {
+  if (!fb->have_prev) return -4;
+  const size_t nbytes = sizeof(double) * fb->p.nn;
+  FB_HIP(hipMemcpyAsync(fb->c, fb->c0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  FB_HIP(hipMemcpyAsync(fb->mu, fb->mu0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  FB_HIP(hipMemcpyAsync(fb->phi, fb->phi0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  fb->have_prev = false;
+  return 0;
+}
+
+// out = {total_free_energy, total_solute, f_elec part}
+int fembe_diagnostics(FemBE* fb, double out[3]) {
+  const FemParams& p = fb->p;
+  const int nblk = 160;
+  hipLaunchKernelGGL(fem_diag_kernel, dim3(nblk), dim3(256), 0, fb->stream, p, fb->tri, fb->Ke, fb->c, fb->phi,
+                     fb->partials);
+  hipLaunchKernelGGL(fem_diag_final_kernel, dim3(1), dim3(64), 0, fb->stream, (const double*)fb->partials, nblk, fb->scal);
+  FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 3 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));
+  FB_HIP(hipStreamSynchronize(fb->stream));
+  out[0] = fb->scal_host[1] + fb->scal_host[2];
+  out[1] = fb->scal_host[0];
+  out[2] = fb->scal_host[2];
+  return 0;
+}
+
+}  // namespace pfhip

@@ -85,6 +85,7 @@ struct pf_handle {
   double* out6_host = nullptr;  // pinned (8 doubles: 6 raw sums + spectral gradient energy)
   Spectral* sp = nullptr;
   Poisson* po = nullptr;   // BM6
+  FemBE* fb = nullptr;     // PF_SCHEME_FEM_BE
   double* phi = nullptr;   // BM6: phi on the lattice, consistent with c[cur] when phi_valid
   bool phi_valid = false;
   hipStream_t stream = nullptr;
@@ -316,6 +317,8 @@ int64_t pf_field_elems_with_ghosts(const pf_config* cfg) {
 int64_t pf_field_elems(const pf_config* cfg) {
   Geometry g;
   if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
+  if (cfg->scheme == PF_SCHEME_FEM_BE)
+    return (int64_t)g.np[0] * g.np[1] + (int64_t)(g.np[0] - 1) * (g.np[1] - 1);  // corners + centres
   if (g.mirror) return (int64_t)g.np[0] * g.np[1] * g.np[2];
   return g.plane * (int64_t)g.nz;
 }
@@ -328,11 +331,16 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   int rc = resolve(cfg, &g, &err);
   if (rc != PF_OK) return fail(nullptr, rc, err);
   if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6) return fail(nullptr, PF_ERR_INVALID, "bad model");
-  if (cfg->scheme != PF_SCHEME_FD_EXPLICIT && cfg->scheme != PF_SCHEME_SPECTRAL_SI)
+  if (cfg->scheme != PF_SCHEME_FD_EXPLICIT && cfg->scheme != PF_SCHEME_SPECTRAL_SI && cfg->scheme != PF_SCHEME_FEM_BE)
     return fail(nullptr, PF_ERR_INVALID, "bad scheme");
+  if (cfg->scheme == PF_SCHEME_FEM_BE &&
+      (cfg->dim != 2 || cfg->bc != PF_BC_MIRROR || cfg->n[0] != cfg->n[1] || cfg->nranks != 1 || cfg->n[0] < 3))
+    return fail(nullptr, PF_ERR_UNSUPPORTED,
+                "PF_SCHEME_FEM_BE: 2-D, PF_BC_MIRROR (natural no-flux), square mesh, one GPU");
   if (cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->nranks != 1)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "the spectral scheme is single-GPU in this build");
-  if (cfg->model == PF_MODEL_BM6 && (cfg->nranks != 1 || cfg->scheme != PF_SCHEME_FD_EXPLICIT))
+  if (cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_FEM_BE &&
+      (cfg->nranks != 1 || cfg->scheme != PF_SCHEME_FD_EXPLICIT))
     return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is implemented for the FD scheme on one GPU in this build");
   if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
   if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
@@ -376,7 +384,11 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   PF_HIP_C(hipMalloc(&h->partials, sizeof(double) * diag_partials_elems()));
   PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 8));
   PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 8, hipHostMallocDefault));
-  if (cfg->model == PF_MODEL_BM6) {
+  if (cfg->scheme == PF_SCHEME_FEM_BE) {
+    int frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
+                           cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err);
+    if (frc != 0) return bail(PF_ERR_HIP);
+  } else if (cfg->model == PF_MODEL_BM6) {
     PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
     int prc = poisson_create(&h->po, cfg->dim, g.nx, g.ny, g.nzg, g.mirror ? g.np[0] : 0, g.mirror ? g.np[1] : 0,
@@ -408,6 +420,7 @@ int pf_destroy(pf_handle* h) {
   if (h->mu_scratch) (void)hipFree(h->mu_scratch);
   if (h->sp) spectral_destroy(h->sp);
   if (h->po) poisson_destroy(h->po);
+  if (h->fb) fembe_destroy(h->fb);
   if (h->phi) (void)hipFree(h->phi);
   if (h->partials) (void)hipFree(h->partials);
   if (h->out6_dev) (void)hipFree(h->out6_dev);
@@ -420,6 +433,10 @@ int pf_destroy(pf_handle* h) {
 static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   if (!h) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->fb) {
+    if (fembe_set_ic(h->fb, c0, amp, w0) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   const Geometry& g = h->g;
   PF_HIP(h, launch_ic(h->c[h->cur], g.nx, g.ny, g.nz, g.ghost, h->cfg.h, c0, amp, w0, g.mirror ? g.np[0] : 0,
                       g.mirror ? g.np[1] : 0, h->stream));
@@ -436,6 +453,11 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
   if (field != PF_FIELD_C) return fail(h, PF_ERR_UNSUPPORTED, "only PF_FIELD_C can be set");
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->fb) {
+    if ((int64_t)n != fembe_nodes(h->fb)) return fail(h, PF_ERR_INVALID, "pf_set_field: wrong element count");
+    if (fembe_set_c(h->fb, host) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   const Geometry& g = h->g;
   double* dst = h->c[h->cur] + (int64_t)g.ghost * g.plane;
   if (!g.mirror) {
@@ -467,6 +489,13 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
 
 int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
+  if (h->fb) {
+    if (field < PF_FIELD_C || field > PF_FIELD_PHI || (field == PF_FIELD_PHI && h->cfg.model != PF_MODEL_BM6))
+      return fail(h, PF_ERR_INVALID, "pf_get_field: bad field");
+    if ((int64_t)n != fembe_nodes(h->fb)) return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count");
+    if (fembe_get(h->fb, field, host) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   if (field != PF_FIELD_C && !(field == PF_FIELD_PHI && h->po))
     return fail(h, PF_ERR_UNSUPPORTED, "pf_get_field: PF_FIELD_C (or PF_FIELD_PHI for BM6) only; mu is never stored");
   const Geometry& g = h->g;
@@ -497,6 +526,21 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   if (!h) return PF_ERR_INVALID;
   if (nsteps < 0 || !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step: need dt > 0 and nsteps >= 0");
   if (h->cfg.nranks != 1) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
+  if (h->fb) {
+    // one backward-Euler Newton solve per step; a failed solve leaves the state untouched and reports ok = 0
+    int conv = 1, its = 0, done = 0;
+    for (int s = 0; s < nsteps && conv; ++s) {
+      if (fembe_step(h->fb, dt, &conv, &its) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+      done += conv;
+    }
+    if (info) {
+      info->ok = conv;
+      info->nsteps = done;
+      info->iters = its;
+      info->cmin = info->cmax = 0.0;
+    }
+    return PF_OK;
+  }
   for (int s = 0; s < nsteps; ++s) {
     int rc = launch_step(h, dt, 0, h->g.nz);
     if (rc) return rc;
@@ -509,6 +553,7 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
     int rc = run_diag(h, raw);
     if (rc) return rc;
     info->nsteps = nsteps;
+    info->iters = 0;
     info->cmin = raw[4];
     info->cmax = raw[5];
     info->ok = (std::isfinite(raw[0]) && std::isfinite(raw[1]) && raw[4] >= -1.0 && raw[5] <= 2.0) ? 1 : 0;
@@ -519,6 +564,12 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
 int pf_rollback(pf_handle* h) {
   if (!h) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->fb) {
+    int r = fembe_rollback(h->fb);
+    if (r == -4) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
+    if (r != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   if (!h->have_prev) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
   h->cur ^= 1;
   h->phi_valid = false;
@@ -590,6 +641,10 @@ int pf_step_finish(pf_handle* h) {
 int pf_diagnostics_local(pf_handle* h, double out[3]) {
   if (!h || !out) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->fb) {
+    if (fembe_diagnostics(h->fb, out) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   double raw[6];
   int rc = run_diag(h, raw);
   if (rc) return rc;

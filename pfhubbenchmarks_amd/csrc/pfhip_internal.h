@@ -61,4 +61,19 @@ void poisson_destroy(Poisson* po);
 int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream);
 const char* poisson_error(const Poisson* po);
 
+// BE-parity mode (fem_be.hip): the reference's P1 crossed-mesh backward-Euler Newton solve on the GPU
+struct FemBE;
+int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, double ca, double cb, double kappa,
+                 double Mob, double k, double eps, hipStream_t stream, std::string* err);
+void fembe_destroy(FemBE* fb);
+int fembe_nodes(const FemBE* fb);
+int fembe_last_iters(const FemBE* fb);
+int fembe_set_ic(FemBE* fb, double c0, double amp, double w0);
+int fembe_set_c(FemBE* fb, const double* host);
+int fembe_get(FemBE* fb, int field, double* host);
+int fembe_step(FemBE* fb, double dt, int* converged, int* iters);
+int fembe_rollback(FemBE* fb);
+int fembe_diagnostics(FemBE* fb, double out[3]);
+const char* fembe_error(const FemBE* fb);
+
 }  // namespace pfhip

@@ -95,6 +95,63 @@ def run_bench1(intervals=200, L=200.0, scheme="fd", dt=None, end_time=1e3, times
     return np.array(rows), spent
 
 
+def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="results", device=0, verbose=True,
+               max_rows=None):
+    """BE-parity mode: the reference's own discretisation (100 x 100 'crossed' P1 mesh) and backward-Euler Newton
+    solve on the GPU (PF_SCHEME_FEM_BE).  controller = "fixture": one BE step per row on the committed run's time
+    grid (rows comparable one to one with results/bench<N>_out.csv); "reference": the script's own rule --
+    dt doubles when the solve took < 5 Newton iterations, else halves (bench1.py:180-183), a failed solve halves dt
+    and retries (bench1.py:164-177); the iteration counts of a direct-LU Newton differ from the reference's inexact
+    SNES/GMRES counts, so that time grid is this solver's own."""
+    bm6 = bench == "bench6"
+    L, N = (100.0, 100) if bm6 else (200.0, 100)              # bench6.py:22-23 / bench1.py:21-22
+    end_time = (3.0 if bm6 else 1e3) if end_time is None else end_time
+    dt0, dt_min = (1e-2, 1e-4) if bm6 else (1e-1, 1e-2)       # bench6.py:180-181 / bench1.py:140-141
+    rows = []
+    t1 = time.time()
+    with PhaseFieldSolver(dim=2, n=N + 1, h=L / N, bc="mirror", scheme="fem_be", model="bm6" if bm6 else "bm1",
+                          device=device) as s:
+        (s.set_ic_bm6 if bm6 else s.set_ic_bm1)()
+        if controller == "fixture":
+            times = report_times(bench)
+            times = times[[i for i, t in enumerate(times) if i == 0 or times[i - 1] < end_time + 1e-12]]
+            if max_rows:
+                times = times[:max_rows]
+            tprev = 0.0
+            for it, tn in enumerate(times):
+                ok, _, _ = s.step(float(tn) - tprev, 1, check=True)
+                if not ok:
+                    raise RuntimeError("Newton failed at t = %g" % tn)
+                tprev = float(tn)
+                F, C, _ = s.diagnostics()
+                rows.append([tprev, F, C])
+                if verbose:
+                    print("Iteration #%d. Time: %g, niters: %d, C_total: %.10f, TFE: %.10f"
+                          % (it + 1, tn, s.last_iters, C, F))
+        else:
+            t, dt, it = 0.0, dt0, 0
+            while t < end_time + 3e-16 and (max_rows is None or len(rows) < max_rows):
+                it += 1
+                ok, _, _ = s.step(dt, 1, check=True)
+                while not ok:
+                    dt = max(0.5 * dt, dt_min)
+                    if verbose:
+                        print("REPEATING Iteration #%d. Time: %g, dt: %g" % (it, t + dt, dt))
+                    ok, _, _ = s.step(dt, 1, check=True)
+                t += dt
+                dt = 2 * dt if s.last_iters < 5 else max(0.5 * dt, dt_min)
+                F, C, _ = s.diagnostics()
+                rows.append([t, F, C])
+                if verbose:
+                    print("Iteration #%d. Time: %g, niters: %d, C_total: %.10f, TFE: %.10f" % (it, t, s.last_iters, C, F))
+    spent = time.time() - t1
+    print("Time spent is %s" % spent)
+    write_csv(os.path.join(out_dir, "%s_out.csv" % bench), rows)
+    if not bm6:
+        write_csv(os.path.join(out_dir, "bench1", "stats.csv"), rows)
+    return np.array(rows), spent
+
+
 def run_bench6(intervals=100, L=100.0, dt=None, end_time=3.0, times=None, out_dir="results", save_solution=False,
                device=0, verbose=True):
     """PFHub BM6 (dolfin/bench6.py): 100 x 100 domain, c0 = 0.5, c1 = 0.04 (bench6.py:53-54), k = 0.09, eps = 90
@@ -132,21 +189,31 @@ def main_bench6(argv=None):
     ap.add_argument("--intervals", type=int, default=100, help="grid intervals per side (h = 100/intervals)")
     ap.add_argument("--dt", type=float, default=None)
     ap.add_argument("--end-time", type=float, default=3.0)
+    ap.add_argument("--scheme", default="fd", choices=["fd", "fem_be"])
+    ap.add_argument("--controller", default="fixture", choices=["fixture", "reference"])
     ap.add_argument("--out-dir", default="results")
     ap.add_argument("--save-solution", action="store_true")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
+    if a.scheme == "fem_be":
+        run_fem_be("bench6", a.controller, a.end_time, a.out_dir, 0, not a.quiet)
+        return
     run_bench6(a.intervals, 100.0, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)
 
 
 def main_bench1(argv=None):
     ap = argparse.ArgumentParser(description="PFHub BM1 on MI355X (counterpart of dolfin/bench1.py)")
     ap.add_argument("--intervals", type=int, default=200, help="grid intervals per side (h = 200/intervals)")
-    ap.add_argument("--scheme", default="fd", choices=["fd", "spectral"])
+    ap.add_argument("--scheme", default="fd", choices=["fd", "spectral", "fem_be"],
+                    help="fem_be = the reference's own P1 backward-Euler discretisation on the GPU (parity mode)")
+    ap.add_argument("--controller", default="fixture", choices=["fixture", "reference"])
     ap.add_argument("--dt", type=float, default=None)
     ap.add_argument("--end-time", type=float, default=1e3)
     ap.add_argument("--out-dir", default="results")
     ap.add_argument("--save-solution", action="store_true")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
+    if a.scheme == "fem_be":
+        run_fem_be("bench1", a.controller, a.end_time, a.out_dir, 0, not a.quiet)
+        return
     run_bench1(a.intervals, 200.0, a.scheme, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpfhip.so")
 
 PF_OK, PF_ERR_INVALID, PF_ERR_UNSUPPORTED, PF_ERR_HIP, PF_ERR_STATE, PF_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 PF_BC_PERIODIC, PF_BC_MIRROR = 0, 1
-PF_SCHEME_FD_EXPLICIT, PF_SCHEME_SPECTRAL_SI = 0, 1
+PF_SCHEME_FD_EXPLICIT, PF_SCHEME_SPECTRAL_SI, PF_SCHEME_FEM_BE = 0, 1, 2
 PF_MODEL_BM1, PF_MODEL_BM6 = 1, 6
 PF_FIELD_C, PF_FIELD_MU, PF_FIELD_PHI = 0, 1, 2
 PF_KERNEL_AUTO, PF_KERNEL_FUSED, PF_KERNEL_TWOPASS = 0, 1, 2
@@ -30,7 +30,8 @@ class PfConfig(C.Structure):
 
 
 class PfStepInfo(C.Structure):
-    _fields_ = [("ok", C.c_int32), ("nsteps", C.c_int32), ("cmin", C.c_double), ("cmax", C.c_double)]
+    _fields_ = [("ok", C.c_int32), ("nsteps", C.c_int32), ("cmin", C.c_double), ("cmax", C.c_double),
+                ("iters", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class PfHaloLayout(C.Structure):

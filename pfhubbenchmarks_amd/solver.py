@@ -37,7 +37,8 @@ class PhaseFieldSolver:
         for d in range(dim):
             cfg.n[d] = int(n3[d])
         cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
-        cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI}[scheme]
+        cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI,
+                      "fem_be": _lib.PF_SCHEME_FEM_BE}[scheme]
         cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6}[model]
         cfg.kernel = {"auto": _lib.PF_KERNEL_AUTO, "fused": _lib.PF_KERNEL_FUSED,
                       "twopass": _lib.PF_KERNEL_TWOPASS}[kernel]
@@ -54,6 +55,10 @@ class PhaseFieldSolver:
         self._h = C.c_void_p()
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
         self.nelem = int(self._lib.pf_field_elems(C.byref(cfg)))
+        if scheme == "fem_be":      # fields are nodal vectors in the reference's node order (corners, then centres)
+            self.shape = (self.nelem,)
+        self.scheme = scheme
+        self.last_iters = 0
         self.t = 0.0
 
     # -- life cycle
@@ -97,6 +102,12 @@ class PhaseFieldSolver:
         self._ck(self._lib.pf_get_field(self._h, _lib.PF_FIELD_C, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
+    def get_mu(self):
+        """PF_SCHEME_FEM_BE only (mu is a solved-for field there; the FD / spectral paths never store it)."""
+        out = np.empty(self.shape, dtype=np.float64)
+        self._ck(self._lib.pf_get_field(self._h, _lib.PF_FIELD_MU, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
     def get_phi(self):
         """BM6 only: the electrostatic potential consistent with the current c (bench6.py:225 `phi`)."""
         out = np.empty(self.shape, dtype=np.float64)
@@ -109,7 +120,8 @@ class PhaseFieldSolver:
         if check:
             info = _lib.PfStepInfo()
             self._ck(self._lib.pf_step(self._h, float(dt), int(nsteps), C.byref(info)))
-            self.t += dt * nsteps
+            self.t += dt * info.nsteps if self.scheme == "fem_be" else dt * nsteps
+            self.last_iters = info.iters
             return bool(info.ok), info.cmin, info.cmax
         self._ck(self._lib.pf_step(self._h, float(dt), int(nsteps), None))
         self.t += dt * nsteps

@@ -357,3 +357,63 @@ def test_bench6_driver(lib, golden_dir, tmp_path):
     rel = np.abs(rows[:, 1] - csv[:4, 1]) / csv[:4, 1]
     assert rel.max() < 1e-3
     assert open(os.path.join(str(tmp_path), "bench6_out.csv")).readline().strip() == "time,total_free_energy,total_solute"
+
+
+def test_fem_be_parity_mode_bm1_against_reference_fixtures(lib, golden_dir):
+    """PF_SCHEME_FEM_BE: the reference's own discretisation on the GPU.  Compared (a) row by row with the reference's
+    committed results/bench1_out.csv and VTU c-fields, (b) with the pinned CPU oracle oracle/fem_be.py."""
+    import os
+    from oracle import fem_be
+    csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
+    fields = np.load(os.path.join(golden_dir, "bm1_fields.npz"))
+    o = fem_be.FemBE("bm1")
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:
+        s.set_ic_bm1(0.5, 0.05)
+        assert s.get_c().shape == (20201,)
+        assert np.abs(s.get_c() - o.c).max() < 1e-14
+        F, C, _ = s.diagnostics()
+        assert abs(F - 297.6736899201) < 1e-8 and abs(C - 20504.4690550850) < 1e-8      # known answers at t = 0
+        tprev = 0.0
+        for i in range(8):
+            dt = csv[i, 0] - tprev
+            ok, _, _ = s.step(dt, 1, check=True)
+            its_o, ok_o = o.step(dt)
+            assert ok and ok_o and s.last_iters == its_o
+            tprev = csv[i, 0]
+            F, C, _ = s.diagnostics()
+            assert abs(F - csv[i, 1]) <= 1e-8 * csv[i, 1], (i, F, csv[i, 1])       # the reference's committed row
+            assert abs(C - csv[i, 2]) <= 1e-9 * csv[i, 2]
+            Fo, Co = o.diagnostics()
+            assert abs(F - Fo) <= 1e-11 * abs(Fo) and abs(C - Co) <= 1e-12 * abs(Co)   # the CPU oracle
+            assert np.abs(s.get_c() - o.c).max() <= 1e-10
+            assert np.abs(s.get_mu() - o.mu).max() <= 1e-9
+            if i < 6:
+                assert abs(fields["times"][i] - csv[i, 0]) < 1e-9
+                assert np.abs(s.get_c() - fields["c"][i]).max() < 5e-9           # the reference's VTU snapshot
+        before = s.get_c()
+        s.step(1.6, 1, check=True)
+        s.rollback()
+        np.testing.assert_array_equal(s.get_c(), before)
+
+
+def test_fem_be_parity_mode_bm6(lib, golden_dir):
+    import os
+    from oracle import fem_be
+    csv = np.loadtxt(os.path.join(golden_dir, "bench6_out.csv"), delimiter=",", skiprows=1)
+    o = fem_be.FemBE("bm6")
+    with PhaseFieldSolver(dim=2, n=101, h=1.0, bc="mirror", scheme="fem_be", model="bm6") as s:
+        s.set_ic_bm6(0.5, 0.04)
+        tprev = 0.0
+        for i in range(4):
+            dt = csv[i, 0] - tprev
+            ok, _, _ = s.step(dt, 1, check=True)
+            its_o, ok_o = o.step(dt)
+            assert ok and ok_o
+            tprev = csv[i, 0]
+            F, C, E = s.diagnostics()
+            assert abs(F - csv[i, 1]) <= 1e-6 * csv[i, 1]          # reference rows (its two committed runs differ by 1e-7)
+            assert abs(C - csv[i, 2]) <= 1e-9 * csv[i, 2]
+            Fo, Co = o.diagnostics()
+            assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(C - Co) <= 1e-12 * abs(Co)
+            assert np.abs(s.get_c() - o.c).max() <= 1e-9
+            assert np.abs(s.get_phi() - o.phi).max() <= 1e-9
