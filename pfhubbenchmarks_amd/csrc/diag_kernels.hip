@@ -13,7 +13,7 @@ namespace pfhip {
 namespace {
 
 constexpr int DIAG_BLOCK = 256;
-constexpr int DIAG_MAX_BLOCKS = 2048;
+constexpr int DIAG_MAX_BLOCKS = 8192;
 
 __device__ __forceinline__ int wrapi(int i, int n) {
   i %= n;
@@ -56,6 +56,7 @@ __device__ __forceinline__ void block_reduce6(double v[6], double* sh /* 4 waves
   }
 }
 
+// Generic partial kernel (any nx): one thread per cell, grid-stride; neighbours through the caches.
 __global__ __launch_bounds__(DIAG_BLOCK) void diag_partial_kernel(const double* __restrict__ c,
                                                                  const double* __restrict__ phi, int nx, int ny,
                                                                  int nz, int ghost, int zwrap, double rho, double ca,
@@ -84,6 +85,67 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_partial_kernel(const double* 
     if (phi) v[3] += w * phi[(int64_t)(z + ghost) * plane + (int64_t)y * nx + x];
     v[4] = fmin(v[4], w);
     v[5] = fmax(v[5], w);
+  }
+  block_reduce6(v, sh);
+  if (threadIdx.x == 0)
+    for (int q = 0; q < 6; ++q) partials[(int64_t)blockIdx.x * 6 + q] = v[q];
+}
+
+// Streaming partial kernel (even nx): a wave owns one y-row of 128 cells (16-byte pairs per lane) and marches through a
+// z-chunk keeping plane z in registers while plane z+1 arrives, so c is read from HBM once (8 B/cell algorithmic):
+// the z+1 difference comes from registers, x+1 from the neighbouring lane (wave shuffle; the last lane loads one
+// extra double), y+1 from the next row (an L1/L2 hit: the neighbouring wave streams it at the same time).
+constexpr int DS_ROWS = 4;  // rows per 256-thread block
+__global__ __launch_bounds__(DIAG_BLOCK) void diag_stream_kernel(const double* __restrict__ c,
+                                                                const double* __restrict__ phi, int nx, int ny, int nz,
+                                                                int ghost, int zwrap, int ntx, int nty, int zchunk,
+                                                                double rho, double ca, double cb,
+                                                                double* __restrict__ partials) {
+  __shared__ double sh[24];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x;
+  const int tx = t % ntx, ty = (t / ntx) % nty, ch = t / (ntx * nty);
+  const int x = tx * 128 + 2 * lane, y = ty * DS_ROWS + wave;
+  const bool on = x < nx && y < ny;
+  const int xc = on ? x : 0, yc = on ? y : 0;
+  const int yp = yc + 1 == ny ? 0 : yc + 1;
+  const int xn = xc + 2 >= nx ? 0 : xc + 2;  // first cell of the next pair (periodic)
+  const int64_t plane = (int64_t)nx * ny;
+  const int64_t o0 = (int64_t)yc * nx + xc, oy = (int64_t)yp * nx + xc, ox = (int64_t)yc * nx + xn;
+  const int zs = ch * zchunk, ze = min(nz, zs + zchunk);
+  double v[6] = {0.0, 0.0, 0.0, 0.0, INFINITY, -INFINITY};
+  auto pl = [&](int z) { return c + (int64_t)((zwrap ? wrapi(z, nz) : z) + ghost) * plane; };
+  double2 cur = *reinterpret_cast<const double2*>(pl(zs) + o0);
+  for (int z = zs; z < ze; ++z) {
+    const double* p0 = pl(z);
+    const double2 nxt = *reinterpret_cast<const double2*>(pl(z + 1) + o0);
+    const double2 up = *reinterpret_cast<const double2*>(p0 + oy);
+    double xr = __shfl_down(cur.x, 1, 64);  // lane+1's first cell
+    if (lane == 63 || xc + 2 >= nx) xr = p0[ox];
+    if (on) {
+      double a = cur.x - ca, b = cb - cur.x, ab = a * b;
+      double f = rho * (ab * ab);
+      double dx = cur.y - cur.x, dy = up.x - cur.x, dz = nxt.x - cur.x;
+      double g = (dx * dx + dy * dy) + dz * dz;
+      a = cur.y - ca;
+      b = cb - cur.y;
+      ab = a * b;
+      f += rho * (ab * ab);
+      dx = xr - cur.y;
+      dy = up.y - cur.y;
+      dz = nxt.y - cur.y;
+      g += (dx * dx + dy * dy) + dz * dz;
+      v[0] += cur.x + cur.y;
+      v[1] += f;
+      v[2] += g;
+      if (phi) {
+        const double2 ph = *reinterpret_cast<const double2*>(phi + (int64_t)(z + ghost) * plane + o0);
+        v[3] += cur.x * ph.x + cur.y * ph.y;
+      }
+      v[4] = fmin(v[4], fmin(cur.x, cur.y));
+      v[5] = fmax(v[5], fmax(cur.x, cur.y));
+    }
+    cur = nxt;
   }
   block_reduce6(v, sh);
   if (threadIdx.x == 0)
@@ -128,7 +190,28 @@ int diag_partials_elems() { return DIAG_MAX_BLOCKS * 6; }
 hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, double rho,
                        double ca, double cb, double* partials, double* out6, hipStream_t stream) {
   const int64_t total = (int64_t)nx * ny * nz;
-  int64_t nb = (total + DIAG_BLOCK - 1) / DIAG_BLOCK;
+  int64_t nb;
+  const bool aligned = (nx % 2 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) &&
+                       (phi == nullptr || (reinterpret_cast<uintptr_t>(phi) & 15) == 0);
+  if (aligned) {
+    const int ntx = (nx + 127) / 128, nty = (ny + DS_ROWS - 1) / DS_ROWS;
+    const int64_t xy = (int64_t)ntx * nty;
+    int nchunk = (int)((2048 + xy - 1) / xy);  // aim at ~2048 blocks
+    if (nchunk > nz) nchunk = nz;
+    if (nchunk < 1) nchunk = 1;
+    while (xy * nchunk > DIAG_MAX_BLOCKS && nchunk > 1) --nchunk;
+    const int zchunk = (nz + nchunk - 1) / nchunk;
+    nchunk = (nz + zchunk - 1) / zchunk;
+    nb = xy * nchunk;
+    if (nb <= DIAG_MAX_BLOCKS) {
+      hipLaunchKernelGGL(diag_stream_kernel, dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, c, phi, nx, ny, nz, ghost,
+                         zwrap, ntx, nty, zchunk, rho, ca, cb, partials);
+      hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(DIAG_BLOCK), 0, stream, (const double*)partials, (int)nb,
+                         out6);
+      return hipGetLastError();
+    }
+  }
+  nb = (total + DIAG_BLOCK - 1) / DIAG_BLOCK;
   if (nb > DIAG_MAX_BLOCKS) nb = DIAG_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(diag_partial_kernel, dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, c, phi, nx, ny, nz, ghost, zwrap,
