@@ -10,6 +10,10 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
                 ghost planes exchanged over RCCL (torch.distributed "nccl") overlapped with the interior kernel.
   bm1_fd_1024c  1024^3 on 1 GPU, or 1024 x 1024 x (1024/N) slabs on N GPUs (BASELINE.json config 4, strong)
   bm1_fd_512s   512^2 2-D (launch-latency bound; reported for completeness)
+  bm1_spectral_512s / _256c   semi-implicit spectral scheme (BASELINE.json config 2)
+  bm1_fem_be    BASELINE.json config 1: the reference's own algorithm (100x100 crossed P1 mesh, backward Euler, Newton)
+                on the GPU; a "step" is one accepted BE step of the committed run's time grid; metric node-updates/s;
+                cpu_baseline = oracle/fem_be.py (numpy/scipy SuperLU) on the same rows; says whether FEniCS is present
 Prints ONE JSON line (rank 0).  `value` counts the cell updates of all ranks; inputs are resident in HBM before the
 timed region.  roofline.achieved = 16 B/cell-update x cells per launch / average kernel time from HIP events
 recorded inside libpfhip around every step launch.  cpu_baseline = the CPU oracle (oracle/ch_fd.c, OpenMP) timed on
@@ -65,6 +69,66 @@ def cpu_baseline_spectral(n, dt, steps):
                                                                                              steps, el)}
 
 
+def bench_fem_be(a, world):
+    """config 1 (reference's own discretisation): accepted backward-Euler steps on the committed time grid."""
+    import importlib.util
+    import numpy as np
+    import torch
+    from pfhubbenchmarks_amd.drivers import report_times
+    from pfhubbenchmarks_amd.solver import PhaseFieldSolver
+    if world != 1:
+        sys.exit("bm1_fem_be is a single-GPU workload")
+    times = report_times("bench1")
+    steps = min(a.steps, len(times) - a.warmup)
+    nodes = 20201
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:
+        s.set_ic_bm1()
+        tprev, its = 0.0, 0
+        for i in range(a.warmup):
+            s.step(times[i] - tprev, 1, check=True)
+            tprev = times[i]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + steps):
+            ok, _, _ = s.step(times[i] - tprev, 1, check=True)
+            assert ok
+            its += s.last_iters
+            tprev = times[i]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        F, C, _ = s.diagnostics()
+    out = {"metric": "node-updates/sec on PFHub BM1, reference algorithm (P1 crossed mesh, backward Euler, Newton)",
+           "value": nodes * steps / el, "unit": "node-updates/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup,
+           "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "bm1_fem_be", "mesh": "100x100 crossed, 20201 nodes, 40402 dofs",
+                      "time_grid": "rows %d..%d of results/bench1_out.csv" % (a.warmup, a.warmup + steps - 1),
+                      "newton_iterations": its, "linear_solver": "block-tridiagonal LU (rocSOLVER/rocBLAS)"},
+           "roofline": None,
+           "check": {"t": float(tprev), "F": F, "C": C},
+           "fenics_on_host": importlib.util.find_spec("dolfin") is not None}
+    if not a.no_cpu_baseline:
+        from oracle import fem_be
+        o = fem_be.FemBE("bm1")
+        tp = 0.0
+        for i in range(a.warmup):
+            o.step(times[i] - tp)
+            tp = times[i]
+        ncpu = min(steps, 6)
+        t0 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + ncpu):
+            o.step(times[i] - tp)
+            tp = times[i]
+        elc = time.perf_counter() - t0
+        from oracle import ch_fd
+        out["cpu_baseline"] = {"value": nodes * ncpu / elc, "unit": "node-updates/s", "cores": ch_fd.host_cores(),
+                               "kind": "port", "sample": "%d accepted BE steps (rows %d..%d), oracle/fem_be.py "
+                               "(scipy SuperLU), %.1f s; FEniCS itself: %s" % (
+                                   ncpu, a.warmup, a.warmup + ncpu - 1, elc,
+                                   "present" if out["fenics_on_host"] else "unavailable on host")}
+    print(json.dumps(out), flush=True)
+
+
 def measured_traffic(workload, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
     separate runs, FETCH_SIZE x2 per MI355X_MICROARCH.md) of THIS workload with the default kernel variant;
@@ -86,7 +150,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c"])
+    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
+                             "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
@@ -117,6 +182,8 @@ def main():
     if a.min_chunk > 0:
         lib.pfk_set_tuning(2, a.min_chunk)
 
+    if a.workload == "bm1_fem_be":
+        return bench_fem_be(a, world)
     h = 1.0
     scheme, bytes_per_cell = "fd", BYTES_PER_CELL_UPDATE
     if a.workload in ("bm1_spectral_512s", "bm1_spectral_256c"):

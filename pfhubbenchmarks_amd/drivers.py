@@ -19,6 +19,7 @@ import time
 
 import numpy as np
 
+from . import io as pio
 from .solver import PhaseFieldSolver, stable_dt
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -75,7 +76,7 @@ def run_bench1(intervals=200, L=200.0, scheme="fd", dt=None, end_time=1e3, times
     if dt is None:
         dt = stable_dt(h, dim=2, safety=0.4) if scheme == "fd" else 1e-2
     dt_min = dt / 64.0
-    rows = []
+    rows, snaps = [], []
     t1 = time.time()
     with PhaseFieldSolver(dim=2, n=intervals + 1, h=h, bc="mirror", scheme=scheme, device=device) as s:
         s.set_ic_bm1(0.5, 0.05)
@@ -85,9 +86,11 @@ def run_bench1(intervals=200, L=200.0, scheme="fd", dt=None, end_time=1e3, times
             rows.append([float(tn), F, C])
             if verbose:
                 print("Iteration #%d. Time: %g, C_total: %.10f, TFE: %.10f" % (it + 1, tn, C, F))
-            if save_solution:
-                os.makedirs(os.path.join(out_dir, "bench1"), exist_ok=True)
-                np.save(os.path.join(out_dir, "bench1", "conc%06d.npy" % it), s.get_c())
+            if save_solution:      # bench1.py:190-191 (one snapshot per accepted step)
+                snaps.append(os.path.join(out_dir, "bench1", "conc%06d.vti" % it))
+                pio.write_vti(snaps[-1], s.get_c(), h, "c")
+    if save_solution:
+        pio.write_pvd(os.path.join(out_dir, "bench1", "conc.pvd"), times[:len(snaps)], snaps)
     spent = time.time() - t1
     print("Time spent is %s" % spent)
     write_csv(os.path.join(out_dir, "bench1_out.csv"), rows)
@@ -96,7 +99,7 @@ def run_bench1(intervals=200, L=200.0, scheme="fd", dt=None, end_time=1e3, times
 
 
 def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="results", device=0, verbose=True,
-               max_rows=None):
+               max_rows=None, save_solution=False):
     """BE-parity mode: the reference's own discretisation (100 x 100 'crossed' P1 mesh) and backward-Euler Newton
     solve on the GPU (PF_SCHEME_FEM_BE).  controller = "fixture": one BE step per row on the committed run's time
     grid (rows comparable one to one with results/bench<N>_out.csv); "reference": the script's own rule --
@@ -125,6 +128,8 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
                 tprev = float(tn)
                 F, C, _ = s.diagnostics()
                 rows.append([tprev, F, C])
+                if save_solution:   # same mesh, node order and PointData layout as the reference's conc00000N.vtu
+                    pio.write_vtu_crossed(os.path.join(out_dir, bench, "conc%06d.vtu" % it), s.get_c(), N, L)
                 if verbose:
                     print("Iteration #%d. Time: %g, niters: %d, C_total: %.10f, TFE: %.10f"
                           % (it + 1, tn, s.last_iters, C, F))
@@ -146,6 +151,9 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
                     print("Iteration #%d. Time: %g, niters: %d, C_total: %.10f, TFE: %.10f" % (it, t, s.last_iters, C, F))
     spent = time.time() - t1
     print("Time spent is %s" % spent)
+    if save_solution and controller == "fixture":
+        pio.write_pvd(os.path.join(out_dir, bench, "conc.pvd"), [r[0] for r in rows],
+                      ["conc%06d.vtu" % i for i in range(len(rows))])
     write_csv(os.path.join(out_dir, "%s_out.csv" % bench), rows)
     if not bm6:
         write_csv(os.path.join(out_dir, "bench1", "stats.csv"), rows)
@@ -164,7 +172,7 @@ def run_bench6(intervals=100, L=100.0, dt=None, end_time=3.0, times=None, out_di
     if dt is None:
         dt = stable_dt(h, dim=2, safety=0.4)
     dt_min = dt / 64.0
-    rows = []
+    rows, snaps = [], []
     t1 = time.time()
     with PhaseFieldSolver(dim=2, n=intervals + 1, h=h, bc="mirror", model="bm6", device=device) as s:
         s.set_ic_bm6(0.5, 0.04)
@@ -174,10 +182,14 @@ def run_bench6(intervals=100, L=100.0, dt=None, end_time=3.0, times=None, out_di
             rows.append([float(tn), F, C])
             if verbose:
                 print("Iteration #%d. Time: %g, C_total: %.10f, TFE: %.10f" % (it + 1, tn, C, F))
-            if save_solution:
-                os.makedirs(os.path.join(out_dir, "bench6"), exist_ok=True)
-                np.save(os.path.join(out_dir, "bench6", "conc%06d.npy" % it), s.get_c())
-                np.save(os.path.join(out_dir, "bench6", "phi%06d.npy" % it), s.get_phi())
+            if save_solution:      # bench6.py:227-229: file0 << (c, t); file1 << (phi, t)
+                snaps.append((os.path.join(out_dir, "bench6", "conc%06d.vti" % it),
+                              os.path.join(out_dir, "bench6", "phi%06d.vti" % it)))
+                pio.write_vti(snaps[-1][0], s.get_c(), h, "c")
+                pio.write_vti(snaps[-1][1], s.get_phi(), h, "phi")
+    if save_solution:
+        pio.write_pvd(os.path.join(out_dir, "bench6", "conc.pvd"), times[:len(snaps)], [a for a, _ in snaps])
+        pio.write_pvd(os.path.join(out_dir, "bench6", "phi.pvd"), times[:len(snaps)], [b for _, b in snaps])
     spent = time.time() - t1
     print("Time spent is %s" % spent)
     write_csv(os.path.join(out_dir, "bench6_out.csv"), rows)
@@ -196,7 +208,7 @@ def main_bench6(argv=None):
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
     if a.scheme == "fem_be":
-        run_fem_be("bench6", a.controller, a.end_time, a.out_dir, 0, not a.quiet)
+        run_fem_be("bench6", a.controller, a.end_time, a.out_dir, 0, not a.quiet, None, a.save_solution)
         return
     run_bench6(a.intervals, 100.0, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)
 
@@ -214,6 +226,6 @@ def main_bench1(argv=None):
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
     if a.scheme == "fem_be":
-        run_fem_be("bench1", a.controller, a.end_time, a.out_dir, 0, not a.quiet)
+        run_fem_be("bench1", a.controller, a.end_time, a.out_dir, 0, not a.quiet, None, a.save_solution)
         return
     run_bench1(a.intervals, 200.0, a.scheme, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)
