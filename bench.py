@@ -10,7 +10,10 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
                 ghost planes exchanged over RCCL (torch.distributed "nccl") overlapped with the interior kernel.
   bm1_fd_1024c  1024^3 on 1 GPU, or 1024 x 1024 x (1024/N) slabs on N GPUs (BASELINE.json config 4, strong)
   bm1_fd_512s   512^2 2-D (launch-latency bound; reported for completeness)
-  bm1_spectral_512s / _256c   semi-implicit spectral scheme (BASELINE.json config 2)
+  bm1_spectral_512s / _256c / _512c   semi-implicit spectral scheme (BASELINE.json config 2); _512c also runs on N > 1
+                GPUs (512 x 512 x 512 N box, slab FFT: one RCCL all-to-all each way per transform)
+  bm6_fd_512c / _256c   BM6 (BASELINE.json config 5) in a periodic box: FFT Poisson solve + coupled fused FD step per
+                step; N > 1: slab FFT Poisson (2 all-to-alls) + ghost exchange of c and phi
   bm1_fem_be    BASELINE.json config 1: the reference's own algorithm (100x100 crossed P1 mesh, backward Euler, Newton)
                 on the GPU; a "step" is one accepted BE step of the committed run's time grid; metric node-updates/s;
                 cpu_baseline = oracle/fem_be.py (numpy/scipy SuperLU) on the same rows; says whether FEniCS is present
@@ -152,7 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
-                             "bm1_fem_be"])
+                             "bm1_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
@@ -187,14 +190,25 @@ def main():
         return bench_fem_be(a, world)
     h = 1.0
     scheme, bytes_per_cell = "fd", BYTES_PER_CELL_UPDATE
-    if a.workload in ("bm1_spectral_512s", "bm1_spectral_256c"):
+    model = "bm1"
+    if a.workload in ("bm6_fd_512c", "bm6_fd_256c"):
+        # CH kernel 16 B + phi read 8 B + Poisson transform pair idealised at 48 B (r2c 16, invert 16, c2r 16)
+        model, bytes_per_cell = "bm6", 72.0
+        nn = 512 if a.workload.endswith("512c") else 256
+        dim, gn, scaling = 3, (nn, nn, nn * world), "weak"
+        dt = 5e-4
+    elif a.workload == "bm1_spectral_512c":
+        scheme, bytes_per_cell = "spectral", 72.0
+        dim, gn, scaling = 3, (512, 512, 512 * world), "weak"
+        dt = 1e-2
+    elif a.workload in ("bm1_spectral_512s", "bm1_spectral_256c"):
         # BASELINE.json config 2: semi-implicit spectral; 72 B/cell-update = one-pass-per-transform idealisation
         # (f' 16 + r2c 16 + k-space 24 + c2r 16) -- 512^2 is launch-latency bound, not HBM bound
         scheme, bytes_per_cell = "spectral", 72.0
         dim, gn, scaling = (2, (512, 512, 1), "weak") if a.workload.endswith("512s") else (3, (256, 256, 256), "weak")
         dt = 1e-2
         if world > 1:
-            sys.exit("the spectral scheme is single-GPU in this build")
+            sys.exit("this 2-D / small spectral workload is single-GPU; use bm1_spectral_512c for N > 1")
     elif a.workload == "bm1_fd_512s":
         dim, gn, scaling = 2, (512, 512, 1), "weak"
         dt = 1e-3
@@ -208,10 +222,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        from pfhubbenchmarks_amd.solver import FFTSlabSolver, HipFFTSlabEngine
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        eng = HipSlabEngine(gn, h, world, rank, local_rank)
-        eng.set_ic_bm1(0.5, 0.05)
-        solver = SlabSolver(eng)
+        if scheme == "spectral" or model == "bm6":
+            eng = HipFFTSlabEngine(gn, h, world, rank, local_rank, scheme=scheme, model=model)
+            (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
+            solver = FFTSlabSolver(eng)
+        else:
+            eng = HipSlabEngine(gn, h, world, rank, local_rank)
+            eng.set_ic_bm1(0.5, 0.05)
+            solver = SlabSolver(eng)
         timer = eng
         local_cells = gn[0] * gn[1] * eng.nz
 
@@ -224,8 +244,8 @@ def main():
             dist.barrier()
     else:
         n = gn[:dim]
-        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank, scheme=scheme)
-        s.set_ic_bm1(0.5, 0.05)
+        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank, scheme=scheme, model=model)
+        (s.set_ic_bm6 if model == "bm6" else s.set_ic_bm1)()
         solver = timer = s
         local_cells = gn[0] * gn[1] * gn[2]
 
@@ -259,8 +279,10 @@ def main():
     kernel_s_per_step = k_ms * 1e-3 * k_launches / max(a.steps, 1)
     achieved = bytes_per_cell * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
     out = {
-        "metric": "cell-updates/sec on PFHub BM1 Cahn-Hilliard (%s)" % (
-            "explicit FD, fused HIP stencil" if scheme == "fd" else "semi-implicit spectral, rocFFT + HIP k-space"),
+        "metric": "cell-updates/sec on PFHub %s (%s)" % (
+            "BM1 Cahn-Hilliard" if model == "bm1" else "BM6 Cahn-Hilliard + Poisson",
+            ("explicit FD, fused HIP stencil" + (" + rocFFT Poisson" if model == "bm6" else "")) if scheme == "fd"
+            else "semi-implicit spectral, rocFFT + HIP k-space"),
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -276,7 +298,9 @@ def main():
                      "bytes_per_cell_update": bytes_per_cell},
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and scheme == "spectral":
+    if model == "bm6":
+        pass          # no CPU leg for the BM6 box (the BM6 oracle is a test checker, minutes per step at this size)
+    elif rank == 0 and world == 1 and not a.no_cpu_baseline and scheme == "spectral":
         out["cpu_baseline"] = cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8)
     elif rank == 0 and world == 1 and not a.no_cpu_baseline:
         if dim == 3:

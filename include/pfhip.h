@@ -81,6 +81,9 @@ typedef struct pf_config {
   void* stream;         /* hipStream_t to launch on; NULL = library creates its own */
   double* ext_c[2];     /* optional caller-owned DEVICE buffers for the two c time levels, each
                            pf_field_elems_with_ghosts() doubles; NULL = library allocates (hipMalloc) */
+  double* ext_a2a[2];   /* slab FFT modes (nranks > 1 with PF_SCHEME_SPECTRAL_SI or PF_MODEL_BM6): optional caller-owned
+                           all-to-all buffers, pf_a2a_buffer_doubles() doubles each */
+  double* ext_phi;      /* BM6 slab mode: optional caller-owned ghosted phi buffer (same size as an ext_c buffer) */
 } pf_config;
 
 typedef struct pf_step_info {
@@ -104,6 +107,26 @@ typedef struct pf_halo_layout {
   int32_t reserved0;
 } pf_halo_layout;
 
+/* Distributed operations that need collectives the library does not perform itself (it never communicates).
+ * Protocol: pf_dist_begin(h, op, dt); then loop { pf_dist_advance(h, &req); switch (req.kind) ... } until
+ * PF_DIST_DONE.  The library runs its kernels up to the next exchange on the handle's stream and describes the
+ * exchange; the caller performs it stream-ordered on the same stream (RCCL through torch.distributed) and calls
+ * pf_dist_advance again. */
+enum { PF_DIST_DONE = 0, PF_DIST_ALLTOALL = 1, PF_DIST_HALO = 2 };
+enum {
+  PF_DIST_OP_STEP = 1,   /* one time step (spectral slab step; BM6 slab step = Poisson solve + coupled FD step) */
+  PF_DIST_OP_REFRESH = 2 /* make everything pf_diagnostics_local reads consistent with the current c:
+                            ghost planes, phi (BM6), resident spectrum (spectral) */
+};
+typedef struct pf_dist_request {
+  int32_t kind;             /* PF_DIST_* */
+  int32_t n_halo;           /* PF_DIST_HALO: how many ghosted buffers to refresh (layout: pf_halo_layout_get) */
+  double* src;              /* PF_DIST_ALLTOALL: equal split, doubles_per_peer doubles to / from every rank */
+  double* dst;
+  int64_t doubles_per_peer;
+  double* halo_base[2];     /* PF_DIST_HALO: base pointers of the ghosted buffers */
+} pf_dist_request;
+
 typedef struct pf_handle pf_handle;
 
 /* ---- library ---------------------------------------------------------------------------------------- */
@@ -122,6 +145,9 @@ int pf_slab_partition(int n_planes, int nranks, int rank, int* first, int* count
 int64_t pf_field_elems_with_ghosts(const pf_config* cfg);
 /* doubles of one rank's owned part of a field (what pf_set_field / pf_get_field move) */
 int64_t pf_field_elems(const pf_config* cfg);
+
+/* doubles per all-to-all buffer of the slab FFT modes for this config (<0: box not divisible by nranks) */
+int64_t pf_a2a_buffer_doubles(const pf_config* cfg);
 
 /* ---- life cycle ------------------------------------------------------------------------------------- */
 int pf_create(const pf_config* cfg, pf_handle** out);
@@ -146,6 +172,10 @@ int pf_sync(pf_handle* h);
 int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
 int pf_step_begin(pf_handle* h, double dt);
 int pf_step_finish(pf_handle* h);
+
+/* slab FFT modes and ghost refresh: see pf_dist_request above */
+int pf_dist_begin(pf_handle* h, int op, double dt);
+int pf_dist_advance(pf_handle* h, pf_dist_request* req);
 
 /* ---- diagnostics (bench1.py:121-125, bench6.py:155-165) ---------------------------------------------- */
 /* out = {total_free_energy, total_solute, f_elec part}; synchronises.  nranks > 1: use the _local variant

@@ -86,6 +86,11 @@ struct pf_handle {
   Spectral* sp = nullptr;
   Poisson* po = nullptr;   // BM6
   FemBE* fb = nullptr;     // PF_SCHEME_FEM_BE
+  SlabFFT* sf = nullptr;   // slab FFT modes (nranks > 1 spectral / BM6)
+  bool own_phi = false;
+  bool chat_valid = false; // slab spectral: resident spectrum consistent with c[cur]
+  int d_op = 0, d_phase = 0;
+  double d_dt = 0.0;
   double* phi = nullptr;   // BM6: phi on the lattice, consistent with c[cur] when phi_valid
   bool phi_valid = false;
   hipStream_t stream = nullptr;
@@ -122,7 +127,7 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   FdArgs a;
   a.cin = h->c[h->cur];
   a.cout = h->c[1 - h->cur];
-  a.phi = h->po ? h->phi : nullptr;
+  a.phi = h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr;
   a.nx = h->g.nx;
   a.ny = h->g.ny;
   a.nz = h->g.nz;
@@ -135,7 +140,7 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   a.two_rho = 2.0 * c.rho_s;
   a.kh2 = c.kappa / (c.h * c.h);
   a.amh2 = dt * c.M / (c.h * c.h);
-  a.kphi = h->po ? c.k : 0.0;
+  a.kphi = h->cfg.model == PF_MODEL_BM6 ? c.k : 0.0;
   return a;
 }
 
@@ -164,6 +169,8 @@ int timing_flush(pf_handle* h) {
 
 // BM6: phi = phi(c[cur]) (explicit coupling: the step uses phi^n; diagnostics recompute it for the new c)
 int ensure_phi(pf_handle* h) {
+  if (h->sf && h->cfg.model == PF_MODEL_BM6 && !h->phi_valid)
+    return fail(h, PF_ERR_STATE, "slab BM6: phi is stale -- run pf_dist_begin(PF_DIST_OP_REFRESH) / (OP_STEP) first");
   if (!h->po || h->phi_valid) return PF_OK;
   if (poisson_solve(h->po, h->c[h->cur], h->phi, h->stream) != 0) return fail(h, PF_ERR_HIP, poisson_error(h->po));
   h->phi_valid = true;
@@ -226,19 +233,25 @@ int run_diag(pf_handle* h, double raw[6]) {
     int prc = ensure_phi(h);
     if (prc) return prc;
   }
-  PF_HIP(h, launch_diag(h->c[h->cur], h->po ? h->phi : nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
+  if (h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI && !h->chat_valid)
+    return fail(h, PF_ERR_STATE, "slab spectral: run pf_dist_begin(PF_DIST_OP_REFRESH) before diagnostics");
+  PF_HIP(h, launch_diag(h->c[h->cur], h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
                         c.c_beta, h->partials, h->out6_dev, h->stream));
+  const bool sf_spec = h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI;
   if (h->sp) {
     // spectral scheme: |grad c|^2 summed in k-space (Parseval) instead of forward differences
     if (spectral_grad_energy(h->sp, h->c[h->cur], h->out6_dev + 6, h->stream) != 0)
       return fail(h, PF_ERR_HIP, spectral_error(h->sp));
+  } else if (sf_spec) {
+    if (slabfft_grad_energy_local(h->sf, h->out6_dev + 6) != 0) return fail(h, PF_ERR_HIP, slabfft_error(h->sf));
   }
   PF_HIP(h, hipMemcpyAsync(h->out6_host, h->out6_dev, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PF_HIP(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < 6; ++i) raw[i] = h->out6_host[i];
-  if (h->sp) {
+  if (h->sp || sf_spec) {
     // store as the equivalent "sum of squared differences / h^2 * h^2" so scale_diag's kappa/(2 h^2) factor applies
-    const int64_t n = h->g.plane * (int64_t)h->g.nz;
+    // (slab mode: this rank's share of the k-space sum, normalised by the GLOBAL lattice size)
+    const int64_t n = h->g.plane * (int64_t)h->g.nzg;
     raw[2] = h->out6_host[6] / (double)n * (h->cfg.h * h->cfg.h);
   }
   return PF_OK;
@@ -337,11 +350,13 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
       (cfg->dim != 2 || cfg->bc != PF_BC_MIRROR || cfg->n[0] != cfg->n[1] || cfg->nranks != 1 || cfg->n[0] < 3))
     return fail(nullptr, PF_ERR_UNSUPPORTED,
                 "PF_SCHEME_FEM_BE: 2-D, PF_BC_MIRROR (natural no-flux), square mesh, one GPU");
-  if (cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->nranks != 1)
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "the spectral scheme is single-GPU in this build");
-  if (cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_FEM_BE &&
-      (cfg->nranks != 1 || cfg->scheme != PF_SCHEME_FD_EXPLICIT))
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is implemented for the FD scheme on one GPU in this build");
+  const bool slab_fft = cfg->nranks > 1 && (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
+  if (slab_fft && slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks) < 0)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "slab FFT modes need ny and nz divisible by nranks");
+  if ((cfg->ext_a2a[0] == nullptr) != (cfg->ext_a2a[1] == nullptr))
+    return fail(nullptr, PF_ERR_INVALID, "ext_a2a: give both buffers or none");
+  if (cfg->model == PF_MODEL_BM6 && cfg->scheme == PF_SCHEME_SPECTRAL_SI)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is implemented for the FD and FEM_BE schemes");
   if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
   if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
     return fail(nullptr, PF_ERR_INVALID, "ext_c: give both buffers or none");
@@ -388,14 +403,27 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     int frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
                            cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err);
     if (frc != 0) return bail(PF_ERR_HIP);
+  } else if (cfg->model == PF_MODEL_BM6 && cfg->nranks > 1) {
+    if (cfg->ext_phi) {
+      h->phi = cfg->ext_phi;
+    } else {
+      PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
+      h->own_phi = true;
+    }
+    PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
   } else if (cfg->model == PF_MODEL_BM6) {
     PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
+    h->own_phi = true;
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
     int prc = poisson_create(&h->po, cfg->dim, g.nx, g.ny, g.nzg, g.mirror ? g.np[0] : 0, g.mirror ? g.np[1] : 0,
                              cfg->h, cfg->k, cfg->eps_r, h->stream, &h->err);
     if (prc != 0) return bail(PF_ERR_HIP);
   }
-  if (cfg->scheme == PF_SCHEME_SPECTRAL_SI) {
+  if (slab_fft) {
+    int frc = slabfft_create(&h->sf, g.nx, g.ny, g.nzg, cfg->nranks, cfg->rank, cfg->h,
+                             cfg->scheme == PF_SCHEME_SPECTRAL_SI, cfg->ext_a2a[0], cfg->ext_a2a[1], h->stream, &h->err);
+    if (frc != 0) return bail(frc == -2 ? PF_ERR_UNSUPPORTED : PF_ERR_HIP);
+  } else if (cfg->scheme == PF_SCHEME_SPECTRAL_SI) {
     int src = spectral_create(&h->sp, cfg->dim, g.nx, g.ny, g.nzg, cfg->h, h->stream, &h->err);
     if (src != 0) return bail(PF_ERR_HIP);
   }
@@ -421,7 +449,8 @@ int pf_destroy(pf_handle* h) {
   if (h->sp) spectral_destroy(h->sp);
   if (h->po) poisson_destroy(h->po);
   if (h->fb) fembe_destroy(h->fb);
-  if (h->phi) (void)hipFree(h->phi);
+  if (h->phi && h->own_phi) (void)hipFree(h->phi);
+  if (h->sf) slabfft_destroy(h->sf);
   if (h->partials) (void)hipFree(h->partials);
   if (h->out6_dev) (void)hipFree(h->out6_dev);
   if (h->out6_host) (void)hipHostFree(h->out6_host);
@@ -443,6 +472,7 @@ static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   h->have_prev = false;
   if (h->sp) spectral_invalidate(h->sp);
   h->phi_valid = false;
+  h->chat_valid = false;
   return PF_OK;
 }
 
@@ -484,6 +514,7 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
   h->have_prev = false;
   if (h->sp) spectral_invalidate(h->sp);
   h->phi_valid = false;
+  h->chat_valid = false;
   return PF_OK;
 }
 
@@ -546,6 +577,7 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
     if (rc) return rc;
     h->cur ^= 1;
   h->phi_valid = false;
+  h->chat_valid = false;
     h->have_prev = true;
   }
   if (info) {
@@ -573,9 +605,11 @@ int pf_rollback(pf_handle* h) {
   if (!h->have_prev) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
   h->cur ^= 1;
   h->phi_valid = false;
+  h->chat_valid = false;
   h->have_prev = false;
   if (h->sp) spectral_invalidate(h->sp);
   h->phi_valid = false;
+  h->chat_valid = false;
   return PF_OK;
 }
 
@@ -608,6 +642,7 @@ int pf_step_begin(pf_handle* h, double dt) {
   if (!h) return PF_ERR_INVALID;
   if (!(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step_begin: need dt > 0");
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_begin: not in slab mode");
+  if (h->sf) return fail(h, PF_ERR_STATE, "pf_step_begin: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
   const int g = h->g.ghost, nz = h->g.nz;
   int rc = launch_step(h, dt, g, nz - g);  // interior planes need owned data only
@@ -633,9 +668,156 @@ int pf_step_finish(pf_handle* h) {
   }
   h->cur ^= 1;
   h->phi_valid = false;
+  h->chat_valid = false;
   h->have_prev = true;
   h->step_open = false;
   return PF_OK;
+}
+
+int64_t pf_a2a_buffer_doubles(const pf_config* cfg) {
+  Geometry g;
+  if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
+  return slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks);
+}
+
+int pf_dist_begin(pf_handle* h, int op, double dt) {
+  if (!h) return PF_ERR_INVALID;
+  if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_dist_begin: not in slab mode (nranks == 1)");
+  if (op != PF_DIST_OP_STEP && op != PF_DIST_OP_REFRESH) return fail(h, PF_ERR_INVALID, "pf_dist_begin: bad op");
+  if (op == PF_DIST_OP_STEP && !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_dist_begin: need dt > 0");
+  if (h->step_open || h->d_op) return fail(h, PF_ERR_STATE, "pf_dist_begin: another distributed operation is open");
+  h->d_op = op;
+  h->d_phase = 0;
+  h->d_dt = dt;
+  return PF_OK;
+}
+
+int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
+  if (!h || !req) return PF_ERR_INVALID;
+  if (!h->d_op) return fail(h, PF_ERR_STATE, "pf_dist_advance without pf_dist_begin");
+  std::memset(req, 0, sizeof(*req));
+  const pf_config& c = h->cfg;
+  const Geometry& g = h->g;
+  const bool bm6 = c.model == PF_MODEL_BM6;
+  const bool spec = c.scheme == PF_SCHEME_SPECTRAL_SI;
+  double* owned = h->c[h->cur] + (int64_t)g.ghost * g.plane;
+  auto a2a = [&](int from) {
+    req->kind = PF_DIST_ALLTOALL;
+    req->src = slabfft_buf(h->sf, from);
+    req->dst = slabfft_buf(h->sf, 1 - from);
+    req->doubles_per_peer = slabfft_doubles_per_peer(h->sf);
+    return (int)PF_OK;
+  };
+  auto done = [&]() {
+    h->d_op = 0;
+    h->d_phase = 0;
+    req->kind = PF_DIST_DONE;
+    return (int)PF_OK;
+  };
+#define SF_CALL(expr)                                                                   \
+  do {                                                                                  \
+    if ((expr) != 0) {                                                                  \
+      h->d_op = 0;                                                                      \
+      return fail(h, PF_ERR_HIP, slabfft_error(h->sf));                                 \
+    }                                                                                   \
+  } while (0)
+  if (spec) {
+    // ---- slab spectral: [fwd(c) if the resident spectrum is stale] -> fwd(f'(c)) -> k-space update -> inverse
+    for (;;) {
+      switch (h->d_phase) {
+        case 0:
+          if (h->chat_valid) {
+            h->d_phase = 2;
+            break;
+          }
+          SF_CALL(slabfft_forward_local(h->sf, owned));
+          h->d_phase = 1;
+          return a2a(0);
+        case 1:
+          SF_CALL(slabfft_z(h->sf, 0));
+          SF_CALL(slabfft_store_chat(h->sf));
+          h->chat_valid = true;
+          h->d_phase = 2;
+          break;
+        case 2:
+          if (h->d_op == PF_DIST_OP_REFRESH) return done();
+          SF_CALL(slabfft_forward_local_dfdc(h->sf, owned, c.c_alpha, c.c_beta, 2.0 * c.rho_s));
+          h->d_phase = 3;
+          return a2a(0);
+        case 3:
+          SF_CALL(slabfft_z(h->sf, 0));
+          SF_CALL(slabfft_spectral_update_on_T(h->sf, h->d_dt * c.M, h->d_dt * c.M * c.kappa));
+          SF_CALL(slabfft_z(h->sf, 1));
+          h->d_phase = 4;
+          return a2a(1);
+        default: {
+          SF_CALL(slabfft_inverse_local(h->sf, h->c[1 - h->cur] + (int64_t)g.ghost * g.plane));
+          h->cur ^= 1;
+          h->have_prev = true;
+          h->phi_valid = false;
+          // chat stays valid: it IS the spectrum of the new c
+          return done();
+        }
+      }
+    }
+  }
+  if (bm6) {
+    // ---- slab BM6: Poisson solve by slab FFT -> ghost refresh of c and phi -> coupled FD step
+    switch (h->d_phase) {
+      case 0:
+        if (h->phi_valid && h->d_op == PF_DIST_OP_REFRESH) return done();
+        SF_CALL(slabfft_forward_local(h->sf, owned));
+        h->d_phase = 1;
+        return a2a(0);
+      case 1:
+        SF_CALL(slabfft_z(h->sf, 0));
+        SF_CALL(slabfft_poisson_on_T(h->sf, c.k / c.eps_r));
+        SF_CALL(slabfft_z(h->sf, 1));
+        h->d_phase = 2;
+        return a2a(1);
+      case 2:
+        SF_CALL(slabfft_inverse_local(h->sf, h->phi + (int64_t)g.ghost * g.plane));
+        h->d_phase = 3;
+        req->kind = PF_DIST_HALO;
+        req->n_halo = 2;
+        req->halo_base[0] = h->c[h->cur];
+        req->halo_base[1] = h->phi;
+        return PF_OK;
+      default: {
+        h->phi_valid = true;
+        if (h->d_op == PF_DIST_OP_STEP) {
+          int rc = launch_step(h, h->d_dt, 0, g.nz);
+          if (rc) {
+            h->d_op = 0;
+            return rc;
+          }
+          h->cur ^= 1;
+          h->have_prev = true;
+          h->phi_valid = false;
+        }
+        return done();
+      }
+    }
+  }
+  // ---- plain FD slab (BM1): ghost refresh [+ a non-overlapped step; pf_step_begin/finish is the overlapped form]
+  if (h->d_phase == 0) {
+    h->d_phase = 1;
+    req->kind = PF_DIST_HALO;
+    req->n_halo = 1;
+    req->halo_base[0] = h->c[h->cur];
+    return PF_OK;
+  }
+  if (h->d_op == PF_DIST_OP_STEP) {
+    int rc = launch_step(h, h->d_dt, 0, g.nz);
+    if (rc) {
+      h->d_op = 0;
+      return rc;
+    }
+    h->cur ^= 1;
+    h->have_prev = true;
+  }
+  return done();
+#undef SF_CALL
 }
 
 int pf_diagnostics_local(pf_handle* h, double out[3]) {

@@ -61,6 +61,24 @@ void poisson_destroy(Poisson* po);
 int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream);
 const char* poisson_error(const Poisson* po);
 
+// slab-decomposed FFT building blocks (slabfft.hip)
+struct SlabFFT;
+int64_t slabfft_buffer_doubles(int nx, int ny, int nz, int P);
+int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, double h, bool with_spectral, double* extA,
+                   double* extB, hipStream_t stream, std::string* err);
+void slabfft_destroy(SlabFFT* sf);
+int64_t slabfft_doubles_per_peer(const SlabFFT* sf);
+double* slabfft_buf(const SlabFFT* sf, int which);  // 0 = A (pack side), 1 = B (transposed side)
+int slabfft_forward_local(SlabFFT* sf, const double* real_in);
+int slabfft_forward_local_dfdc(SlabFFT* sf, const double* c, double ca, double cb, double two_rho);
+int slabfft_z(SlabFFT* sf, int inverse);
+int slabfft_inverse_local(SlabFFT* sf, double* real_out);
+int slabfft_poisson_on_T(SlabFFT* sf, double k_over_eps);
+int slabfft_store_chat(SlabFFT* sf);
+int slabfft_spectral_update_on_T(SlabFFT* sf, double dtM, double dtMkappa);
+int slabfft_grad_energy_local(SlabFFT* sf, double* out_dev);
+const char* slabfft_error(const SlabFFT* sf);
+
 // BE-parity mode (fem_be.hip): the reference's P1 crossed-mesh backward-Euler Newton solve on the GPU
 struct FemBE;
 int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, double ca, double cb, double kappa,

@@ -1,0 +1,317 @@
+// Slab-decomposed 3-D FFT building blocks for the multi-GPU spectral / Poisson paths (SURVEY.md section 8e:
+// "slab FFT with one all-to-all transpose each way per transform").
+//
+// A rank owns nzl = nz/P z-planes of a periodic nx x ny x nz box.  Forward transform of a real slab:
+//   (1) batched 2-D r2c over (y, x) of the local planes            -> tmp [zl][y][kx]
+//   (2) pack by destination rank (y split into P chunks of nyl)    -> A   [q][zl][yq][kx]
+//   (3) ALL-TO-ALL (done by the caller over RCCL)                  -> B   [p][zl][yq][kx]  ==  T [z][yq][kx]
+//   (4) batched strided 1-D c2c along z                            -> spectrum in the "transposed" layout T
+// and the mirror image back.  k-space kernels work on T: global indices kz = z, ky = rank*nyl + yq, kx.
+// The library never communicates: pf_dist_advance() runs up to the next exchange and tells the caller which
+// buffers to all-to-all (include/pfhip.h: pf_dist_request).
+#include <hipfft/hipfft.h>
+
+#include "pfhip_internal.h"
+
+namespace pfhip {
+
+namespace {
+
+constexpr double TWO_PI_S = 6.283185307179586476925286766559;
+
+struct SfGeom {
+  int nx, ny, nz, nxh, P, rank, nzl, nyl;
+  double h;
+};
+
+__global__ __launch_bounds__(256) void sf_pack_kernel(const double2* __restrict__ tmp, double2* __restrict__ A,
+                                                      const SfGeom g) {
+  const int64_t n = (int64_t)g.nzl * g.ny * g.nxh;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int kx = (int)(i % g.nxh);
+    const int y = (int)((i / g.nxh) % g.ny);
+    const int zl = (int)(i / ((int64_t)g.nxh * g.ny));
+    const int q = y / g.nyl, yq = y % g.nyl;
+    A[(((int64_t)q * g.nzl + zl) * g.nyl + yq) * g.nxh + kx] = tmp[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void sf_unpack_kernel(const double2* __restrict__ A, double2* __restrict__ tmp,
+                                                        const SfGeom g) {
+  const int64_t n = (int64_t)g.nzl * g.ny * g.nxh;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int kx = (int)(i % g.nxh);
+    const int y = (int)((i / g.nxh) % g.ny);
+    const int zl = (int)(i / ((int64_t)g.nxh * g.ny));
+    const int q = y / g.nyl, yq = y % g.nyl;
+    tmp[i] = A[(((int64_t)q * g.nzl + zl) * g.nyl + yq) * g.nxh + kx];
+  }
+}
+
+__device__ __forceinline__ void t_index(const SfGeom& g, int64_t i, int& kx, int& ky, int& kz) {
+  kx = (int)(i % g.nxh);
+  const int yq = (int)((i / g.nxh) % g.nyl);
+  kz = (int)(i / ((int64_t)g.nxh * g.nyl));
+  ky = g.rank * g.nyl + yq;
+}
+
+// Poisson on T: B <- -(k/eps) B / lambda_h / N   (5/7-point eigenvalues; zero mode dropped)
+__global__ __launch_bounds__(256) void sf_poisson_kernel(double2* __restrict__ B, const SfGeom g, double k_over_eps,
+                                                         double inv_n) {
+  const int64_t n = (int64_t)g.nz * g.nyl * g.nxh;
+  const double inv_h2 = 1.0 / (g.h * g.h);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    int kx, ky, kz;
+    t_index(g, i, kx, ky, kz);
+    double lam = (2.0 * cos(TWO_PI_S * kx / g.nx) - 2.0) + (2.0 * cos(TWO_PI_S * ky / g.ny) - 2.0);
+    lam += 2.0 * cos(TWO_PI_S * kz / g.nz) - 2.0;
+    lam *= inv_h2;
+    const double s = (kx == 0 && ky == 0 && kz == 0) ? 0.0 : -k_over_eps * inv_n / lam;
+    const double2 v = B[i];
+    B[i] = make_double2(v.x * s, v.y * s);
+  }
+}
+
+__device__ __forceinline__ double t_ksq(const SfGeom& g, int64_t i) {
+  int kx, ky, kz;
+  t_index(g, i, kx, ky, kz);
+  if (2 * ky > g.ny) ky -= g.ny;
+  if (2 * kz > g.nz) kz -= g.nz;
+  const double a = TWO_PI_S / (g.nx * g.h) * kx, b = TWO_PI_S / (g.ny * g.h) * ky, c = TWO_PI_S / (g.nz * g.h) * kz;
+  return (a * a + b * b) + c * c;
+}
+
+// spectral CH on T: chat <- (chat - dtM k^2 B) / (1 + dtM kappa k^4);  B <- chat / N   (B holds ghat on entry)
+__global__ __launch_bounds__(256) void sf_spectral_update_kernel(double2* __restrict__ chat, double2* __restrict__ B,
+                                                                 const SfGeom g, double dtM, double dtMkappa,
+                                                                 double inv_n) {
+  const int64_t n = (int64_t)g.nz * g.nyl * g.nxh;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double k2 = t_ksq(g, i);
+    const double num = dtM * k2;
+    const double den = 1.0 / fma(dtMkappa, k2 * k2, 1.0);
+    const double2 ch = chat[i], gh = B[i];
+    double2 o;
+    o.x = fma(-num, gh.x, ch.x) * den;
+    o.y = fma(-num, gh.y, ch.y) * den;
+    chat[i] = o;
+    B[i] = make_double2(o.x * inv_n, o.y * inv_n);
+  }
+}
+
+// local part of sum_k w_k k^2 |chat_k|^2  -> partials (one per block)
+__global__ __launch_bounds__(256) void sf_grad_energy_kernel(const double2* __restrict__ chat, const SfGeom g,
+                                                             double* __restrict__ partials) {
+  __shared__ double sh[4];
+  const int64_t n = (int64_t)g.nz * g.nyl * g.nxh;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int kx = (int)(i % g.nxh);
+    const double w = (kx == 0 || 2 * kx == g.nx) ? 1.0 : 2.0;
+    const double2 c = chat[i];
+    acc += w * t_ksq(g, i) * (c.x * c.x + c.y * c.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sf_sum_kernel(const double* __restrict__ partials, int n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void sf_dfdc_kernel(const double* __restrict__ c, double* __restrict__ g, int64_t n,
+                                                      double ca, double cb, double two_rho) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double w = c[i];
+    const double a = w - ca, b = cb - w;
+    g[i] = two_rho * ((a * b) * (b - a));
+  }
+}
+
+int sf_grid(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+struct SlabFFT {
+  SfGeom g;
+  int64_t blk;  // complex elements per peer block
+  hipfftHandle p2f = 0, p2i = 0, pz = 0;
+  bool have_plans = false;
+  double2 *tmp = nullptr, *A = nullptr, *B = nullptr, *chat = nullptr;
+  bool own_ab = false;
+  double *greal = nullptr, *partials = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+
+#define SF_HIP(expr)                                                       \
+  do {                                                                     \
+    hipError_t e_ = (expr);                                                \
+    if (e_ != hipSuccess) {                                                \
+      sf->err = std::string(#expr) + ": " + hipGetErrorString(e_);         \
+      return -3;                                                           \
+    }                                                                      \
+  } while (0)
+#define SF_FFT(expr)                                                       \
+  do {                                                                     \
+    hipfftResult r_ = (expr);                                              \
+    if (r_ != HIPFFT_SUCCESS) {                                            \
+      sf->err = std::string(#expr) + ": hipfft error " + std::to_string((int)r_); \
+      return -3;                                                           \
+    }                                                                      \
+  } while (0)
+
+const char* slabfft_error(const SlabFFT* sf) { return sf->err.c_str(); }
+int64_t slabfft_doubles_per_peer(const SlabFFT* sf) { return 2 * sf->blk; }
+double* slabfft_buf(const SlabFFT* sf, int which) { return reinterpret_cast<double*>(which == 0 ? sf->A : sf->B); }
+
+// doubles each of the two all-to-all buffers must hold (pure host arithmetic; <0 if the box does not divide)
+int64_t slabfft_buffer_doubles(int nx, int ny, int nz, int P) {
+  if (P < 1 || ny % P || nz % P) return -1;
+  return 2 * (int64_t)(nz / P) * ny * (nx / 2 + 1);
+}
+
+int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, double h, bool with_spectral, double* extA,
+                   double* extB, hipStream_t stream, std::string* err) {
+  SlabFFT* sf = new SlabFFT();
+  *out = sf;
+  sf->stream = stream;
+  SfGeom& g = sf->g;
+  g.nx = nx;
+  g.ny = ny;
+  g.nz = nz;
+  g.nxh = nx / 2 + 1;
+  g.P = P;
+  g.rank = rank;
+  g.h = h;
+  auto body = [&]() -> int {
+    if (ny % P || nz % P) {
+      sf->err = "slab FFT needs ny and nz divisible by the number of ranks";
+      return -2;
+    }
+    g.nzl = nz / P;
+    g.nyl = ny / P;
+    sf->blk = (int64_t)g.nzl * g.nyl * g.nxh;
+    int n2[2] = {ny, nx};
+    SF_FFT(hipfftPlanMany(&sf->p2f, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, g.nzl));
+    SF_FFT(hipfftPlanMany(&sf->p2i, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, g.nzl));
+    int n1[1] = {nz};
+    int emb[1] = {nz};
+    const int stride = g.nyl * g.nxh;
+    SF_FFT(hipfftPlanMany(&sf->pz, 1, n1, emb, stride, 1, emb, stride, 1, HIPFFT_Z2Z, stride));
+    sf->have_plans = true;
+    SF_FFT(hipfftSetStream(sf->p2f, stream));
+    SF_FFT(hipfftSetStream(sf->p2i, stream));
+    SF_FFT(hipfftSetStream(sf->pz, stream));
+    const size_t loc = sizeof(double2) * (size_t)g.nzl * ny * g.nxh;
+    SF_HIP(hipMalloc(&sf->tmp, loc));
+    if (extA && extB) {
+      sf->A = reinterpret_cast<double2*>(extA);
+      sf->B = reinterpret_cast<double2*>(extB);
+    } else {
+      sf->own_ab = true;
+      SF_HIP(hipMalloc(&sf->A, loc));
+      SF_HIP(hipMalloc(&sf->B, loc));
+    }
+    SF_HIP(hipMalloc(&sf->partials, sizeof(double) * 2049));
+    if (with_spectral) {
+      SF_HIP(hipMalloc(&sf->chat, loc));
+      SF_HIP(hipMalloc(&sf->greal, sizeof(double) * (size_t)g.nzl * ny * nx));
+    }
+    return 0;
+  };
+  int rc = body();
+  if (rc && err) *err = sf->err;
+  return rc;
+}
+
+void slabfft_destroy(SlabFFT* sf) {
+  if (!sf) return;
+  if (sf->have_plans) {
+    (void)hipfftDestroy(sf->p2f);
+    (void)hipfftDestroy(sf->p2i);
+    (void)hipfftDestroy(sf->pz);
+  }
+  if (sf->tmp) (void)hipFree(sf->tmp);
+  if (sf->own_ab) {
+    if (sf->A) (void)hipFree(sf->A);
+    if (sf->B) (void)hipFree(sf->B);
+  }
+  if (sf->chat) (void)hipFree(sf->chat);
+  if (sf->greal) (void)hipFree(sf->greal);
+  if (sf->partials) (void)hipFree(sf->partials);
+  delete sf;
+}
+
+// real slab (nzl contiguous planes) -> A, ready for the all-to-all A -> B
+int slabfft_forward_local(SlabFFT* sf, const double* real_in) {
+  const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nxh;
+  SF_FFT(hipfftExecD2Z(sf->p2f, const_cast<double*>(real_in), reinterpret_cast<hipfftDoubleComplex*>(sf->tmp)));
+  hipLaunchKernelGGL(sf_pack_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, (const double2*)sf->tmp, sf->A, sf->g);
+  SF_HIP(hipGetLastError());
+  return 0;
+}
+// same for f'(c) of the slab (spectral scheme)
+int slabfft_forward_local_dfdc(SlabFFT* sf, const double* c, double ca, double cb, double two_rho) {
+  const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nx;
+  hipLaunchKernelGGL(sf_dfdc_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, c, sf->greal, n, ca, cb, two_rho);
+  return slabfft_forward_local(sf, sf->greal);
+}
+int slabfft_z(SlabFFT* sf, int inverse) {
+  SF_FFT(hipfftExecZ2Z(sf->pz, reinterpret_cast<hipfftDoubleComplex*>(sf->B),
+                       reinterpret_cast<hipfftDoubleComplex*>(sf->B), inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+  return 0;
+}
+// A (after the all-to-all B -> A) -> real slab
+int slabfft_inverse_local(SlabFFT* sf, double* real_out) {
+  const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nxh;
+  hipLaunchKernelGGL(sf_unpack_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, (const double2*)sf->A, sf->tmp, sf->g);
+  SF_FFT(hipfftExecZ2D(sf->p2i, reinterpret_cast<hipfftDoubleComplex*>(sf->tmp), real_out));
+  SF_HIP(hipGetLastError());
+  return 0;
+}
+int slabfft_poisson_on_T(SlabFFT* sf, double k_over_eps) {
+  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.nxh;
+  const double inv_n = 1.0 / ((double)sf->g.nx * sf->g.ny * sf->g.nz);
+  hipLaunchKernelGGL(sf_poisson_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, sf->B, sf->g, k_over_eps, inv_n);
+  SF_HIP(hipGetLastError());
+  return 0;
+}
+int slabfft_store_chat(SlabFFT* sf) {  // B (spectrum of c on T) -> resident chat
+  SF_HIP(hipMemcpyAsync(sf->chat, sf->B, sizeof(double2) * (size_t)sf->g.nz * sf->g.nyl * sf->g.nxh,
+                        hipMemcpyDeviceToDevice, sf->stream));
+  return 0;
+}
+int slabfft_spectral_update_on_T(SlabFFT* sf, double dtM, double dtMkappa) {
+  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.nxh;
+  const double inv_n = 1.0 / ((double)sf->g.nx * sf->g.ny * sf->g.nz);
+  hipLaunchKernelGGL(sf_spectral_update_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, sf->chat, sf->B, sf->g, dtM,
+                     dtMkappa, inv_n);
+  SF_HIP(hipGetLastError());
+  return 0;
+}
+// this rank's share of sum_k w_k k^2 |chat_k|^2 -> out_dev[0]
+int slabfft_grad_energy_local(SlabFFT* sf, double* out_dev) {
+  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.nxh;
+  const int nb = sf_grid(n);
+  hipLaunchKernelGGL(sf_grad_energy_kernel, dim3(nb), dim3(256), 0, sf->stream, (const double2*)sf->chat, sf->g,
+                     sf->partials);
+  hipLaunchKernelGGL(sf_sum_kernel, dim3(1), dim3(256), 0, sf->stream, (const double*)sf->partials, nb, out_dev);
+  SF_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pfhip

@@ -25,7 +25,7 @@ class PfConfig(C.Structure):
         ("h", C.c_double),
         ("rho_s", C.c_double), ("c_alpha", C.c_double), ("c_beta", C.c_double), ("kappa", C.c_double),
         ("M", C.c_double), ("k", C.c_double), ("eps_r", C.c_double),
-        ("stream", C.c_void_p), ("ext_c", C.c_void_p * 2),
+        ("stream", C.c_void_p), ("ext_c", C.c_void_p * 2), ("ext_a2a", C.c_void_p * 2), ("ext_phi", C.c_void_p),
     ]
 
 
@@ -41,6 +41,15 @@ class PfHaloLayout(C.Structure):
         ("recv_hi_off", C.c_int64), ("rank_lo", C.c_int32), ("rank_hi", C.c_int32), ("cur_index", C.c_int32),
         ("reserved0", C.c_int32),
     ]
+
+
+PF_DIST_DONE, PF_DIST_ALLTOALL, PF_DIST_HALO = 0, 1, 2
+PF_DIST_OP_STEP, PF_DIST_OP_REFRESH = 1, 2
+
+
+class PfDistRequest(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_halo", C.c_int32), ("src", C.c_void_p), ("dst", C.c_void_p),
+                ("doubles_per_peer", C.c_int64), ("halo_base", C.c_void_p * 2)]
 
 
 class PfkChParams(C.Structure):
@@ -59,6 +68,9 @@ SYMBOLS = {
     "pf_slab_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_field_elems_with_ghosts": (C.c_int64, [C.POINTER(PfConfig)]),
     "pf_field_elems": (C.c_int64, [C.POINTER(PfConfig)]),
+    "pf_a2a_buffer_doubles": (C.c_int64, [C.POINTER(PfConfig)]),
+    "pf_dist_begin": (C.c_int, [_H, C.c_int, C.c_double]),
+    "pf_dist_advance": (C.c_int, [_H, C.POINTER(PfDistRequest)]),
     "pf_create": (C.c_int, [C.POINTER(PfConfig), C.POINTER(_H)]),
     "pf_destroy": (C.c_int, [_H]),
     "pf_set_ic_bm1": (C.c_int, [_H, C.c_double, C.c_double]),

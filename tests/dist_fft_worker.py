@@ -1,0 +1,40 @@
+"""Worker of tests/test_dist_gloo.py (FFT slab modes): one gloo rank running FFTSlabSolver over the numpy mirror of the
+library's distributed state machine.  Usage: python tests/dist_fft_worker.py <out> <mode>   mode: spectral | bm6"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch.distributed as dist
+    from oracle_engine import OracleFFTSlabEngine
+    from pfhubbenchmarks_amd.solver import FFTSlabSolver
+    out, mode = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = (16, 12, 8)
+    eng = OracleFFTSlabEngine(n, 1.0, world, rank, scheme="spectral" if mode == "spectral" else "fd",
+                              model="bm6" if mode == "bm6" else "bm1")
+    rng = np.random.default_rng(4)
+    full = 0.5 + 0.05 * rng.standard_normal((n[2], n[1], n[0]))
+    eng.set_local(full[eng.z0:eng.z0 + eng.nz])
+    s = FFTSlabSolver(eng)
+    dt = 1e-2 if mode == "spectral" else 1e-3
+    d0 = s.diagnostics()
+    s.step(dt, 3)
+    d1 = s.diagnostics()
+    s.step(dt, 1)
+    field = s.gather_field()
+    if rank == 0:
+        np.savez(out, field=field, d0=np.array(d0), d1=np.array(d1), full=full, dt=dt)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

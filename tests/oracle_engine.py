@@ -64,3 +64,146 @@ class OracleSlabEngine:
 
     def sync(self):
         pass
+
+
+class OracleFFTSlabEngine(OracleSlabEngine):
+    """CPU mirror of HipFFTSlabEngine: the same distributed state machine (pf_dist_begin / pf_dist_advance in
+    csrc/pfhip_api.hip) restated with numpy FFTs, so FFTSlabSolver's collectives run under gloo without a GPU."""
+
+    def __init__(self, n, h, nranks, rank, scheme="fd", model="bm1", k=0.09, eps=90.0, kappa=2.0, M=5.0):
+        super().__init__(n, h, nranks, rank)
+        self.P, self.rank = nranks, rank
+        self.scheme, self.model = scheme, model
+        self.k, self.eps, self.kappa, self.M = k, eps, kappa, M
+        nx, ny, nz = self.nx, self.ny, self.nz_global
+        assert ny % nranks == 0 and nz % nranks == 0
+        self.nyl, self.nxh = ny // nranks, nx // 2 + 1
+        na = 2 * self.nz * ny * self.nxh
+        self.a2a = [torch.zeros(na, dtype=torch.float64) for _ in range(2)]
+        self.phi = torch.zeros((self.nz + 4, ny, nx), dtype=torch.float64)
+        self.phi_valid = False
+        self.chat = None
+        self.op = 0
+
+    # complex views of the all-to-all buffers
+    def _A(self):
+        return self.a2a[0].numpy().view(np.complex128).reshape(self.P, self.nz, self.nyl, self.nxh)
+
+    def _B(self):
+        return self.a2a[1].numpy().view(np.complex128).reshape(self.nz_global, self.nyl, self.nxh)
+
+    def _owned(self, t):
+        return t[2:2 + self.nz].numpy()
+
+    def _fwd_local(self, real):
+        tmp = np.fft.rfft2(real, axes=(1, 2))
+        self._A()[...] = tmp.reshape(self.nz, self.P, self.nyl, self.nxh).transpose(1, 0, 2, 3)
+
+    def _inv_local(self, out):
+        tmp = self._A().transpose(1, 0, 2, 3).reshape(self.nz, self.ny, self.nxh)
+        out[...] = np.fft.irfft2(tmp, s=(self.ny, self.nx), axes=(1, 2))
+
+    def _kidx(self):
+        kz = np.arange(self.nz_global)[:, None, None]
+        ky = (self.rank * self.nyl + np.arange(self.nyl))[None, :, None]
+        kx = np.arange(self.nxh)[None, None, :]
+        return kx, ky, kz
+
+    def dist_begin(self, op, dt=0.0):
+        assert self.op == 0
+        self.op, self.phase, self.dt = op, 0, dt
+
+    def _done(self):
+        self.op = 0
+        return ("done",)
+
+    def dist_advance(self):
+        nx, ny, nz, h = self.nx, self.ny, self.nz_global, self.h
+        cur = self.buffers[self._cur]
+        if self.scheme == "spectral":
+            while True:
+                if self.phase == 0:
+                    if self.chat is not None:
+                        self.phase = 2
+                        continue
+                    self._fwd_local(self._owned(cur))
+                    self.phase = 1
+                    return ("alltoall", self.a2a[1], self.a2a[0])
+                if self.phase == 1:
+                    self.chat = np.fft.fft(self._B(), axis=0)
+                    self.phase = 2
+                    continue
+                if self.phase == 2:
+                    if self.op == 2:
+                        return self._done()
+                    from oracle import ch_spectral
+                    self._fwd_local(ch_spectral.fprime(self._owned(cur)))
+                    self.phase = 3
+                    return ("alltoall", self.a2a[1], self.a2a[0])
+                if self.phase == 3:
+                    gh = np.fft.fft(self._B(), axis=0)
+                    kx, ky, kz = self._kidx()
+                    ky = np.where(2 * ky > ny, ky - ny, ky)
+                    kz = np.where(2 * kz > nz, kz - nz, kz)
+                    k2 = ((2 * np.pi / (nx * h) * kx) ** 2 + (2 * np.pi / (ny * h) * ky) ** 2) + (2 * np.pi / (nz * h) * kz) ** 2
+                    self.chat = (self.chat - (self.dt * self.M) * k2 * gh) / (1.0 + (self.dt * self.M * self.kappa) * k2 ** 2)
+                    self._B()[...] = np.fft.ifft(self.chat, axis=0)
+                    self.phase = 4
+                    return ("alltoall", self.a2a[0], self.a2a[1])
+                self._inv_local(self._owned(self.buffers[1 - self._cur]))
+                self._cur ^= 1
+                return self._done()
+        if self.model == "bm6":
+            if self.phase == 0:
+                if self.phi_valid and self.op == 2:
+                    return self._done()
+                self._fwd_local(self._owned(cur))
+                self.phase = 1
+                return ("alltoall", self.a2a[1], self.a2a[0])
+            if self.phase == 1:
+                ch = np.fft.fft(self._B(), axis=0)
+                kx, ky, kz = self._kidx()
+                lam = ((2 * np.cos(2 * np.pi * kx / nx) - 2) + (2 * np.cos(2 * np.pi * ky / ny) - 2)
+                       + (2 * np.cos(2 * np.pi * kz / nz) - 2)) / (h * h)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    ph = np.where(lam != 0.0, -(self.k / self.eps) * ch / lam, 0.0)
+                self._B()[...] = np.fft.ifft(ph, axis=0)
+                self.phase = 2
+                return ("alltoall", self.a2a[0], self.a2a[1])
+            if self.phase == 2:
+                self._inv_local(self._owned(self.phi))
+                self.phase = 3
+                return ("halo", [cur, self.phi])
+            self.phi_valid = True
+            if self.op == 1:
+                ch_fd.fd_step(cur.numpy(), self.dt, h=h, phi=self.phi.numpy(), k_phi=self.k, ghost=2, zwrap=0,
+                              out=self.buffers[1 - self._cur].numpy())
+                self._cur ^= 1
+                self.phi_valid = False
+            return self._done()
+        if self.phase == 0:
+            self.phase = 1
+            return ("halo", [cur])
+        if self.op == 1:
+            self._launch(self.dt, 0, self.nz)
+            self._cur ^= 1
+        return self._done()
+
+    def diag_local(self):
+        cur = self.buffers[self._cur].numpy()
+        if self.scheme == "spectral":
+            c = cur[2:2 + self.nz]
+            f = 5.0 * ((c - 0.3) * (0.7 - c)) ** 2
+            kx, ky, kz = self._kidx()
+            w = np.where((kx == 0) | (2 * kx == self.nx), 1.0, 2.0)
+            ky = np.where(2 * ky > self.ny, ky - self.ny, ky)
+            kz = np.where(2 * kz > self.nz_global, kz - self.nz_global, kz)
+            h = self.h
+            k2 = ((2 * np.pi / (self.nx * h) * kx) ** 2 + (2 * np.pi / (self.ny * h) * ky) ** 2) + (
+                2 * np.pi / (self.nz_global * h) * kz) ** 2
+            g = np.sum(w * k2 * np.abs(self.chat) ** 2) / (self.nx * self.ny * self.nz_global)
+            vol = h ** 3
+            return [vol * (f.sum() + 0.5 * self.kappa * g), vol * c.sum(), 0.0]
+        phi = self.phi.numpy() if self.model == "bm6" else None
+        F, C, E = ch_fd.diagnostics(cur, h=self.h, dim=3, ghost=2, zwrap=0, phi=phi, k=self.k)
+        return [F, C, E]

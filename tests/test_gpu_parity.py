@@ -417,3 +417,69 @@ def test_fem_be_parity_mode_bm6(lib, golden_dir):
             assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(C - Co) <= 1e-12 * abs(Co)
             assert np.abs(s.get_c() - o.c).max() <= 1e-9
             assert np.abs(s.get_phi() - o.phi).max() <= 1e-9
+
+
+def _lockstep(engs, op, dt=0.0):
+    """Run the distributed state machine of all slab handles on the one GPU, doing by hand (tensor copies) the
+    all-to-all / halo exchanges that FFTSlabSolver does over RCCL."""
+    P = len(engs)
+    for e in engs:
+        e.dist_begin(op, dt)
+    while True:
+        reqs = [e.dist_advance() for e in engs]
+        torch.cuda.synchronize()
+        kinds = {r[0] for r in reqs}
+        assert len(kinds) == 1
+        kind = kinds.pop()
+        if kind == "done":
+            return
+        if kind == "alltoall":
+            for q in range(P):
+                dst = reqs[q][1].view(P, -1)
+                for p in range(P):
+                    dst[p].copy_(reqs[p][2].view(P, -1)[q])
+        else:
+            nb = len(reqs[0][1])
+            for b in range(nb):
+                for r, e in enumerate(engs):
+                    lo, hi = engs[(r - 1) % P], engs[(r + 1) % P]
+                    mine = reqs[r][1][b]
+                    mine[0:2].copy_(reqs[(r - 1) % P][1][b][lo.nz:lo.nz + 2])
+                    mine[e.nz + 2:e.nz + 4].copy_(reqs[(r + 1) % P][1][b][2:4])
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mode", ["spectral", "bm6"])
+def test_fft_slab_modes_on_one_gpu(lib, mode):
+    """slab FFT modes (pf_dist_begin / pf_dist_advance): two rank handles on the one GPU, collectives emulated by
+    copies, against the single-domain numpy oracles"""
+    from oracle import bm6_fd, ch_spectral
+    from pfhubbenchmarks_amd.solver import HipFFTSlabEngine
+    n = (64, 24, 16)
+    rng = np.random.default_rng(31)
+    full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
+    P = 2
+    engs = [HipFFTSlabEngine(n, 1.0, P, r, 0, scheme="spectral" if mode == "spectral" else "fd",
+                             model="bm6" if mode == "bm6" else "bm1") for r in range(P)]
+    for e in engs:
+        e.set_local(full[e.z0:e.z0 + e.nz])
+    dt = 1e-2 if mode == "spectral" else 1e-3
+    if mode == "spectral":
+        o = ch_spectral.SpectralCH(full, h=1.0)
+    else:
+        o = bm6_fd.BM6FD(full, 1.0)
+    _lockstep(engs, 2)
+    d = np.sum([e.diag_local() for e in engs], 0)
+    ref = o.diagnostics()
+    assert abs(d[0] - ref[0]) <= 1e-11 * abs(ref[0]) and abs(d[1] - ref[1]) <= 1e-13 * abs(ref[1])
+    for _ in range(3):
+        _lockstep(engs, 1, dt)
+    o.step(dt, 3)
+    got = np.concatenate([e.get_local() for e in engs], 0)
+    assert np.abs(got - o.c).max() <= 1e-12
+    _lockstep(engs, 2)
+    d = np.sum([e.diag_local() for e in engs], 0)
+    ref = o.diagnostics()
+    assert abs(d[0] - ref[0]) <= 1e-11 * abs(ref[0]) and abs(d[1] - ref[1]) <= 1e-13 * abs(ref[1])
+    for e in engs:
+        e.close()
