@@ -106,7 +106,8 @@ def bench_fem_be(a, world):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "bm1_fem_be", "mesh": "100x100 crossed, 20201 nodes, 40402 dofs",
                       "time_grid": "rows %d..%d of results/bench1_out.csv" % (a.warmup, a.warmup + steps - 1),
-                      "newton_iterations": its, "linear_solver": "block-tridiagonal LU (rocSOLVER/rocBLAS)"},
+                      "newton_iterations": its, "linear_solver": "block cyclic reduction, strided-batched rocSOLVER/rocBLAS "
+                                       "(PFHIP_FEM_SOLVER=thomas: sequential block Thomas)"},
            "roofline": None,
            "check": {"t": float(tprev), "F": F, "C": C},
            # (this repo has its own dolfin/ directory of command-line shims, so probe FEniCS's dependencies instead)

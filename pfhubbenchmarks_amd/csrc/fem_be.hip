@@ -6,9 +6,10 @@
 //             (+ poisson_weak_form pfbase.py:410-421, dfdc += k phi, Dirichlet phi: bench6.py:61-90)
 //   quadrature degree 3 -> 6-point Strang-Fix rule for f'(c), f''(c), f(c)     bench1.py:14-16
 //   solver    Newton on ||R||_2 < 1e-6 (bench1.py:85-88), full steps; the reference's GMRES+SOR inner solve
-//             (bench1.py:98-99) is replaced by a DIRECT block-tridiagonal LU: with unknowns grouped by mesh row
-//             ({corner row j, centre row j}) the Jacobian is block tridiagonal with (2N+1) nf-sized blocks, factored
-//             by a block Thomas sweep (rocSOLVER getrf/getrs + rocBLAS gemm per block).  Robust at every dt of the
+//             (bench1.py:98-99) is replaced by a DIRECT block-tridiagonal solve: with unknowns grouped by mesh row
+//             ({corner row j, centre row j}) the Jacobian is block tridiagonal with (2N+1) nf-sized blocks, solved by
+//             block cyclic reduction (7 levels of strided-batched rocSOLVER getrf/getrs + rocBLAS gemm; the sequential
+//             block Thomas sweep is kept behind PFHIP_FEM_SOLVER=thomas, 7x slower).  Robust at every dt of the
 //             reference run (0.1 .. 102.4), where unpreconditioned Krylov stalls.
 //   diagnostics  total_solute / total_free_energy with the same element quadrature     bench1.py:121-125
 //
@@ -18,6 +19,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -302,6 +304,8 @@ struct FemBE {
   double *c = nullptr, *mu = nullptr, *phi = nullptr, *c0 = nullptr, *mu0 = nullptr, *phi0 = nullptr;
   // linear system
   double *D = nullptr, *Lo = nullptr, *Up = nullptr, *rhs = nullptr;
+  double *Lo2 = nullptr, *Up2 = nullptr;  // second coupling set (block cyclic reduction ping-pongs between the two)
+  int solver = 0;                          // 0: block cyclic reduction (batched), 1: block Thomas (sequential)
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double atol = 1e-6;
@@ -448,6 +452,12 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_HIP(hipMalloc(&fb->D, bs));
     FB_HIP(hipMalloc(&fb->Lo, bs));
     FB_HIP(hipMalloc(&fb->Up, bs));
+    FB_HIP(hipMalloc(&fb->Lo2, bs));
+    FB_HIP(hipMalloc(&fb->Up2, bs));
+    {
+      const char* e = getenv("PFHIP_FEM_SOLVER");
+      fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
+    }
     FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * (size_t)p.nb * p.ng));
     FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
     FB_HIP(hipMalloc(&fb->info, sizeof(rocblas_int) * p.ng));
@@ -470,6 +480,7 @@ void fembe_destroy(FemBE* fb) {
   for (void* q : {(void*)fb->tri, (void*)fb->Ke, (void*)fb->ell_col, (void*)fb->ell_K, (void*)fb->ell_M,
                   (void*)fb->nt_ptr, (void*)fb->nt_tri, (void*)fb->nt_loc, (void*)fb->c, (void*)fb->mu, (void*)fb->phi,
                   (void*)fb->c0, (void*)fb->mu0, (void*)fb->phi0, (void*)fb->D, (void*)fb->Lo, (void*)fb->Up,
+                  (void*)fb->Lo2, (void*)fb->Up2,
                   (void*)fb->rhs, (void*)fb->piv, (void*)fb->info, (void*)fb->scal, (void*)fb->partials})
     if (q) (void)hipFree(q);
   if (fb->scal_host) (void)hipHostFree(fb->scal_host);
@@ -548,6 +559,85 @@ static int block_solve(FemBE* fb) {
   return 0;
 }
 
+// Block cyclic reduction: log2(ng) levels; every level eliminates the odd-numbered active blocks with STRIDED-BATCHED
+// rocSOLVER / rocBLAS calls (all blocks of a level factor concurrently -- the sequential block Thomas sweep above
+// is latency-bound: 101 dependent stages of small dense kernels).  Level with stride s, active blocks g = k s:
+//   odd k (eliminated):  Lb = D^-1 Lo, Ub = D^-1 Up, rb = D^-1 r
+//   even k (kept):       D  -= Lo Ub[left] + Up Lb[right];   r -= Lo rb[left] + Up rb[right]
+//                        Lo' = -Lo Lb[left]  (now couples to g - 2s);   Up' = -Up Ub[right]  (to g + 2s)
+// then back-substitution level by level:  x_e = rb_e - Lb_e x_{e-s} - Ub_e x_{e+s}.
+static int block_solve_bcr(FemBE* fb) {
+  const FemParams& p = fb->p;
+  const int nb = p.nb, ng = p.ng;
+  const int64_t bs = (int64_t)nb * nb;
+  const double one = 1.0, mone = -1.0, zero = 0.0;
+  double* Ls[2] = {fb->Lo, fb->Lo2};
+  double* Us[2] = {fb->Up, fb->Up2};
+  struct Level {
+    int s, m, set;
+  };
+  std::vector<Level> levels;
+  int s = 1, m = ng, set = 0;
+  while (m > 1) {
+    const int ne = m / 2, nk = (m + 1) / 2;
+    const int64_t st = 2 * (int64_t)s * bs, sv = 2 * (int64_t)s * nb;
+    double *Lc = Ls[set], *Uc = Us[set], *Ln = Ls[1 - set], *Un = Us[1 - set];
+    double* De = fb->D + (int64_t)s * bs;
+    rocblas_int* pe = fb->piv + (int64_t)s * nb;
+    FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
+    FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
+                                             Lc + (int64_t)s * bs, nb, st, ne));
+    FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
+                                             Uc + (int64_t)s * bs, nb, st, ne));
+    FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, 1, De, nb, st, pe, sv,
+                                             fb->rhs + (int64_t)s * nb, nb, sv, ne));
+    const int nl = nk - 1;  // kept blocks k = 2, 4, .. have a left neighbour
+    if (nl > 0) {
+      const int64_t j0 = 2 * (int64_t)s;
+      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
+                                            Lc + j0 * bs, nb, st, Uc + (int64_t)s * bs, nb, st, &one, fb->D + j0 * bs,
+                                            nb, st, nl));
+      FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Lc + j0 * bs, nb, st,
+                                            fb->rhs + (int64_t)s * nb, 1, sv, &one, fb->rhs + j0 * nb, 1, sv, nl));
+      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
+                                            Lc + j0 * bs, nb, st, Lc + (int64_t)s * bs, nb, st, &zero, Ln + j0 * bs, nb,
+                                            st, nl));
+    }
+    const int nr = ne;  // kept blocks k = 0, 2, .. with k + 1 <= m - 1 have a right neighbour
+    if (nr > 0) {
+      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone, Uc,
+                                            nb, st, Lc + (int64_t)s * bs, nb, st, &one, fb->D, nb, st, nr));
+      FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Uc, nb, st,
+                                            fb->rhs + (int64_t)s * nb, 1, sv, &one, fb->rhs, 1, sv, nr));
+      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone, Uc,
+                                            nb, st, Uc + (int64_t)s * bs, nb, st, &zero, Un, nb, st, nr));
+    }
+    // couplings that do not exist at the next level
+    FB_HIP(hipMemsetAsync(Ln, 0, sizeof(double) * bs, fb->stream));
+    if (nk > nr) FB_HIP(hipMemsetAsync(Un + 2 * (int64_t)s * (nk - 1) * bs, 0, sizeof(double) * bs, fb->stream));
+    levels.push_back({s, m, set});
+    s *= 2;
+    m = nk;
+    set = 1 - set;
+  }
+  FB_BLAS(rocsolver_dgetrf(fb->bh, nb, nb, fb->D, nb, fb->piv, fb->info));
+  FB_BLAS(rocsolver_dgetrs(fb->bh, rocblas_operation_none, nb, 1, fb->D, nb, fb->piv, fb->rhs, nb));
+  for (int l = (int)levels.size() - 1; l >= 0; --l) {
+    const Level& L = levels[l];
+    const int ne = L.m / 2;
+    const int nright = (L.m % 2) ? ne : ne - 1;  // eliminated blocks that have a right neighbour
+    const int64_t st = 2 * (int64_t)L.s * bs, sv = 2 * (int64_t)L.s * nb;
+    double* re = fb->rhs + (int64_t)L.s * nb;
+    FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Ls[L.set] + (int64_t)L.s * bs,
+                                          nb, st, fb->rhs, 1, sv, &one, re, 1, sv, ne));
+    if (nright > 0)
+      FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone,
+                                            Us[L.set] + (int64_t)L.s * bs, nb, st, fb->rhs + 2 * (int64_t)L.s * nb, 1, sv,
+                                            &one, re, 1, sv, nright));
+  }
+  return 0;
+}
+
 // one backward-Euler step; *converged = 0 leaves the state unchanged (bench1.py:164-177 then halves dt)
 int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
   const FemParams& p = fb->p;
@@ -577,7 +667,7 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     const int nid = p.N * p.nf + (p.nf == 3 ? 2 * (p.N + 1) : 0);
     hipLaunchKernelGGL(fem_identity_kernel, dim3((nid + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
     FB_HIP(hipGetLastError());
-    rc = block_solve(fb);
+    rc = fb->solver == 1 ? block_solve(fb) : block_solve_bcr(fb);
     if (rc) return rc;
     hipLaunchKernelGGL(fem_update_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
                        (const double*)fb->rhs, fb->c, fb->mu, fb->phi);
