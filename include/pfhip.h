@@ -206,7 +206,8 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
                    int zwrap, int zlo, int zhi, const pfk_ch_params* p, int impl, void* stream);
 
 /* tuning hooks for benchmarks: key 0 = fused-kernel variant (table in csrc/ch_fd_kernels.hip);
- * key 1 = target number of workgroups for the z-chunk split; key 2 = minimum planes per z-chunk */
+ * key 1 = target number of workgroups for the z-chunk split; key 2 = minimum planes per z-chunk;
+ * key 3 = largest number of 2-D time steps fused into one launch (1, 2 or 4) */
 int pfk_set_tuning(int key, int value);
 
 #ifdef __cplusplus

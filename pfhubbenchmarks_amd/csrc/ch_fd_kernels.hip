@@ -314,6 +314,97 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
   }
 }
 
+// ---- 2-D multi-step kernel --------------------------------------------------------------------------------------
+// The reference's real workloads are small 2-D boxes (200 x 200, bench1.py:21-22): a 400^2 lattice is 1.3 MB, so a
+// step is launch-latency bound, not HBM bound.  This kernel keeps a tile in LDS / registers for K time steps per launch
+// (overlapped tiling: a 128 x R tile shrinks by 2 cells per side per step, so the output is (128-4K) x (R-4K)):
+// K = 4 cuts launches 4x for ~1.7x redundant arithmetic.  Every lane and row runs identical code (no roles): cells
+// outside the shrinking valid region compute garbage nobody reads.  Same per-cell operation order as the 3-D kernel
+// with nz = 1 (the z terms are exactly +0), hence bit-identical to K single steps.
+template <int K, int S>
+__global__ __launch_bounds__(512) void ch_fd2d_multistep_kernel(const FdArgs a, int ntx) {
+  constexpr int NW = 8, R = NW * S, H = 2 * K;
+  constexpr int TXO = TXW - 2 * H, TYO = R - 2 * H;
+  static_assert(TYO > 0 && TXO > 0, "tile too small for K steps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Ct = reinterpret_cast<double*>(smem_raw) + PITCH;  // rows -1 .. R (pad row above and below)
+  double* Mt = Ct + (R + 2) * PITCH;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tx = blockIdx.x % ntx, ty = blockIdx.x / ntx;
+  const int x0 = tx * TXO, y0 = ty * TYO;
+  const int col = 2 + 2 * lane;  // LDS column of the pair (tile column 2*lane)
+  const uint32_t plane_bytes = (uint32_t)((int64_t)a.nx * a.ny * 8);
+  const int xg = wrapi(x0 - H + 2 * lane, a.nx);
+  const auto rc = plane_rsrc(a.cin, plane_bytes);
+  const auto ro = plane_rsrc(a.cout, plane_bytes);
+  double2 c[S];
+  int rr[S];
+  uint32_t soff[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int r = wave * S + s;
+    rr[s] = r;
+    c[s] = bld2(rc, (uint32_t)((wrapi(y0 - H + r, a.ny) * a.nx + xg) * 8));
+    const int yo = y0 + r - H, xo = x0 + 2 * lane - H;
+    const bool ok = r >= H && r < R - H && yo < a.ny && 2 * lane >= H && 2 * lane < TXW - H && xo < a.nx;
+    soff[s] = ok ? (uint32_t)((yo * a.nx + xo) * 8) : OOB;
+    st2(Ct + r * PITCH + col, c[s]);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double2 mu[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double2 up = s > 0 ? c[s > 0 ? s - 1 : 0] : ld2(Ct + (rr[s] - 1) * PITCH + col);
+      const double2 dn = s + 1 < S ? c[s + 1 < S ? s + 1 : 0] : ld2(Ct + (rr[s] + 1) * PITCH + col);
+      const double2 lxy = lap_xy_pair_ud(Ct, rr[s], col, c[s], up, dn);
+      double2 m;  // nz == 1: Lz = fma(-2, c, c + c) is exactly +0
+      m.x = fma(-a.kh2, lxy.x + 0.0, fprime(c[s].x, a.ca, a.cb, a.two_rho));
+      m.y = fma(-a.kh2, lxy.y + 0.0, fprime(c[s].y, a.ca, a.cb, a.two_rho));
+      mu[s] = m;
+      st2(Mt + rr[s] * PITCH + col, m);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double2 up = s > 0 ? mu[s > 0 ? s - 1 : 0] : ld2(Mt + (rr[s] - 1) * PITCH + col);
+      const double2 dn = s + 1 < S ? mu[s + 1 < S ? s + 1 : 0] : ld2(Mt + (rr[s] + 1) * PITCH + col);
+      const double2 mxy = lap_xy_pair_ud(Mt, rr[s], col, mu[s], up, dn);
+      c[s].x = fma(a.amh2, mxy.x + 0.0, c[s].x);
+      c[s].y = fma(a.amh2, mxy.y + 0.0, c[s].y);
+    }
+    if (k + 1 < K) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) st2(Ct + rr[s] * PITCH + col, c[s]);
+      lds_barrier();
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) bst2(ro, soff[s], c[s]);
+}
+
+template <int K, int S>
+hipError_t launch_2d_t(const FdArgs& a, hipStream_t stream) {
+  constexpr int R = 8 * S, TXO = TXW - 4 * K, TYO = R - 4 * K;
+  const int ntx = (a.nx + TXO - 1) / TXO, nty = (a.ny + TYO - 1) / TYO;
+  const size_t lds = sizeof(double) * 2 * (R + 2) * PITCH;
+  auto kern = ch_fd2d_multistep_kernel<K, S>;
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+  }
+  FdArgs b = a;  // the 2-D kernel addresses plane 0 of ghost-free buffers
+  hipLaunchKernelGGL(kern, dim3(ntx * nty), dim3(512), lds, stream, b, ntx);
+  return hipGetLastError();
+}
+
 // ---- two-pass reference implementation (any nx, ny, nz; 40 B/cell of traffic) ------------------------------
 __global__ __launch_bounds__(256) void ch_fd_mu_kernel(const FdArgs a, double* __restrict__ mu) {
   // mu on planes zlo-1 .. zhi  -> scratch plane index (z - (zlo-1))
@@ -450,6 +541,34 @@ hipError_t launch_ch_fd_twopass(const FdArgs& a, double* mu_scratch, hipStream_t
   hipLaunchKernelGGL(ch_fd_mu_kernel, dim3(grid_for(n1)), dim3(256), 0, stream, a, mu_scratch);
   hipLaunchKernelGGL(ch_fd_update_kernel, dim3(grid_for(n2)), dim3(256), 0, stream, a, (const double*)mu_scratch);
   return hipGetLastError();
+}
+
+// K steps of a 2-D (nz == 1, periodic, no phi) problem in one launch; K in {1, 2, 4}
+bool ch_fd2d_supported(const FdArgs& a) {
+  return a.nz == 1 && a.zwrap == 1 && a.ghost == 0 && a.phi == nullptr && ch_fd_fused_supported(a);
+}
+int g_2d_rows4 = 4, g_2d_rows2 = 3, g_2d_rows1 = 2;  // measured best on MI355X at 400^2 .. 2048^2 (profiles/r01/sweep_2d_multistep.log); rows per wave for K = 4 / 2 / 1 (tuning: pfk_set_tuning key 4)
+hipError_t launch_ch_fd2d(const FdArgs& a, int K, hipStream_t stream) {
+  switch (K) {
+    case 4:
+      if (g_2d_rows4 == 4) return launch_2d_t<4, 4>(a, stream);
+      if (g_2d_rows4 == 3) return launch_2d_t<4, 3>(a, stream);
+      return launch_2d_t<4, 6>(a, stream);
+    case 2:
+      if (g_2d_rows2 == 2) return launch_2d_t<2, 2>(a, stream);
+      if (g_2d_rows2 == 3) return launch_2d_t<2, 3>(a, stream);
+      return launch_2d_t<2, 4>(a, stream);
+    case 1:
+      if (g_2d_rows1 == 2) return launch_2d_t<1, 2>(a, stream);
+      if (g_2d_rows1 == 1) return launch_2d_t<1, 1>(a, stream);
+      return launch_2d_t<1, 3>(a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+void set_2d_rows(int k, int rows) {
+  if (k == 4) g_2d_rows4 = rows;
+  if (k == 2) g_2d_rows2 = rows;
+  if (k == 1) g_2d_rows1 = rows;
 }
 
 void set_fused_variant(int v) { g_fused_variant = v; }

@@ -179,7 +179,9 @@ int ensure_phi(pf_handle* h) {
 
 // one FD step on planes [zlo, zhi) of the current buffer into the other buffer
 // (spectral scheme: one whole-domain semi-implicit step, zlo/zhi ignored)
-int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
+int g_max_k2d = 4;  // pfk_set_tuning key 3: largest number of 2-D steps fused into one launch (1, 2 or 4)
+
+int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1) {
   if (h->sp) {
     std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
     if (h->timing) {
@@ -216,7 +218,9 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi) {
     int prc = ensure_phi(h);
     if (prc) return prc;
   }
-  if (impl == PF_KERNEL_FUSED) {
+  if (impl == PF_KERNEL_FUSED && ch_fd2d_supported(a)) {
+    PF_HIP(h, launch_ch_fd2d(a, K, h->stream));  // 2-D: K steps per launch, tile resident in LDS
+  } else if (impl == PF_KERNEL_FUSED) {
     PF_HIP(h, launch_ch_fd_fused(a, h->stream));
   } else {
     int rc = ensure_mu_scratch(h, h->g.plane * (int64_t)(zhi - zlo + 2));
@@ -572,9 +576,23 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
     }
     return PF_OK;
   }
-  for (int s = 0; s < nsteps; ++s) {
-    int rc = launch_step(h, dt, 0, h->g.nz);
+  // 2-D BM1 on the fused path: up to 4 steps per launch; the LAST step is always a launch of its own so that the
+  // other buffer holds the state before it (pf_rollback)
+  bool multi = false;
+  if (!h->sp && h->cfg.kernel != PF_KERNEL_TWOPASS) {
+    FdArgs probe = make_args(h, dt, 0, h->g.nz);
+    multi = ch_fd2d_supported(probe);
+  }
+  for (int s = 0; s < nsteps;) {
+    const int left = nsteps - s;
+    int K = 1;
+    if (multi && left > 4 && g_max_k2d >= 4)
+      K = 4;
+    else if (multi && left > 2 && g_max_k2d >= 2)
+      K = 2;
+    int rc = launch_step(h, dt, 0, h->g.nz, K);
     if (rc) return rc;
+    s += K;
     h->cur ^= 1;
   h->phi_valid = false;
   h->chat_valid = false;
@@ -923,6 +941,14 @@ int pfk_set_tuning(int key, int value) {
   }
   if (key == 2 && value > 0) {
     set_fused_chunking(0, value);
+    return PF_OK;
+  }
+  if (key == 3 && (value == 1 || value == 2 || value == 4)) {
+    g_max_k2d = value;
+    return PF_OK;
+  }
+  if (key == 4 && value >= 11 && value <= 46) {  // value = 10 * K + rows-per-wave
+    set_2d_rows(value / 10, value % 10);
     return PF_OK;
   }
   return PF_ERR_INVALID;

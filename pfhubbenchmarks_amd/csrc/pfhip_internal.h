@@ -27,6 +27,10 @@ hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream);
 // mu_scratch: (zhi - zlo + 2) planes of nx*ny doubles
 hipError_t launch_ch_fd_twopass(const FdArgs& a, double* mu_scratch, hipStream_t stream);
 bool ch_fd_fused_supported(const FdArgs& a);
+// 2-D (nz == 1, single rank, BM1): K in {1, 2, 4} time steps per launch, cin -> cout
+bool ch_fd2d_supported(const FdArgs& a);
+hipError_t launch_ch_fd2d(const FdArgs& a, int K, hipStream_t stream);
+void set_2d_rows(int k, int rows);
 
 // diagnostics: raw sums {sum c, sum f_chem, sum |fwd diff|^2, sum c*phi, min c, max c} -> out6 (device, 6 doubles)
 // partials: device scratch of diag_partials_elems() doubles

@@ -483,3 +483,31 @@ def test_fft_slab_modes_on_one_gpu(lib, mode):
     assert abs(d[0] - ref[0]) <= 1e-11 * abs(ref[0]) and abs(d[1] - ref[1]) <= 1e-13 * abs(ref[1])
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("shape", [(34, 18), (50, 130), (512, 512), (7, 258), (200, 400)])
+def test_2d_multistep_launches_are_bit_identical_to_single_steps(lib, orc, shape):
+    """2-D path: up to 4 time steps per launch with the tile resident in LDS (csrc: ch_fd2d_multistep_kernel) must equal
+    the oracle's single steps bit for bit, for every split of nsteps into 4 / 2 / 1-step launches."""
+    ny, nx = shape
+    rng = np.random.default_rng(nx + ny)
+    c = 0.5 + 0.1 * rng.standard_normal(shape)
+    for kmax in (4, 2, 1):
+        assert lib.pfk_set_tuning(3, kmax) == 0
+        with PhaseFieldSolver(dim=2, n=(nx, ny), h=1.0, kernel="fused") as s:
+            s.set_c(c)
+            ref = c
+            done = 0
+            for n in (1, 2, 3, 5, 12):
+                s.step(1e-3, n)
+                for _ in range(n):
+                    ref = orc.fd_step(ref, 1e-3)
+                done += n
+                np.testing.assert_array_equal(s.get_c(), ref, err_msg="kmax %d after %d steps" % (kmax, done))
+            before = s.get_c()
+            s.step(1e-3, 9)
+            s.rollback()                      # the state before the LAST step, also after multi-step launches
+            for _ in range(8):
+                before = orc.fd_step(before, 1e-3)
+            np.testing.assert_array_equal(s.get_c(), before)
+    lib.pfk_set_tuning(3, 4)
