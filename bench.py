@@ -305,9 +305,24 @@ def main():
         out["cpu_baseline"] = cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8)
     elif rank == 0 and world == 1 and not a.no_cpu_baseline:
         if dim == 3:
-            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 64, dt, 80)
+            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 64, dt, 400)
         else:
             out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 1, dt, 4000)
+    if rank == 0 and world == 1 and a.workload == "bm1_fd_512c":
+        # BASELINE.json's metric also names 512^2: short side measurements (wall clock incl. launches), same run
+        also = {}
+        for name, sch, nst, dts in (("bm1_spectral_512s", "spectral", 300, 1e-2), ("bm1_fd_512s", "fd", 4001, 1e-3)):
+            with PhaseFieldSolver(dim=2, n=512, h=h, scheme=sch, device=local_rank) as s2:
+                s2.set_ic_bm1(0.5, 0.05)
+                s2.step(dts, 21)
+                s2.sync()
+                t0 = time.perf_counter()
+                s2.step(dts, nst)
+                s2.sync()
+                e2 = time.perf_counter() - t0
+            also[name] = {"value": 512 * 512 * nst / e2, "unit": "cell-updates/s", "us_per_step": e2 / nst * 1e6,
+                          "steps": nst}
+        out["also"] = also
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
