@@ -32,6 +32,8 @@ constexpr int PITCH = TXW + 4;  // LDS row pitch in doubles: columns x0-2 .. x0+
 struct KArgs {
   FdArgs f;
   int ntx, nty, nchunk, zchunk, ntiles;
+  int nchunk1;  // chunks [0, nchunk1) cover [zlo, zhi); chunks [nchunk1, nchunk) cover the second range [zlo2, zhi2)
+  int zchunk2;
 };
 
 __device__ __forceinline__ int wrapi(int i, int n) {
@@ -124,8 +126,9 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
   const int x0 = tx * TXW, y0 = ty * TY;
   const int w = min(TXW, a.nx - x0);   // valid tile width (even)
   const int hgt = min(TY, a.ny - y0);  // valid tile height
-  const int zs = a.zlo + ch * k.zchunk;
-  const int ze = min(a.zhi, zs + k.zchunk);
+  const bool second = ch >= k.nchunk1;
+  const int zs = second ? a.zlo2 + (ch - k.nchunk1) * k.zchunk2 : a.zlo + ch * k.zchunk;
+  const int ze = second ? min(a.zhi2, zs + k.zchunk2) : min(a.zhi, zs + k.zchunk);
   const int niter = (ze - zs) + 4;
   const int64_t plane = (int64_t)a.nx * a.ny;
   const uint32_t plane_bytes = (uint32_t)(plane * 8);
@@ -495,7 +498,13 @@ hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   if (nchunk > max_chunks) nchunk = max_chunks;
   if (nchunk < 1) nchunk = 1;
   k.zchunk = (nzr + nchunk - 1) / nchunk;
-  k.nchunk = (nzr + k.zchunk - 1) / k.zchunk;
+  k.nchunk1 = (nzr + k.zchunk - 1) / k.zchunk;
+  k.nchunk = k.nchunk1;
+  k.zchunk2 = 1;
+  if (a.zhi2 > a.zlo2) {  // second range (slab mode: the two boundary strips in one launch): one chunk
+    k.zchunk2 = a.zhi2 - a.zlo2;
+    k.nchunk += 1;
+  }
   k.ntiles = xy * k.nchunk;
   const int grid = ((k.ntiles + 7) / 8) * 8;
   const size_t lds = sizeof(double) * (2 * (TY + 4) + 1) * PITCH;  // + dummy row

@@ -511,3 +511,38 @@ def test_2d_multistep_launches_are_bit_identical_to_single_steps(lib, orc, shape
                 before = orc.fd_step(before, 1e-3)
             np.testing.assert_array_equal(s.get_c(), before)
     lib.pfk_set_tuning(3, 4)
+
+
+def test_api_error_paths_return_status_codes(lib):
+    """programmer errors come back as negative pf_status + message, never as exceptions / crashes across the C ABI"""
+    assert lib.pf_destroy(None) == 0
+    with PhaseFieldSolver(dim=2, n=64, h=1.0) as s:
+        h = s._h
+        buf = np.zeros(10)
+        assert lib.pf_set_field(h, L.PF_FIELD_C, buf.ctypes.data_as(C.c_void_p), 10) == L.PF_ERR_INVALID
+        assert b"element count" in lib.pf_last_error(h)
+        assert lib.pf_get_field(h, L.PF_FIELD_MU, buf.ctypes.data_as(C.c_void_p), 10) == L.PF_ERR_UNSUPPORTED
+        assert lib.pf_rollback(h) == L.PF_ERR_STATE
+        assert lib.pf_step(h, C.c_double(-1.0), 1, None) == L.PF_ERR_INVALID
+        assert lib.pf_step(h, C.c_double(1e-3), 0, None) == 0
+        assert lib.pf_step_begin(h, C.c_double(1e-3)) == L.PF_ERR_STATE          # not a slab handle
+        assert lib.pf_dist_begin(h, L.PF_DIST_OP_STEP, C.c_double(1e-3)) == L.PF_ERR_STATE
+        req = L.PfDistRequest()
+        assert lib.pf_dist_advance(h, C.byref(req)) == L.PF_ERR_STATE
+        lay = L.PfHaloLayout()
+        assert lib.pf_halo_layout_get(h, C.byref(lay)) == L.PF_ERR_STATE
+        assert lib.pfk_set_tuning(3, 3) == L.PF_ERR_INVALID and lib.pfk_set_tuning(99, 1) == L.PF_ERR_INVALID
+    e = HipSlabEngine((64, 16, 8), 1.0, 2, 0, 0)
+    out = (C.c_double * 3)()
+    assert lib.pf_step(e._h, C.c_double(1e-3), 1, None) == L.PF_ERR_STATE          # slab handles step via begin/finish
+    assert lib.pf_diagnostics(e._h, out) == L.PF_ERR_STATE
+    assert lib.pf_step_finish(e._h) == L.PF_ERR_STATE
+    assert lib.pf_step_begin(e._h, C.c_double(1e-3)) == 0
+    assert lib.pf_step_begin(e._h, C.c_double(1e-3)) == L.PF_ERR_STATE            # already open
+    assert lib.pf_diagnostics_local(e._h, out) == L.PF_ERR_STATE
+    assert lib.pf_step_finish(e._h) == 0
+    e.close()
+    cfg = L.default_config(3, 30, 1.0)      # slab FFT modes need divisibility
+    cfg.nranks, cfg.rank, cfg.scheme = 4, 0, L.PF_SCHEME_SPECTRAL_SI
+    hh = C.c_void_p()
+    assert lib.pf_create(C.byref(cfg), C.byref(hh)) == L.PF_ERR_UNSUPPORTED and not hh
