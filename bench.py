@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
     ap.add_argument("--min-chunk", type=int, default=0, help="pfk_set_tuning key 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab", action="store_true",
+                    help="N = 1 only: run the multi-GPU code path (RCCL process group of size 1, ghost planes, overlapped "
+                         "exchange with itself) to measure its overhead against the plain single-GPU path")
     a = ap.parse_args()
 
     import torch
@@ -221,8 +224,11 @@ def main():
         dt = 5e-4
 
     dist = None
-    if world > 1:
+    if world > 1 or a.slab:
         import torch.distributed as dist
+        if a.slab and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         from pfhubbenchmarks_amd.solver import FFTSlabSolver, HipFFTSlabEngine
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if scheme == "spectral" or model == "bm6":
@@ -289,7 +295,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
                    "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
-                   "parallelism": "slab%d" % world},
+                   "parallelism": "slab%d%s" % (world, "-forced" if a.slab else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(a.workload, a.variant) if world == 1 else None,

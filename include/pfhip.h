@@ -74,7 +74,8 @@ typedef struct pf_config {
   int32_t device;       /* HIP device ordinal */
   int32_t nranks;       /* slab decomposition along the slowest axis (z in 3-D, y in 2-D); 1 = whole domain */
   int32_t rank;
-  int32_t reserved0;
+  int32_t force_slab;   /* 1: use the ghost-plane (slab) code path even with nranks == 1 -- the rank is then its own ring
+                           neighbour; lets a single GPU exercise the exact multi-GPU path (tests) */
   double h;             /* grid spacing (same on every axis) */
   double rho_s, c_alpha, c_beta, kappa, M; /* bench1.py:32-36 */
   double k, eps_r;                         /* bench6.py:38-39 (BM6 only) */

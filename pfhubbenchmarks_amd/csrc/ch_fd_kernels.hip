@@ -208,7 +208,10 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
     eld[d] = bld2(rc, e_off);
     eld2[d] = bld2(rc, e_off2);
     if constexpr (HAS_PHI) {
-      const auto rp = plane_rsrc(a.phi + zmap(Pl - 1), valid ? plane_bytes : 0u);
+      // phi is needed on the planes where mu is: zs-1 .. ze.  The pipeline-fill iterations would ask for plane zs-3
+      // (one plane BELOW the ghost layers in slab mode): give them an empty descriptor instead of an address.
+      const bool pvalid = valid && Pl - 1 >= zs - 1;
+      const auto rp = plane_rsrc(a.phi + zmap(pvalid ? Pl - 1 : zs - 1), pvalid ? plane_bytes : 0u);
 #pragma unroll
       for (int s = 0; s < S; ++s) ph[d][s] = bld2(rp, off[s]);
       e_ph[d] = bld2(rp, e_mu ? e_off : OOB);

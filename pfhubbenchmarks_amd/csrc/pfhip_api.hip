@@ -47,7 +47,7 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
   g->nzg = ext(2);
   g->plane = (int64_t)g->nx * g->ny;
   if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return bad("bad nranks / rank");
-  if (cfg->nranks > 1) {
+  if (cfg->nranks > 1 || cfg->force_slab == 1) {
     if (cfg->dim != 3) {
       if (err) *err = "slab decomposition is implemented for dim == 3 only";
       return (int)PF_ERR_UNSUPPORTED;
@@ -364,7 +364,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
       (cfg->dim != 2 || cfg->bc != PF_BC_MIRROR || cfg->n[0] != cfg->n[1] || cfg->nranks != 1 || cfg->n[0] < 3))
     return fail(nullptr, PF_ERR_UNSUPPORTED,
                 "PF_SCHEME_FEM_BE: 2-D, PF_BC_MIRROR (natural no-flux), square mesh, one GPU");
-  const bool slab_fft = cfg->nranks > 1 && (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
+  const bool slab_fft = (cfg->nranks > 1 || cfg->force_slab == 1) &&
+                        (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
   if (slab_fft && slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks) < 0)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "slab FFT modes need ny and nz divisible by nranks");
   if ((cfg->ext_a2a[0] == nullptr) != (cfg->ext_a2a[1] == nullptr))
@@ -417,7 +418,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     int frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
                            cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err);
     if (frc != 0) return bail(PF_ERR_HIP);
-  } else if (cfg->model == PF_MODEL_BM6 && cfg->nranks > 1) {
+  } else if (cfg->model == PF_MODEL_BM6 && slab_fft) {
     if (cfg->ext_phi) {
       h->phi = cfg->ext_phi;
     } else {
@@ -570,7 +571,7 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
 int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   if (!h) return PF_ERR_INVALID;
   if (nsteps < 0 || !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step: need dt > 0 and nsteps >= 0");
-  if (h->cfg.nranks != 1) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
+  if (h->g.ghost != 0) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
   if (h->fb) {
     // one backward-Euler Newton solve per step; a failed solve leaves the state untouched and reports ok = 0
     int conv = 1, its = 0, done = 0;
@@ -862,7 +863,7 @@ int pf_diagnostics_local(pf_handle* h, double out[3]) {
 
 int pf_diagnostics(pf_handle* h, double out[3]) {
   if (!h || !out) return PF_ERR_INVALID;
-  if (h->cfg.nranks != 1)
+  if (h->g.ghost != 0)
     return fail(h, PF_ERR_STATE, "pf_diagnostics: slab mode uses pf_diagnostics_local + a sum over ranks");
   return pf_diagnostics_local(h, out);
 }

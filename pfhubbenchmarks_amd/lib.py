@@ -21,7 +21,7 @@ class PfConfig(C.Structure):
     _fields_ = [
         ("struct_bytes", C.c_int32), ("dim", C.c_int32), ("n", C.c_int32 * 3), ("bc", C.c_int32),
         ("scheme", C.c_int32), ("model", C.c_int32), ("kernel", C.c_int32), ("device", C.c_int32),
-        ("nranks", C.c_int32), ("rank", C.c_int32), ("reserved0", C.c_int32),
+        ("nranks", C.c_int32), ("rank", C.c_int32), ("force_slab", C.c_int32),
         ("h", C.c_double),
         ("rho_s", C.c_double), ("c_alpha", C.c_double), ("c_beta", C.c_double), ("kappa", C.c_double),
         ("M", C.c_double), ("k", C.c_double), ("eps_r", C.c_double),

@@ -174,6 +174,7 @@ class HipSlabEngine:
         cfg = _lib.default_config(3, int(nx), float(h))
         cfg.n[0], cfg.n[1], cfg.n[2] = int(nx), int(ny), int(nz)
         cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
+        cfg.force_slab = 1          # nranks == 1: the rank is its own ring neighbour (single-GPU tests of this path)
         for k, v in params.items():
             setattr(cfg, k, float(v))
         self.device = torch.device("cuda", device)
@@ -343,6 +344,7 @@ class HipFFTSlabEngine(HipSlabEngine):
         cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
         cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI}[scheme]
         cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6}[model]
+        cfg.force_slab = 1
         for k, v in params.items():
             setattr(cfg, k, float(v))
         self.device = torch.device("cuda", device)

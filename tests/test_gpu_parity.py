@@ -546,3 +546,20 @@ def test_api_error_paths_return_status_codes(lib):
     cfg.nranks, cfg.rank, cfg.scheme = 4, 0, L.PF_SCHEME_SPECTRAL_SI
     hh = C.c_void_p()
     assert lib.pf_create(C.byref(cfg), C.byref(hh)) == L.PF_ERR_UNSUPPORTED and not hh
+
+
+def test_nccl_path_single_rank(lib):
+    """the production multi-GPU host path (RCCL through torch.distributed) with world size 1 on the one GPU"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_single_rank_worker.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "NCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
