@@ -21,6 +21,12 @@
  *   implicit PETSc ghost scatter inside solver.solve()      | pf_step_begin / pf_step_finish + pf_halo_layout:
  *     (dolfinx/pfbase/pde_problems.py:69,87 shows it)       |   the caller exchanges ghost planes in between
  *   implicit MPI_Allreduce inside df.assemble               | pf_diagnostics_local (caller all-reduces 3 doubles)
+ *   distributed solves under mpirun (PETSc scatters)        | pf_dist_begin / pf_dist_advance: request protocol for the modes
+ *                                                           |   that need an all-to-all (spectral, BM6 Poisson) -- the
+ *                                                           |   library describes the exchange, the caller performs it
+ *   the whole FEniCS pipeline, unchanged numerics           | cfg.scheme = PF_SCHEME_FEM_BE: P1 'crossed' mesh (bench1.py:21-23,
+ *     (mesh, P1xP1, quadrature 3, BE, Newton 1e-6)          |   39-41), Strang-Fix quadrature (:14-16), BE Newton (:85-88);
+ *                                                           |   pf_step == solver.solve(), info.iters == niters
  *
  * Conventions: plain C types only; every function returns 0 on success or a negative pf_status; no C++
  * exception crosses the boundary; pf_last_error() gives a human-readable message.  A handle is not

@@ -97,10 +97,19 @@ template <class R>
 __device__ __forceinline__ void bst2(R rs, uint32_t boff, double2 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)boff, 0, 0);
 }
+// non-temporal variants (aux = 2): streaming data that this launch never touches again
+template <class R>
+__device__ __forceinline__ void bst2_nt(R rs, uint32_t boff, double2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)boff, 0, 2);
+}
+template <class R>
+__device__ __forceinline__ double2 bld2_nt(R rs, uint32_t boff) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff, 0, 2));
+}
 
 // NW waves x S rows per wave; DEPTH = planes prefetched ahead in registers (bytes in flight per workgroup =
 // DEPTH x (TY+4) KiB: what hides the HBM latency when only one or two workgroups fit on a CU).
-template <int NW, int S, int DEPTH, bool HAS_PHI>
+template <int NW, int S, int DEPTH, bool HAS_PHI, int NT = 0>  // NT: 1 = non-temporal stores, 2 = + non-temporal loads
 __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
   static_assert(NW >= 4, "roles of waves 0..3");
   constexpr int TY = NW * S;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
     const int Pl = valid ? Pc : ze + 1;
     const auto rc = plane_rsrc(a.cin + zmap(Pl), valid ? plane_bytes : 0u);
 #pragma unroll
-    for (int s = 0; s < S; ++s) ld[d][s] = bld2(rc, off[s]);
+    for (int s = 0; s < S; ++s) ld[d][s] = NT >= 2 ? bld2_nt(rc, off[s]) : bld2(rc, off[s]);
     eld[d] = bld2(rc, e_off);
     eld2[d] = bld2(rc, e_off2);
     if constexpr (HAS_PHI) {
@@ -309,7 +318,10 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
       mz.y = fma(-2.0, mu2[s].y, mu3[s].y + mu1[s].y);
       o.x = fma(a.amh2, mxy2[s].x + mz.x, c2[s].x);
       o.y = fma(a.amh2, mxy2[s].y + mz.y, c2[s].y);
-      bst2(ro, soff[s], o);
+      if constexpr (NT >= 1)
+        bst2_nt(ro, soff[s], o);
+      else
+        bst2(ro, soff[s], o);
       mu3[s] = mu2[s];
       mu2[s] = mu1[s];
       mxy2[s] = mxy1;
@@ -473,7 +485,7 @@ int g_fused_variant = 0;  // tuning hook (pfk_set_tuning key 0): index into the 
 int g_target_wgs = 0;  // key 1: split z into chunks until the grid has about this many workgroups (0 = #CUs)
 int g_min_chunk = 16;  // key 2: ... but never fewer than this many planes per chunk
 
-template <int NW, int S, int DEPTH>
+template <int NW, int S, int DEPTH, int NT = 0>
 hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   constexpr int TY = NW * S;
   KArgs k;
@@ -512,9 +524,9 @@ hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   const int grid = ((k.ntiles + 7) / 8) * 8;
   const size_t lds = sizeof(double) * (2 * (TY + 4) + 1) * PITCH;  // + dummy row
   if (a.phi)
-    hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, true>), dim3(grid), dim3(64 * NW), lds, stream, k);
+    hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, true, NT>), dim3(grid), dim3(64 * NW), lds, stream, k);
   else
-    hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, false>), dim3(grid), dim3(64 * NW), lds, stream, k);
+    hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, false, NT>), dim3(grid), dim3(64 * NW), lds, stream, k);
   return hipGetLastError();
 }
 
@@ -538,6 +550,8 @@ hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream) {
     case 4: return launch_fused_t<16, 1, 2>(a, stream);
     case 5: return launch_fused_t<16, 1, 3>(a, stream);
     case 6: return launch_fused_t<4, 4, 1>(a, stream);
+    case 7: return launch_fused_t<8, 2, 2, 1>(a, stream);
+    case 8: return launch_fused_t<8, 2, 2, 2>(a, stream);
     default: return launch_fused_t<8, 2, 2>(a, stream);
   }
 }
