@@ -107,6 +107,21 @@ struct pf_handle {
 
 namespace {
 
+// the step just launched wrote the other buffer: make it current; everything derived from the old c is stale
+void swap_buffers(pf_handle* h) {
+  h->cur ^= 1;
+  h->have_prev = true;
+  h->phi_valid = false;
+  h->chat_valid = false;
+}
+// c changed behind the schemes' backs (set_field / set_ic / rollback)
+void invalidate_derived(pf_handle* h) {
+  h->have_prev = false;
+  h->phi_valid = false;
+  h->chat_valid = false;
+  if (h->sp) spectral_invalidate(h->sp);
+}
+
 int fail(pf_handle* h, int code, const std::string& msg) {
   if (h)
     h->err = msg;
@@ -484,10 +499,7 @@ static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   const Geometry& g = h->g;
   PF_HIP(h, launch_ic(h->c[h->cur], g.nx, g.ny, g.nz, g.ghost, h->cfg.h, c0, amp, w0, g.mirror ? g.np[0] : 0,
                       g.mirror ? g.np[1] : 0, h->stream));
-  h->have_prev = false;
-  if (h->sp) spectral_invalidate(h->sp);
-  h->phi_valid = false;
-  h->chat_valid = false;
+  invalidate_derived(h);
   return PF_OK;
 }
 
@@ -526,10 +538,7 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
     PF_HIP(h, hipMemcpyAsync(dst, ext.data(), sizeof(double) * ext.size(), hipMemcpyHostToDevice, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
   }
-  h->have_prev = false;
-  if (h->sp) spectral_invalidate(h->sp);
-  h->phi_valid = false;
-  h->chat_valid = false;
+  invalidate_derived(h);
   return PF_OK;
 }
 
@@ -604,10 +613,7 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
     int rc = launch_step(h, dt, 0, h->g.nz, K);
     if (rc) return rc;
     s += K;
-    h->cur ^= 1;
-  h->phi_valid = false;
-  h->chat_valid = false;
-    h->have_prev = true;
+    swap_buffers(h);
   }
   if (info) {
     double raw[6];
@@ -633,12 +639,7 @@ int pf_rollback(pf_handle* h) {
   }
   if (!h->have_prev) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
   h->cur ^= 1;
-  h->phi_valid = false;
-  h->chat_valid = false;
-  h->have_prev = false;
-  if (h->sp) spectral_invalidate(h->sp);
-  h->phi_valid = false;
-  h->chat_valid = false;
+  invalidate_derived(h);
   return PF_OK;
 }
 
@@ -693,10 +694,7 @@ int pf_step_finish(pf_handle* h) {
     rc = launch_step(h, h->open_dt, 0, nz);
     if (rc) return rc;
   }
-  h->cur ^= 1;
-  h->phi_valid = false;
-  h->chat_valid = false;
-  h->have_prev = true;
+  swap_buffers(h);
   h->step_open = false;
   return PF_OK;
 }
@@ -818,9 +816,7 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
             h->d_op = 0;
             return rc;
           }
-          h->cur ^= 1;
-          h->have_prev = true;
-          h->phi_valid = false;
+          swap_buffers(h);
         }
         return done();
       }
@@ -840,8 +836,7 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
       h->d_op = 0;
       return rc;
     }
-    h->cur ^= 1;
-    h->have_prev = true;
+    swap_buffers(h);
   }
   return done();
 #undef SF_CALL
