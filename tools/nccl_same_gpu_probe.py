@@ -1,3 +1,6 @@
+"""Probe: does RCCL accept two ranks on ONE device?  (No: 'Duplicate GPU detected' -- which is why the N > 1 path is
+validated on a 1-GPU box with a world-size-1 group instead, tests/nccl_single_rank_worker.py.)
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/nccl_same_gpu_probe.py"""
 import os, torch, torch.distributed as dist
 rank=int(os.environ["RANK"]); world=int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
