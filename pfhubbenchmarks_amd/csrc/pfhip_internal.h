@@ -57,6 +57,16 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
 
+// fused LDS-FFT spectral step for 2-D power-of-two grids (spectral2d_fused.hip); same spectrum layout as rocFFT D2Z
+struct Fused2D;
+bool fused2d_supported(int dim, int nx, int ny);
+int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream);
+void fused2d_destroy(Fused2D* f);
+void fused2d_invalidate(Fused2D* f);
+int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
+int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
+                 double M, double kappa, double ca, double cb, double two_rho);
+
 // Poisson solve of BM6 (poisson.hip): lap(phi) = -k c / eps on the lattice; npx, npy > 0 = the reference's
 // Dirichlet-x / no-flux-y boundary conditions on the even extension of an npx x npy-node domain, 0 = periodic box
 struct Poisson;

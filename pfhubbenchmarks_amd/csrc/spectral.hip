@@ -9,6 +9,8 @@
 // may overwrite its input.  The same pointwise f' as the FD kernel: a = c-ca; b = cb-c; 2 rho ((a b)(b-a)).
 #include <hipfft/hipfft.h>
 
+#include <cstdlib>
+
 #include "pfhip_internal.h"
 
 namespace pfhip {
@@ -133,6 +135,7 @@ struct Spectral {
   double* g = nullptr;
   double* partials = nullptr;  // 2048 + 1 doubles
   bool chat_valid = false;
+  Fused2D* fast = nullptr;  // 2-D power-of-two grids: hand-written LDS FFT path (2 launches per step)
   KsArgs ks;
   std::string err;
 };
@@ -194,6 +197,13 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * sp->nh));
     SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
     SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 2049));
+    const char* e = getenv("PFHIP_SPECTRAL_2D");  // "rocfft" forces the library path (A/B comparison)
+    if (fused2d_supported(dim, nx, ny) && !(e && std::string(e) == "rocfft")) {
+      if (fused2d_create(&sp->fast, nx, ny, h, stream) != 0) {
+        sp->err = "fused2d_create failed";
+        return -3;
+      }
+    }
     return 0;
   };
   return fail(body());
@@ -210,13 +220,25 @@ void spectral_destroy(Spectral* sp) {
   if (sp->scratch) (void)hipFree(sp->scratch);
   if (sp->g) (void)hipFree(sp->g);
   if (sp->partials) (void)hipFree(sp->partials);
+  if (sp->fast) fused2d_destroy(sp->fast);
   delete sp;
 }
 
-void spectral_invalidate(Spectral* sp) { sp->chat_valid = false; }
+void spectral_invalidate(Spectral* sp) {
+  sp->chat_valid = false;
+  if (sp->fast) fused2d_invalidate(sp->fast);
+}
 
 static int ensure_chat(Spectral* sp, const double* c) {
   if (sp->chat_valid) return 0;
+  if (sp->fast) {
+    if (fused2d_spectrum(sp->fast, c, sp->chat, sp->ghat) != 0) {
+      sp->err = "fused2d_spectrum launch failed";
+      return -3;
+    }
+    sp->chat_valid = true;
+    return 0;
+  }
   SP_FFT(hipfftExecD2Z(sp->fwd, const_cast<double*>(c), reinterpret_cast<hipfftDoubleComplex*>(sp->chat)));
   sp->chat_valid = true;
   return 0;
@@ -227,6 +249,13 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
                   double cb, double two_rho, hipStream_t stream) {
   int rc = ensure_chat(sp, c_in);
   if (rc) return rc;
+  if (sp->fast) {
+    if (fused2d_step(sp->fast, c_in, c_out, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho) != 0) {
+      sp->err = "fused2d_step launch failed";
+      return -3;
+    }
+    return 0;
+  }
   hipLaunchKernelGGL(dfdc_kernel, dim3(grid_for(sp->n / 2)), dim3(256), 0, stream, c_in, sp->g, sp->n, ca, cb, two_rho);
   SP_FFT(hipfftExecD2Z(sp->fwd, sp->g, reinterpret_cast<hipfftDoubleComplex*>(sp->ghat)));
   KsArgs ks = sp->ks;
