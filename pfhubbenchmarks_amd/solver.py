@@ -324,6 +324,8 @@ class SlabSolver:
         if self.dist.get_backend(self.group) == "nccl":
             loc = loc.to(self.engine.buffers[0].device)
         sizes = [slab_partition(self.engine.nz_global, world, r)[1] for r in range(world)]
+        if len(set(sizes)) != 1:
+            raise ValueError("gather_field needs equal slabs (nz divisible by the number of ranks)")
         parts = [torch.empty((s,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device) for s in sizes]
         self.dist.all_gather(parts, loc, group=self.group)
         return torch.cat(parts, 0).cpu().numpy()
@@ -444,4 +446,5 @@ class FFTSlabSolver:
         v = t.cpu().tolist()
         return v[0], v[1], v[2]
 
-    gather_field = SlabSolver.gather_field
+    def gather_field(self):
+        return SlabSolver.gather_field(self)

@@ -564,3 +564,31 @@ def test_nccl_path_single_rank(lib):
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "nccl_single_rank_worker.py")], env=env, cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "NCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_bench_contract_json_line():
+    """bench.py prints exactly one JSON line with the fields the driver reads (short run of the default workload)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "cell-updates/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64"
+    assert d["config"]["workload"] == "bm1_fd_512c" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 2.0e9          # HBM bytes per launch >= algorithmic 2.15 GB
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "cell-updates/s" and cb["cores"] >= 1 and cb["value"] > 0
+    assert abs(d["value"] - 512 ** 3 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert d["check"]["C_rel_drift"] < 1e-12
