@@ -573,7 +573,9 @@ hipError_t launch_ch_fd_twopass(const FdArgs& a, double* mu_scratch, hipStream_t
 bool ch_fd2d_supported(const FdArgs& a) {
   return a.nz == 1 && a.zwrap == 1 && a.ghost == 0 && a.phi == nullptr && ch_fd_fused_supported(a);
 }
-int g_2d_rows4 = 4, g_2d_rows2 = 3, g_2d_rows1 = 2;  // measured best on MI355X at 400^2 .. 2048^2 (profiles/r01/sweep_2d_multistep.log); rows per wave for K = 4 / 2 / 1 (tuning: pfk_set_tuning key 4)
+// rows per wave for K = 4 / 2 / 1 (pfk_set_tuning key 4); defaults = the best of the sweep on MI355X at 400^2 .. 2048^2
+// (profiles/r01/sweep_2d_multistep.log)
+int g_2d_rows4 = 4, g_2d_rows2 = 3, g_2d_rows1 = 2;
 hipError_t launch_ch_fd2d(const FdArgs& a, int K, hipStream_t stream) {
   switch (K) {
     case 4:

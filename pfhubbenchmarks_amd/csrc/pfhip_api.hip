@@ -193,10 +193,11 @@ int ensure_phi(pf_handle* h) {
   return PF_OK;
 }
 
-// one FD step on planes [zlo, zhi) of the current buffer into the other buffer
-// (spectral scheme: one whole-domain semi-implicit step, zlo/zhi ignored)
 int g_max_k2d = 4;  // pfk_set_tuning key 3: largest number of 2-D steps fused into one launch (1, 2 or 4)
 
+// One FD step on planes [zlo, zhi) (and optionally [zlo2, zhi2): the second boundary strip of a slab, same launch) of the
+// current buffer into the other buffer; K > 1: K steps in one launch (2-D only).  Spectral scheme: one whole-domain
+// semi-implicit step, the plane ranges are ignored.
 int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 = 0, int zhi2 = 0) {
   if (h->sp) {
     std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
@@ -264,7 +265,8 @@ int run_diag(pf_handle* h, double raw[6]) {
   }
   if (h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI && !h->chat_valid)
     return fail(h, PF_ERR_STATE, "slab spectral: run pf_dist_begin(PF_DIST_OP_REFRESH) before diagnostics");
-  PF_HIP(h, launch_diag(h->c[h->cur], h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
+  const double* phi = h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr;
+  PF_HIP(h, launch_diag(h->c[h->cur], phi, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
                         c.c_beta, h->partials, h->out6_dev, h->stream));
   const bool sf_spec = h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI;
   if (h->sp) {

@@ -19,7 +19,7 @@ struct FdArgs {
   int ghost;          // ghost planes per side present in the buffers
   int zwrap;          // 1: periodic inside the buffer; 0: read ghost planes
   int zlo, zhi;       // output plane range [zlo, zhi)
-  int zlo2, zhi2;     // optional second output range handled by the same launch (fused kernel only; empty if zhi2 <= zlo2)
+  int zlo2, zhi2;     // optional second output range of the same launch (fused kernel only; empty if zhi2 <= zlo2)
   double ca, cb, two_rho, kh2, amh2, kphi;
 };
 
