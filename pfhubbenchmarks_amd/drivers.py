@@ -213,6 +213,43 @@ def main_bench6(argv=None):
     run_bench6(a.intervals, 100.0, a.dt, a.end_time, None, a.out_dir, a.save_solution, 0, not a.quiet)
 
 
+def run_b13d(intervals=50, L=100.0, dt=None, end_time=50.0, out_dir="results", device=0, verbose=True):
+    """3-D BM1 (dolfin/b13d.py): 100^3 no-flux box, 50^3 cells (b13d.py:24-26), the 2-D initial condition extruded in z
+    (b13d.py:55 with pfbase.py:187-189 using x[0], x[1] only), end_time = 50 (b13d.py:125).  Rows at the accepted
+    times of the committed 2-D run up to end_time.  The reference script writes results/bench1_out.csv
+    (b13d.py:199-206); to keep the 2-D trajectory this driver writes results/b13d_out.csv."""
+    h = L / intervals
+    times = report_times("bench1")
+    times = times[[i for i, t in enumerate(times) if i == 0 or times[i - 1] < end_time + 1e-12]]
+    if dt is None:
+        dt = stable_dt(h, dim=3, safety=0.4)
+    rows = []
+    t1 = time.time()
+    with PhaseFieldSolver(dim=3, n=intervals + 1, h=h, bc="mirror", device=device) as s:
+        s.set_ic_bm1(0.5, 0.05)
+        for it, tn in enumerate(times):
+            dt = advance_to(s, float(tn), dt, dt / 64.0)
+            F, C, _ = s.diagnostics()
+            rows.append([float(tn), F, C])
+            if verbose:
+                print("Iteration #%d. Time: %g, C_total: %.10f, TFE: %.10f" % (it + 1, tn, C, F))
+    spent = time.time() - t1
+    print("Time spent is %s" % spent)
+    write_csv(os.path.join(out_dir, "b13d_out.csv"), rows)
+    return np.array(rows), spent
+
+
+def main_b13d(argv=None):
+    ap = argparse.ArgumentParser(description="3-D PFHub BM1 on MI355X (counterpart of dolfin/b13d.py)")
+    ap.add_argument("--intervals", type=int, default=50)
+    ap.add_argument("--dt", type=float, default=None)
+    ap.add_argument("--end-time", type=float, default=50.0)
+    ap.add_argument("--out-dir", default="results")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args(argv)
+    run_b13d(a.intervals, 100.0, a.dt, a.end_time, a.out_dir, 0, not a.quiet)
+
+
 def main_bench1(argv=None):
     ap = argparse.ArgumentParser(description="PFHub BM1 on MI355X (counterpart of dolfin/bench1.py)")
     ap.add_argument("--intervals", type=int, default=200, help="grid intervals per side (h = 200/intervals)")

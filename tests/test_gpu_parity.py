@@ -592,3 +592,15 @@ def test_bench_contract_json_line():
     assert cb["kind"] == "port" and cb["unit"] == "cell-updates/s" and cb["cores"] >= 1 and cb["value"] > 0
     assert abs(d["value"] - 512 ** 3 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     assert d["check"]["C_rel_drift"] < 1e-12
+
+
+def test_b13d_driver_3d_extrusion_invariants(lib, tmp_path):
+    """3-D BM1 driver (dolfin/b13d.py semantics): z-extruded data -> F_3D = L_z F_2D and C_3D = L_z C_2D at every row
+    (SURVEY a14), with the 2-D run at the same h and dt."""
+    from pfhubbenchmarks_amd.drivers import run_b13d, run_bench1
+    r3, _ = run_b13d(intervals=50, end_time=1.0, dt=0.005, out_dir=str(tmp_path), verbose=False)
+    r2, _ = run_bench1(intervals=50, L=100.0, scheme="fd", dt=0.005, end_time=1.0, out_dir=str(tmp_path / "two"),
+                       verbose=False)
+    assert r3.shape == r2.shape == (4, 3)
+    np.testing.assert_allclose(r3[:, 1], 100.0 * r2[:, 1], rtol=1e-12)
+    np.testing.assert_allclose(r3[:, 2], 100.0 * r2[:, 2], rtol=1e-12)
