@@ -604,3 +604,69 @@ def test_b13d_driver_3d_extrusion_invariants(lib, tmp_path):
     assert r3.shape == r2.shape == (4, 3)
     np.testing.assert_allclose(r3[:, 1], 100.0 * r2[:, 1], rtol=1e-12)
     np.testing.assert_allclose(r3[:, 2], 100.0 * r2[:, 2], rtol=1e-12)
+
+
+def test_fused_kernel_fuzz_shapes_ranges_phi_with_nan_guards(lib, orc):
+    """Randomised shapes / plane ranges / ghost mode / phi coupling for the stateless kernel entry, bit-compared with
+    the oracle.  Every device buffer sits between NaN-filled guard bands and the outputs outside the requested plane
+    range must stay untouched: an out-of-range read that matters, or a stray write, shows up as a mismatch."""
+    rng = np.random.default_rng(2024)
+    guard = 4096
+    for case in range(48):
+        nx = 2 * int(rng.integers(1, 150))
+        ny = int(rng.integers(1, 40))
+        nz = int(rng.integers(1, 12))
+        slab = bool(rng.integers(0, 2)) and nz >= 1
+        ghost, zwrap = (2, 0) if slab else (0, 1)
+        zlo = int(rng.integers(0, nz))
+        zhi = int(rng.integers(zlo + 1, nz + 1))
+        with_phi = bool(rng.integers(0, 2))
+        variant = int(rng.choice([0, 3, 6]))
+        shape = (nz + 2 * ghost, ny, nx)
+        c = 0.5 + 0.1 * rng.standard_normal(shape)
+        phi = rng.standard_normal(shape) if with_phi else None
+        sentinel = -7.25
+        ref = np.full(shape, sentinel)
+        orc.fd_step(c, 1e-3, phi=phi, k_phi=0.09 if with_phi else 0.0, ghost=ghost, zwrap=zwrap, zlo=zlo, zhi=zhi, out=ref)
+
+        def guarded(a, fill=np.nan):
+            t = torch.full((a.size + 2 * guard,), fill, dtype=torch.float64, device="cuda")
+            t[guard:guard + a.size] = torch.from_numpy(np.ascontiguousarray(a).ravel()).cuda()
+            return t
+        tc = guarded(c)
+        tp = guarded(phi) if with_phi else None
+        to = guarded(np.full(shape, sentinel), fill=sentinel)
+        p = L.PfkChParams(0.3, 0.7, 10.0, 2.0, 1e-3 * 5.0, 0.09 if with_phi else 0.0)
+        assert lib.pfk_set_tuning(0, variant) == 0
+        rc = lib.pfk_ch_fd_step(C.c_void_p(tc.data_ptr() + 8 * guard), C.c_void_p(to.data_ptr() + 8 * guard),
+                                C.c_void_p(tp.data_ptr() + 8 * guard) if with_phi else None, nx, ny, nz, ghost, zwrap,
+                                zlo, zhi, C.byref(p), L.PF_KERNEL_FUSED, None)
+        assert rc == 0, lib.pf_last_error(None)
+        torch.cuda.synchronize()
+        got = to.cpu().numpy()
+        msg = "case %d: nx %d ny %d nz %d slab %s z [%d,%d) phi %s variant %d" % (case, nx, ny, nz, slab, zlo, zhi,
+                                                                                  with_phi, variant)
+        np.testing.assert_array_equal(got[guard:-guard].reshape(shape), ref, err_msg=msg)
+        assert np.all(got[:guard] == sentinel) and np.all(got[-guard:] == sentinel), msg   # no stray writes
+    lib.pfk_set_tuning(0, 0)
+
+
+def test_diagnostics_fuzz(lib, orc):
+    """diagnostics reduction (streaming kernel for even nx, generic kernel for odd nx) on random 2-D / 3-D shapes,
+    periodic and mirror, against the oracle's compensated sums"""
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        dim = int(rng.integers(2, 4))
+        n = [int(rng.integers(2, 140)), int(rng.integers(1, 30)), int(rng.integers(1, 9))][:dim]
+        mirror = bool(rng.integers(0, 2)) and all(v >= 2 for v in n)
+        if not mirror and n[0] % 2 == 1 and rng.integers(0, 2):
+            n[0] += 1
+        shape = tuple(reversed(n))
+        c = 0.5 + 0.1 * rng.standard_normal(shape)
+        kern = "auto"
+        with PhaseFieldSolver(dim=dim, n=tuple(n), h=0.7, bc="mirror" if mirror else "periodic", kernel=kern) as s:
+            s.set_c(c)
+            F, Ctot, _ = s.diagnostics()
+        lat = orc.even_extend(c) if mirror else c
+        Fo, Co, _ = orc.diagnostics(lat, h=0.7, mirror=mirror)
+        assert abs(F - Fo) <= 2e-13 * abs(Fo) and abs(Ctot - Co) <= 2e-13 * abs(Co), (case, n, mirror, F, Fo)
