@@ -14,6 +14,8 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
                 GPUs (512 x 512 x 512 N box, slab FFT: one RCCL all-to-all each way per transform)
   bm6_fd_512c / _256c   BM6 (BASELINE.json config 5) in a periodic box: FFT Poisson solve + coupled fused FD step per
                 step; N > 1: slab FFT Poisson (2 all-to-alls) + ghost exchange of c and phi
+  bm6_fd_512c_elim      the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c) exactly): the step is
+                the fused kernel alone, no transform in the time loop (phi is solved only for diagnostics)
   bm1_fem_be    BASELINE.json config 1: the reference's own algorithm (100x100 crossed P1 mesh, backward Euler, Newton)
                 on the GPU; a "step" is one accepted BE step of the committed run's time grid; metric node-updates/s;
                 cpu_baseline = oracle/fem_be.py (numpy/scipy SuperLU) on the same rows; says whether FEniCS is present
@@ -156,7 +158,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
-                             "bm1_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm1_fem_be"])
+                             "bm1_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
@@ -194,8 +196,13 @@ def main():
         return bench_fem_be(a, world)
     h = 1.0
     scheme, bytes_per_cell = "fd", BYTES_PER_CELL_UPDATE
-    model = "bm1"
-    if a.workload in ("bm6_fd_512c", "bm6_fd_256c"):
+    model, elim = "bm1", False
+    if a.workload == "bm6_fd_512c_elim":
+        # BM6 with phi eliminated algebraically (PF_FLAG_BM6_ELIMINATE_PHI): the step is the fused CH kernel alone
+        model, elim, bytes_per_cell = "bm6", True, BYTES_PER_CELL_UPDATE
+        dim, gn, scaling = 3, (512, 512, 512 * world), "weak"
+        dt = 5e-4
+    elif a.workload in ("bm6_fd_512c", "bm6_fd_256c"):
         # CH kernel 16 B + phi read 8 B + Poisson transform pair idealised at 48 B (r2c 16, invert 16, c2r 16)
         model, bytes_per_cell = "bm6", 72.0
         nn = 512 if a.workload.endswith("512c") else 256
@@ -232,7 +239,7 @@ def main():
         from pfhubbenchmarks_amd.solver import FFTSlabSolver, HipFFTSlabEngine
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if scheme == "spectral" or model == "bm6":
-            eng = HipFFTSlabEngine(gn, h, world, rank, local_rank, scheme=scheme, model=model)
+            eng = HipFFTSlabEngine(gn, h, world, rank, local_rank, scheme=scheme, model=model, eliminate_phi=elim)
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
             solver = FFTSlabSolver(eng)
         else:
@@ -251,7 +258,8 @@ def main():
             dist.barrier()
     else:
         n = gn[:dim]
-        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank, scheme=scheme, model=model)
+        s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank, scheme=scheme, model=model,
+                             eliminate_phi=elim)
         (s.set_ic_bm6 if model == "bm6" else s.set_ic_bm1)()
         solver = timer = s
         local_cells = gn[0] * gn[1] * gn[2]

@@ -91,7 +91,18 @@ typedef struct pf_config {
   double* ext_a2a[2];   /* slab FFT modes (nranks > 1 with PF_SCHEME_SPECTRAL_SI or PF_MODEL_BM6): optional caller-owned
                            all-to-all buffers, pf_a2a_buffer_doubles() doubles each */
   double* ext_phi;      /* BM6 slab mode: optional caller-owned ghosted phi buffer (same size as an ext_c buffer) */
+  int32_t flags;        /* PF_FLAG_* */
+  int32_t reserved1;
 } pf_config;
+
+/* pf_config.flags */
+enum {
+  PF_FLAG_BM6_ELIMINATE_PHI = 1 /* BM6, periodic box, FD scheme: phi solves lap_h(phi) = -(k/eps)(c - mean c) with the SAME
+                                   discrete Laplacian the Cahn-Hilliard step applies to mu, so lap_h(k phi) =
+                                   -(k^2/eps)(c - mean c) exactly and the time step needs no Poisson solve:
+                                   c_new += -dt M k^2/eps (c - mean c).  phi is still solved for diagnostics / output.
+                                   Differs from the explicit-phi path by rounding only. */
+};
 
 typedef struct pf_step_info {
   int32_t ok;        /* 1 if the state after the step(s) is finite and inside the guard band c in [-1, 2] */
@@ -171,6 +182,9 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n);
  * (then the guard reduction is read back).  The state before the LAST step stays available to pf_rollback. */
 int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info);
 int pf_rollback(pf_handle* h);
+/* PF_FLAG_BM6_ELIMINATE_PHI: the lattice mean of c (a conserved quantity).  nranks == 1: computed by the library when
+ * needed; slab mode: the caller passes the GLOBAL mean (total_solute / volume) once after setting the state. */
+int pf_set_mean_c(pf_handle* h, double mean_c);
 int pf_sync(pf_handle* h);
 
 /* slab mode (nranks > 1), one step:  begin (interior planes; needs no ghosts) -> caller exchanges the ghost
@@ -202,6 +216,7 @@ typedef struct pfk_ch_params {
   double kappa_over_h2;            /* kappa / h^2 */
   double dtM_over_h2;              /* dt * M / h^2 */
   double k_phi;                    /* BM6 coupling k (0 for BM1) */
+  double gq, cbar;                 /* PF_FLAG_BM6_ELIMINATE_PHI: c_new += gq (c - cbar), gq = -dt M k^2/eps (0 = off) */
 } pfk_ch_params;
 
 /* One explicit FD Cahn-Hilliard step on planes [zlo, zhi) of a slab:

@@ -56,11 +56,16 @@ def poisson_dirichlet_x(c_ext, npx, npy, h, k=0.09, eps=90.0):
 
 
 class BM6FD:
-    def __init__(self, c, h, mirror_nodes=None, k=0.09, eps=90.0):
-        """c: lattice array (2-D or 3-D).  mirror_nodes = (npx, npy) selects the reference's boundary conditions."""
+    def __init__(self, c, h, mirror_nodes=None, k=0.09, eps=90.0, eliminate_phi=False, cbar=None):
+        """c: lattice array (2-D or 3-D).  mirror_nodes = (npx, npy) selects the reference's boundary conditions.
+        eliminate_phi (periodic box only): lap_h(k phi) = -(k^2/eps)(c - mean c) exactly, so the step needs no Poisson
+        solve: cnew += -dt M k^2/eps (c - cbar) (PF_FLAG_BM6_ELIMINATE_PHI); cbar defaults to the mean of the start field."""
         self.c = np.ascontiguousarray(c, dtype=np.float64)
         self.h, self.k, self.eps = h, k, eps
         self.mirror_nodes = mirror_nodes
+        assert not (eliminate_phi and mirror_nodes is not None)
+        self.eliminate_phi = eliminate_phi
+        self.cbar = float(np.mean(self.c)) if cbar is None else float(cbar)
 
     def phi(self):
         if self.mirror_nodes is None:
@@ -69,6 +74,11 @@ class BM6FD:
 
     def step(self, dt, nsteps=1):
         for _ in range(nsteps):
+            if self.eliminate_phi:
+                c3 = self.c if self.c.ndim == 3 else self.c[None]
+                out = ch_fd.fd_step(c3, dt, h=self.h, elim=(self.k, self.eps, self.cbar))
+                self.c = out if self.c.ndim == 3 else out[0]
+                continue
             phi = np.ascontiguousarray(self.phi())
             c3 = self.c if self.c.ndim == 3 else self.c[None]
             p3 = phi if phi.ndim == 3 else phi[None]

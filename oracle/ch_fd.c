@@ -20,6 +20,8 @@
  *   a = c - ca; b = cb - c; fp = two_rho * ((a*b) * (b - a))
  *   mu   = fma(-kappa/h^2, Lxy + Lz, fp)   [+ fma(k, phi, .) for BM6]
  *   cnew = fma(dt M / h^2, Mxy + Mz, c)    with Mxy, Mz the same stencils applied to mu
+ *   [BM6, periodic box, phi eliminated: lap_h(k phi) = -(k^2/eps)(c - mean c) exactly, because phi solves the discrete
+ *    Poisson problem with the same lap_h (bench6.py:72); then  cnew = fma(gq, c - cbar, cnew),  gq = -dt M k^2 / eps]
  */
 #include <math.h>
 #include <stdint.h>
@@ -45,6 +47,7 @@ typedef struct orc_ch_params {
   double kappa_over_h2;
   double dtM_over_h2;
   double k_phi;
+  double gq, cbar; /* BM6 in a periodic box with phi eliminated: cnew += gq (c - cbar), gq = -dt M k^2 / eps (0 = off) */
 } orc_ch_params;
 
 static inline int64_t wrap(int64_t i, int64_t n) {
@@ -116,7 +119,9 @@ int orc_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
         const double mxy = fma(-4.0, m, sx + sy);
         const double sz = mm[(int64_t)y * nx + x] + mp[(int64_t)y * nx + x];
         const double mz = fma(-2.0, m, sz);
-        o[(int64_t)y * nx + x] = fma(q->dtM_over_h2, mxy + mz, c0[(int64_t)y * nx + x]);
+        double cn = fma(q->dtM_over_h2, mxy + mz, c0[(int64_t)y * nx + x]);
+        if (q->gq != 0.0) cn = fma(q->gq, c0[(int64_t)y * nx + x] - q->cbar, cn);
+        o[(int64_t)y * nx + x] = cn;
       }
     }
     double* t = mrow[0];

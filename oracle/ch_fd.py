@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 class OrcParams(C.Structure):
     _fields_ = [("c_alpha", C.c_double), ("c_beta", C.c_double), ("two_rho", C.c_double),
-                ("kappa_over_h2", C.c_double), ("dtM_over_h2", C.c_double), ("k_phi", C.c_double)]
+                ("kappa_over_h2", C.c_double), ("dtM_over_h2", C.c_double), ("k_phi", C.c_double),
+                ("gq", C.c_double), ("cbar", C.c_double)]
 
 
 def _cpu_has(flag):
@@ -85,9 +86,11 @@ def set_threads(n=0):
     return load().orc_set_threads(int(n) if n > 0 else host_cores())
 
 
-def make_params(dt, h=1.0, rho_s=5.0, c_alpha=0.3, c_beta=0.7, kappa=2.0, M=5.0, k_phi=0.0):
-    """Same host arithmetic as libpfhip's make_args (pfhip_api.hip): two_rho = 2 rho, kappa/(h*h), dt*M/(h*h)."""
-    return OrcParams(c_alpha, c_beta, 2.0 * rho_s, kappa / (h * h), dt * M / (h * h), k_phi)
+def make_params(dt, h=1.0, rho_s=5.0, c_alpha=0.3, c_beta=0.7, kappa=2.0, M=5.0, k_phi=0.0, elim=None):
+    """Same host arithmetic as libpfhip's make_args (pfhip_api.hip): two_rho = 2 rho, kappa/(h*h), dt*M/(h*h).
+    elim = (k, eps, cbar): BM6 with phi eliminated -> gq = -(dt*M)*(k*k/eps)."""
+    gq, cbar = (0.0, 0.0) if elim is None else (-(dt * M) * (elim[0] * elim[0] / elim[1]), elim[2])
+    return OrcParams(c_alpha, c_beta, 2.0 * rho_s, kappa / (h * h), dt * M / (h * h), k_phi, gq, cbar)
 
 
 def _p(a):

@@ -318,6 +318,10 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
       mz.y = fma(-2.0, mu2[s].y, mu3[s].y + mu1[s].y);
       o.x = fma(a.amh2, mxy2[s].x + mz.x, c2[s].x);
       o.y = fma(a.amh2, mxy2[s].y + mz.y, c2[s].y);
+      if (a.gq != 0.0) {  // BM6, phi eliminated (wave-uniform branch)
+        o.x = fma(a.gq, c2[s].x - a.cbar, o.x);
+        o.y = fma(a.gq, c2[s].y - a.cbar, o.y);
+      }
       if constexpr (NT >= 1)
         bst2_nt(ro, soff[s], o);
       else
@@ -390,8 +394,14 @@ __global__ __launch_bounds__(512) void ch_fd2d_multistep_kernel(const FdArgs a, 
       const double2 up = s > 0 ? mu[s > 0 ? s - 1 : 0] : ld2(Mt + (rr[s] - 1) * PITCH + col);
       const double2 dn = s + 1 < S ? mu[s + 1 < S ? s + 1 : 0] : ld2(Mt + (rr[s] + 1) * PITCH + col);
       const double2 mxy = lap_xy_pair_ud(Mt, rr[s], col, mu[s], up, dn);
-      c[s].x = fma(a.amh2, mxy.x + 0.0, c[s].x);
-      c[s].y = fma(a.amh2, mxy.y + 0.0, c[s].y);
+      double2 cn;
+      cn.x = fma(a.amh2, mxy.x + 0.0, c[s].x);
+      cn.y = fma(a.amh2, mxy.y + 0.0, c[s].y);
+      if (a.gq != 0.0) {
+        cn.x = fma(a.gq, c[s].x - a.cbar, cn.x);
+        cn.y = fma(a.gq, c[s].y - a.cbar, cn.y);
+      }
+      c[s] = cn;
     }
     if (k + 1 < K) {
 #pragma unroll
@@ -474,7 +484,9 @@ __global__ __launch_bounds__(256) void ch_fd_update_kernel(const FdArgs a, const
     const double mxy = fma(-4.0, m, sx + sy);
     const double mz = fma(-2.0, m, mm[(int64_t)y * a.nx + x] + mp[(int64_t)y * a.nx + x]);
     const int64_t g = (int64_t)(a.zlo + zr + a.ghost) * plane + (int64_t)y * a.nx + x;
-    a.cout[g] = fma(a.amh2, mxy + mz, a.cin[g]);
+    double cn = fma(a.amh2, mxy + mz, a.cin[g]);
+    if (a.gq != 0.0) cn = fma(a.gq, a.cin[g] - a.cbar, cn);
+    a.cout[g] = cn;
   }
 }
 

@@ -91,6 +91,9 @@ struct pf_handle {
   bool chat_valid = false; // slab spectral: resident spectrum consistent with c[cur]
   int d_op = 0, d_phase = 0;
   double d_dt = 0.0;
+  bool elim = false;       // PF_FLAG_BM6_ELIMINATE_PHI
+  double cbar = 0.0;       // lattice mean of c (conserved); valid when cbar_valid
+  bool cbar_valid = false;
   double* phi = nullptr;   // BM6: phi on the lattice, consistent with c[cur] when phi_valid
   bool phi_valid = false;
   hipStream_t stream = nullptr;
@@ -116,6 +119,7 @@ void swap_buffers(pf_handle* h) {
 }
 // c changed behind the schemes' backs (set_field / set_ic / rollback)
 void invalidate_derived(pf_handle* h) {
+  h->cbar_valid = false;
   h->have_prev = false;
   h->phi_valid = false;
   h->chat_valid = false;
@@ -142,7 +146,7 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   FdArgs a;
   a.cin = h->c[h->cur];
   a.cout = h->c[1 - h->cur];
-  a.phi = h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr;
+  a.phi = (h->cfg.model == PF_MODEL_BM6 && !h->elim) ? h->phi : nullptr;
   a.nx = h->g.nx;
   a.ny = h->g.ny;
   a.nz = h->g.nz;
@@ -156,7 +160,9 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   a.two_rho = 2.0 * c.rho_s;
   a.kh2 = c.kappa / (c.h * c.h);
   a.amh2 = dt * c.M / (c.h * c.h);
-  a.kphi = h->cfg.model == PF_MODEL_BM6 ? c.k : 0.0;
+  a.kphi = (h->cfg.model == PF_MODEL_BM6 && !h->elim) ? c.k : 0.0;
+  a.gq = h->elim ? -(dt * c.M) * (c.k * c.k / c.eps_r) : 0.0;
+  a.cbar = h->cbar;
   return a;
 }
 
@@ -217,6 +223,18 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 =
     return PF_OK;
   }
   if (zhi <= zlo) return PF_OK;
+  if (h->elim && !h->cbar_valid) {
+    if (h->g.ghost != 0)
+      return fail(h, PF_ERR_STATE, "PF_FLAG_BM6_ELIMINATE_PHI in slab mode: call pf_set_mean_c with the global mean first");
+    // single rank: mean c from the diagnostics reduction (once per state; the mean is conserved by the scheme)
+    const pf_config& cc = h->cfg;
+    PF_HIP(h, launch_diag(h->c[h->cur], nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, cc.rho_s,
+                          cc.c_alpha, cc.c_beta, h->partials, h->out6_dev, h->stream));
+    PF_HIP(h, hipMemcpyAsync(h->out6_host, h->out6_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    h->cbar = h->out6_host[0] / (double)(h->g.plane * (int64_t)h->g.nz);
+    h->cbar_valid = true;
+  }
   FdArgs a = make_args(h, dt, zlo, zhi);
   int impl = h->cfg.kernel;
   if (impl == PF_KERNEL_AUTO) impl = ch_fd_fused_supported(a) ? PF_KERNEL_FUSED : PF_KERNEL_TWOPASS;
@@ -240,7 +258,7 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 =
     e = &h->ev[h->ev_used++];
     PF_HIP(h, hipEventRecord(e->first, h->stream));
   }
-  {
+  if (!h->elim) {
     int prc = ensure_phi(h);
     if (prc) return prc;
   }
@@ -385,6 +403,9 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                         (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
   if (slab_fft && slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks) < 0)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "slab FFT modes need ny and nz divisible by nranks");
+  if ((cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI) &&
+      (cfg->model != PF_MODEL_BM6 || cfg->bc != PF_BC_PERIODIC || cfg->scheme != PF_SCHEME_FD_EXPLICIT))
+    return fail(nullptr, PF_ERR_INVALID, "PF_FLAG_BM6_ELIMINATE_PHI: BM6, periodic box, FD scheme only");
   if ((cfg->ext_a2a[0] == nullptr) != (cfg->ext_a2a[1] == nullptr))
     return fail(nullptr, PF_ERR_INVALID, "ext_a2a: give both buffers or none");
   if (cfg->model == PF_MODEL_BM6 && cfg->scheme == PF_SCHEME_SPECTRAL_SI)
@@ -397,6 +418,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   if (!h) return fail(nullptr, PF_ERR_NOMEM, "out of host memory");
   h->cfg = *cfg;
   h->g = g;
+  h->elim = (cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI) != 0;
   auto bail = [&](int code) {
     g_create_error = h->err;
     pf_destroy(h);
@@ -645,6 +667,14 @@ int pf_rollback(pf_handle* h) {
   return PF_OK;
 }
 
+int pf_set_mean_c(pf_handle* h, double mean_c) {
+  if (!h) return PF_ERR_INVALID;
+  if (!h->elim) return fail(h, PF_ERR_STATE, "pf_set_mean_c: PF_FLAG_BM6_ELIMINATE_PHI is not set");
+  h->cbar = mean_c;
+  h->cbar_valid = true;
+  return PF_OK;
+}
+
 int pf_sync(pf_handle* h) {
   if (!h) return PF_ERR_INVALID;
   PF_HIP(h, hipStreamSynchronize(h->stream));
@@ -674,7 +704,8 @@ int pf_step_begin(pf_handle* h, double dt) {
   if (!h) return PF_ERR_INVALID;
   if (!(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step_begin: need dt > 0");
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_begin: not in slab mode");
-  if (h->sf) return fail(h, PF_ERR_STATE, "pf_step_begin: this mode steps through pf_dist_begin / pf_dist_advance");
+  if (h->sf && !h->elim)
+    return fail(h, PF_ERR_STATE, "pf_step_begin: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
   const int g = h->g.ghost, nz = h->g.nz;
   int rc = launch_step(h, dt, g, nz - g);  // interior planes need owned data only
@@ -916,6 +947,8 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
   a.kh2 = p->kappa_over_h2;
   a.amh2 = p->dtM_over_h2;
   a.kphi = p->k_phi;
+  a.gq = p->gq;
+  a.cbar = p->cbar;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (impl == PF_KERNEL_AUTO) impl = ch_fd_fused_supported(a) ? PF_KERNEL_FUSED : PF_KERNEL_TWOPASS;
   if (impl == PF_KERNEL_FUSED) {

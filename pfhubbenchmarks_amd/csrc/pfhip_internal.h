@@ -21,6 +21,7 @@ struct FdArgs {
   int zlo, zhi;       // output plane range [zlo, zhi)
   int zlo2, zhi2;     // optional second output range of the same launch (fused kernel only; empty if zhi2 <= zlo2)
   double ca, cb, two_rho, kh2, amh2, kphi;
+  double gq, cbar;    // BM6 with phi eliminated: cnew += gq (c - cbar); gq == 0: off
 };
 
 // launchers (return hipError_t of the launch); all asynchronous on `stream`

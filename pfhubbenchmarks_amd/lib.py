@@ -15,6 +15,7 @@ PF_SCHEME_FD_EXPLICIT, PF_SCHEME_SPECTRAL_SI, PF_SCHEME_FEM_BE = 0, 1, 2
 PF_MODEL_BM1, PF_MODEL_BM6 = 1, 6
 PF_FIELD_C, PF_FIELD_MU, PF_FIELD_PHI = 0, 1, 2
 PF_KERNEL_AUTO, PF_KERNEL_FUSED, PF_KERNEL_TWOPASS = 0, 1, 2
+PF_FLAG_BM6_ELIMINATE_PHI = 1
 
 
 class PfConfig(C.Structure):
@@ -26,6 +27,7 @@ class PfConfig(C.Structure):
         ("rho_s", C.c_double), ("c_alpha", C.c_double), ("c_beta", C.c_double), ("kappa", C.c_double),
         ("M", C.c_double), ("k", C.c_double), ("eps_r", C.c_double),
         ("stream", C.c_void_p), ("ext_c", C.c_void_p * 2), ("ext_a2a", C.c_void_p * 2), ("ext_phi", C.c_void_p),
+        ("flags", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -54,7 +56,8 @@ class PfDistRequest(C.Structure):
 
 class PfkChParams(C.Structure):
     _fields_ = [("c_alpha", C.c_double), ("c_beta", C.c_double), ("two_rho", C.c_double),
-                ("kappa_over_h2", C.c_double), ("dtM_over_h2", C.c_double), ("k_phi", C.c_double)]
+                ("kappa_over_h2", C.c_double), ("dtM_over_h2", C.c_double), ("k_phi", C.c_double),
+                ("gq", C.c_double), ("cbar", C.c_double)]
 
 
 # every symbol include/pfhip.h declares: name -> (restype, argtypes)
@@ -79,6 +82,7 @@ SYMBOLS = {
     "pf_get_field": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t]),
     "pf_step": (C.c_int, [_H, C.c_double, C.c_int, C.POINTER(PfStepInfo)]),
     "pf_rollback": (C.c_int, [_H]),
+    "pf_set_mean_c": (C.c_int, [_H, C.c_double]),
     "pf_sync": (C.c_int, [_H]),
     "pf_halo_layout_get": (C.c_int, [_H, C.POINTER(PfHaloLayout)]),
     "pf_step_begin": (C.c_int, [_H, C.c_double]),

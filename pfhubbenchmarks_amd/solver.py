@@ -30,7 +30,7 @@ class PhaseFieldSolver:
     """Single-GPU solver handle (pf_create .. pf_destroy)."""
 
     def __init__(self, dim=2, n=512, h=1.0, bc="periodic", scheme="fd", model="bm1", kernel="auto", device=0,
-                 stream=None, **params):
+                 stream=None, eliminate_phi=False, **params):
         self._lib = _lib.load()
         n3 = list(n) if isinstance(n, (tuple, list)) else [n] * dim
         cfg = _lib.default_config(dim, int(n3[0]), float(h))
@@ -43,6 +43,8 @@ class PhaseFieldSolver:
         cfg.kernel = {"auto": _lib.PF_KERNEL_AUTO, "fused": _lib.PF_KERNEL_FUSED,
                       "twopass": _lib.PF_KERNEL_TWOPASS}[kernel]
         cfg.device = int(device)
+        if eliminate_phi:
+            cfg.flags |= _lib.PF_FLAG_BM6_ELIMINATE_PHI
         for k, v in params.items():
             if not hasattr(cfg, k):
                 raise TypeError("unknown model parameter %r" % k)
@@ -336,9 +338,10 @@ class HipFFTSlabEngine(HipSlabEngine):
     (model="bm6": Poisson solve by slab FFT + coupled FD step).  Adds the two all-to-all buffers (and the ghosted phi
     buffer for BM6) as torch tensors so that torch.distributed can run the exchanges the library asks for."""
 
-    def __init__(self, n, h, nranks, rank, device, scheme="fd", model="bm1", **params):
+    def __init__(self, n, h, nranks, rank, device, scheme="fd", model="bm1", eliminate_phi=False, **params):
         import torch
         self.torch = torch
+        self.eliminate_phi = bool(eliminate_phi)
         self._lib = _lib.load()
         nx, ny, nz = (n, n, n) if isinstance(n, int) else n
         cfg = _lib.default_config(3, int(nx), float(h))
@@ -347,12 +350,15 @@ class HipFFTSlabEngine(HipSlabEngine):
         cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI}[scheme]
         cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6}[model]
         cfg.force_slab = 1
+        if eliminate_phi:
+            cfg.flags |= _lib.PF_FLAG_BM6_ELIMINATE_PHI
         for k, v in params.items():
             setattr(cfg, k, float(v))
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.z0, self.nz = slab_partition(nz, nranks, rank)
         self.nx, self.ny, self.nz_global = nx, ny, nz
+        self.h = float(h)
         mk = lambda shape: torch.zeros(shape, dtype=torch.float64, device=self.device)  # noqa: E731
         self.buffers = [mk((self.nz + 2 * self.ghost, ny, nx)) for _ in range(2)]
         self.stream = torch.cuda.Stream(device=self.device)
@@ -379,6 +385,9 @@ class HipFFTSlabEngine(HipSlabEngine):
     def set_ic_bm6(self, c0=0.5, c1=0.04):
         self._ck(self._lib.pf_set_ic_bm6(self._h, c0, c1))
 
+    def set_mean_c(self, mean_c):
+        self._ck(self._lib.pf_set_mean_c(self._h, float(mean_c)))
+
     def dist_begin(self, op, dt=0.0):
         self._ck(self._lib.pf_dist_begin(self._h, int(op), float(dt)))
 
@@ -393,7 +402,7 @@ class HipFFTSlabEngine(HipSlabEngine):
         return ("halo", [self.tensors[req.halo_base[i]] for i in range(req.n_halo)])
 
 
-class FFTSlabSolver:
+class FFTSlabSolver(SlabSolver):
     """Drives the library's distributed state machine (pf_dist_begin / pf_dist_advance): the library runs its kernels up
     to the next exchange, this class performs the exchange it asks for over torch.distributed -- one all-to-all
     transpose each way per 3-D transform (RCCL: all 7 xGMI links of a GPU carry one peer's block each), and the
@@ -402,11 +411,8 @@ class FFTSlabSolver:
     OP_STEP, OP_REFRESH = _lib.PF_DIST_OP_STEP, _lib.PF_DIST_OP_REFRESH
 
     def __init__(self, engine, group=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.engine = engine
-        self.group = group
-        self.t = 0.0
+        super().__init__(engine, group)
+        self._mean_set = False
 
     def _halo(self, buf):
         dist, e = self.dist, self.engine
@@ -433,18 +439,28 @@ class FFTSlabSolver:
                         self._halo(buf)
 
     def step(self, dt, nsteps=1):
+        e = self.engine
+        if getattr(e, "eliminate_phi", False):
+            # BM6 with phi eliminated: the time step is the plain FD slab step (overlapped ghost exchange, no transform);
+            # the library only needs the conserved global mean of c once
+            if not self._mean_set:
+                _, ctot, _ = self.diagnostics()
+                e.set_mean_c(ctot / (e.h ** 3 * e.nx * e.ny * e.nz_global))
+                self._mean_set = True
+            SlabSolver.step(self, dt, nsteps)
+            return
         for _ in range(nsteps):
             self._run(self.OP_STEP, dt)
             self.t += dt
+        self.ghosts_fresh = False
 
     def diagnostics(self):
         import torch
         self._run(self.OP_REFRESH)
+        self.ghosts_fresh = False       # conservative: the next overlapped step re-exchanges the ghost planes
         loc = self.engine.diag_local()
         t = torch.tensor(loc, dtype=torch.float64, device=self.engine.buffers[0].device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         v = t.cpu().tolist()
         return v[0], v[1], v[2]
 
-    def gather_field(self):
-        return SlabSolver.gather_field(self)

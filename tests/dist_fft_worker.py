@@ -1,5 +1,5 @@
 """Worker of tests/test_dist_gloo.py (FFT slab modes): one gloo rank running FFTSlabSolver over the numpy mirror of the
-library's distributed state machine.  Usage: python tests/dist_fft_worker.py <out> <mode>   mode: spectral | bm6"""
+library's distributed state machine.  Usage: python tests/dist_fft_worker.py <out> <mode>   mode: spectral | bm6 | bm6_elim"""
 import os
 import sys
 
@@ -19,7 +19,7 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n = (16, 12, 8)
     eng = OracleFFTSlabEngine(n, 1.0, world, rank, scheme="spectral" if mode == "spectral" else "fd",
-                              model="bm6" if mode == "bm6" else "bm1")
+                              model="bm6" if mode.startswith("bm6") else "bm1", eliminate_phi=mode == "bm6_elim")
     rng = np.random.default_rng(4)
     full = 0.5 + 0.05 * rng.standard_normal((n[2], n[1], n[0]))
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])

@@ -45,11 +45,12 @@ def main():
     print("FD slab path over NCCL: ok", flush=True)
 
     # --- slab FFT modes: all_to_all_single + halo requests from the library's state machine
-    for scheme, model, dt in (("spectral", "bm1", 1e-2), ("fd", "bm6", 1e-3)):
-        eng = HipFFTSlabEngine(n, 1.0, 1, 0, 0, scheme=scheme, model=model)
+    for scheme, model, dt, elim in (("spectral", "bm1", 1e-2, False), ("fd", "bm6", 1e-3, False),
+                                    ("fd", "bm6", 1e-3, True)):
+        eng = HipFFTSlabEngine(n, 1.0, 1, 0, 0, scheme=scheme, model=model, eliminate_phi=elim)
         eng.set_local(full)
         s = FFTSlabSolver(eng)
-        with PhaseFieldSolver(dim=3, n=n, h=1.0, scheme=scheme, model=model) as ref:
+        with PhaseFieldSolver(dim=3, n=n, h=1.0, scheme=scheme, model=model, eliminate_phi=elim) as ref:
             ref.set_c(full)
             d0, r0 = s.diagnostics(), ref.diagnostics()
             assert abs(d0[0] - r0[0]) <= 1e-11 * abs(r0[0]), (scheme, model, d0, r0)
@@ -61,7 +62,7 @@ def main():
             d1, r1 = s.diagnostics(), ref.diagnostics()
             assert abs(d1[0] - r1[0]) <= 1e-11 * abs(r1[0]) and abs(d1[1] - r1[1]) <= 1e-13 * abs(r1[1])
         eng.close()
-        print("slab FFT mode %s/%s over NCCL: ok" % (scheme, model), flush=True)
+        print("slab FFT mode %s/%s%s over NCCL: ok" % (scheme, model, " (phi eliminated)" if elim else ""), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     print("NCCL_SINGLE_RANK_OK", flush=True)

@@ -70,8 +70,11 @@ class OracleFFTSlabEngine(OracleSlabEngine):
     """CPU mirror of HipFFTSlabEngine: the same distributed state machine (pf_dist_begin / pf_dist_advance in
     csrc/pfhip_api.hip) restated with numpy FFTs, so FFTSlabSolver's collectives run under gloo without a GPU."""
 
-    def __init__(self, n, h, nranks, rank, scheme="fd", model="bm1", k=0.09, eps=90.0, kappa=2.0, M=5.0):
+    def __init__(self, n, h, nranks, rank, scheme="fd", model="bm1", k=0.09, eps=90.0, kappa=2.0, M=5.0,
+                 eliminate_phi=False):
         super().__init__(n, h, nranks, rank)
+        self.eliminate_phi = eliminate_phi
+        self.cbar = None
         self.P, self.rank = nranks, rank
         self.scheme, self.model = scheme, model
         self.k, self.eps, self.kappa, self.M = k, eps, kappa, M
@@ -84,6 +87,16 @@ class OracleFFTSlabEngine(OracleSlabEngine):
         self.phi_valid = False
         self.chat = None
         self.op = 0
+
+    def set_mean_c(self, v):
+        self.cbar = float(v)
+
+    def _launch(self, dt, zlo, zhi):          # FD slab step; with phi eliminated it carries the gq (c - cbar) term
+        if zhi <= zlo:
+            return
+        elim = (self.k, self.eps, self.cbar) if self.eliminate_phi else None
+        ch_fd.fd_step(self.buffers[self._cur].numpy(), dt, h=self.h, ghost=2, zwrap=0, zlo=zlo, zhi=zhi,
+                      out=self.buffers[1 - self._cur].numpy(), elim=elim)
 
     # complex views of the all-to-all buffers
     def _A(self):
@@ -175,7 +188,11 @@ class OracleFFTSlabEngine(OracleSlabEngine):
                 self.phase = 3
                 return ("halo", [cur, self.phi])
             self.phi_valid = True
-            if self.op == 1:
+            if self.op == 1 and self.eliminate_phi:
+                self._launch(self.dt, 0, self.nz)
+                self._cur ^= 1
+                self.phi_valid = False
+            elif self.op == 1:
                 ch_fd.fd_step(cur.numpy(), self.dt, h=h, phi=self.phi.numpy(), k_phi=self.k, ghost=2, zwrap=0,
                               out=self.buffers[1 - self._cur].numpy())
                 self._cur ^= 1
@@ -188,6 +205,10 @@ class OracleFFTSlabEngine(OracleSlabEngine):
             self._launch(self.dt, 0, self.nz)
             self._cur ^= 1
         return self._done()
+
+    def step_finish(self):
+        super().step_finish()
+        self.phi_valid = False
 
     def diag_local(self):
         cur = self.buffers[self._cur].numpy()

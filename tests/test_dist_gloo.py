@@ -45,7 +45,7 @@ def test_slab_solver_matches_single_domain(world, tmp_path, orc):
     np.testing.assert_array_equal(res["field"], c)
 
 
-@pytest.mark.parametrize("mode", ["spectral", "bm6"])
+@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim"])
 def test_fft_slab_solver_matches_single_domain(mode, tmp_path, orc):
     """the all-to-all / halo orchestration of FFTSlabSolver (world size 2, gloo) against the single-domain oracles"""
     from oracle import bm6_fd, ch_spectral
@@ -69,7 +69,7 @@ def test_fft_slab_solver_matches_single_domain(mode, tmp_path, orc):
         o.step(dt, 1)
         ref = o.c
     else:
-        o = bm6_fd.BM6FD(res["full"], 1.0)
+        o = bm6_fd.BM6FD(res["full"], 1.0, eliminate_phi=mode == "bm6_elim")
         F0, C0, _ = o.diagnostics()
         o.step(dt, 3)
         F1, C1, _ = o.diagnostics()

@@ -670,3 +670,35 @@ def test_diagnostics_fuzz(lib, orc):
         lat = orc.even_extend(c) if mirror else c
         Fo, Co, _ = orc.diagnostics(lat, h=0.7, mirror=mirror)
         assert abs(F - Fo) <= 2e-13 * abs(Fo) and abs(Ctot - Co) <= 2e-13 * abs(Co), (case, n, mirror, F, Fo)
+
+
+@pytest.mark.parametrize("shape", [(12, 20, 128), (96, 256)])
+def test_bm6_phi_elimination(lib, shape):
+    """PF_FLAG_BM6_ELIMINATE_PHI (periodic box): lap_h(k phi) = -(k^2/eps)(c - mean c) exactly, so the step needs no Poisson
+    solve.  (a) bit-exact against the oracle restating the same step when both use the same mean; (b) equal to the
+    explicit-phi path up to rounding; (c) phi / f_elec still available for diagnostics."""
+    from oracle import bm6_fd
+    rng = np.random.default_rng(sum(shape))
+    c = 0.5 + 0.04 * rng.standard_normal(shape)
+    dim, n = len(shape), shape[::-1]
+    cbar = float(np.mean(c))
+    o_elim = bm6_fd.BM6FD(c, 1.0, eliminate_phi=True, cbar=cbar)
+    o_phi = bm6_fd.BM6FD(c, 1.0)
+    with PhaseFieldSolver(dim=dim, n=n, h=1.0, model="bm6", eliminate_phi=True) as s:
+        s.set_c(c)
+        _lib_check = L.check(lib.pf_set_mean_c(s._h, C.c_double(cbar)), s._h)
+        s.step(5e-4, 9)
+        o_elim.step(5e-4, 9)
+        np.testing.assert_array_equal(s.get_c(), o_elim.c)                    # (a)
+        o_phi.step(5e-4, 9)
+        assert np.abs(s.get_c() - o_phi.c).max() <= 1e-12                    # (b)
+        F, Ctot, E = s.diagnostics()                                         # (c) Poisson solve on demand
+        Fo, Co, Eo = o_elim.diagnostics()
+        assert abs(F - Fo) <= 1e-12 * abs(Fo) and abs(E - Eo) <= 1e-10 * abs(Eo) and E != 0.0
+        assert np.abs(s.get_phi() - o_elim.phi()).max() <= 1e-12
+    with PhaseFieldSolver(dim=dim, n=n, h=1.0, model="bm6", eliminate_phi=True) as s:   # mean computed by the library
+        s.set_c(c)
+        s.step(5e-4, 9)
+        assert np.abs(s.get_c() - o_elim.c).max() <= 1e-14
+    with pytest.raises(L.PfhipError):                                         # only meaningful for the periodic box
+        PhaseFieldSolver(dim=2, n=33, h=1.0, bc="mirror", model="bm6", eliminate_phi=True)
