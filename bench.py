@@ -318,6 +318,27 @@ def main():
                      "bytes_per_cell_update": bytes_per_cell},
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
+    if rank == 0 and world == 1 and dim == 3 and scheme == "fd":
+        # the same 8 B read + 8 B write per cell as a plain device copy (pfk_stream_copy): what the memory system
+        # delivers for this traffic pattern, measured in the same process (SURVEY 8d "confirm with a device memcpy")
+        import ctypes as C
+        src = torch.ones(local_cells, dtype=torch.float64, device="cuda")
+        dst = torch.empty_like(src)
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(23):
+            if it == 3:
+                e0.record(st)
+            L.check(lib.pfk_stream_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), local_cells,
+                                        C.c_void_p(st.cuda_stream)))
+        e1.record(st)
+        torch.cuda.synchronize()
+        copy_gbs = 16.0 * local_cells * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        assert bool((dst[:: max(1, local_cells // 1000)] == 1.0).all())
+        del src, dst
+        out["roofline"]["device_copy"] = {"achieved": copy_gbs, "unit": "GB/s", "frac_of_peak": copy_gbs / HBM_PEAK_GBS,
+                                          "kernel": "pfk_stream_copy, %d doubles, 20 launches" % local_cells}
+        out["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
     if model == "bm6":
         pass          # no CPU leg for the BM6 box (the BM6 oracle is a test checker, minutes per step at this size)
     elif rank == 0 and world == 1 and not a.no_cpu_baseline and scheme == "spectral":

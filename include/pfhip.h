@@ -78,7 +78,10 @@ typedef struct pf_config {
   int32_t model;        /* PF_MODEL_* */
   int32_t kernel;       /* PF_KERNEL_* (FD scheme only) */
   int32_t device;       /* HIP device ordinal */
-  int32_t nranks;       /* slab decomposition along the slowest axis (z in 3-D, y in 2-D); 1 = whole domain */
+  int32_t nranks;       /* slab decomposition along z (3-D only; 2-D problems run as replicas); 1 = whole domain.
+                           PERIODIC: a ring of slabs.  MIRROR (FD scheme, BM1): a LINE of slabs over the n[2] physical
+                           planes -- x and y stay even-extended, z is not: the first / last rank own the walls and
+                           mirror their own planes into the outer ghost layers (>= 3 planes per rank). */
   int32_t rank;
   int32_t force_slab;   /* 1: use the ghost-plane (slab) code path even with nranks == 1 -- the rank is then its own ring
                            neighbour; lets a single GPU exercise the exact multi-GPU path (tests) */
@@ -120,7 +123,8 @@ typedef struct pf_halo_layout {
   int32_t n_local;         /* owned planes */
   int64_t send_lo_off, send_hi_off; /* first / last `ghost` owned planes */
   int64_t recv_lo_off, recv_hi_off; /* ghost planes below / above */
-  int32_t rank_lo, rank_hi;         /* neighbour ranks (periodic ring) */
+  int32_t rank_lo, rank_hi;         /* neighbour ranks: a ring (periodic bc) or a line (mirror bc: -1 = wall, the
+                                       library mirrors the owned planes into those ghost layers itself) */
   int32_t cur_index;                /* which of the two c buffers (cfg.ext_c[cur_index]) is current */
   int32_t reserved0;
 } pf_halo_layout;
@@ -229,8 +233,15 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
 
 /* tuning hooks for benchmarks: key 0 = fused-kernel variant (table in csrc/ch_fd_kernels.hip);
  * key 1 = target number of workgroups for the z-chunk split; key 2 = minimum planes per z-chunk;
- * key 3 = largest number of 2-D time steps fused into one launch (1, 2 or 4) */
+ * key 3 = largest number of 2-D time steps fused into one launch (1, 2 or 4); key 4 = 10 K + rows per wave of the 2-D
+ * K-step kernel; keys 5 / 6 = workgroups per CU / kernel form of pfk_stream_copy */
 int pfk_set_tuning(int key, int value);
+
+/* Device copy dst[i] = src[i], n doubles, 16-byte accesses: the measured HBM ceiling for a 1-read + 1-write stream
+ * (8 B + 8 B per element -- the algorithmic traffic of the fused CH step).  bench.py times it beside the stencil so
+ * roofline.frac (against the 8 TB/s datasheet peak, SURVEY 8d: "confirm with a device memcpy/triad on the box") can
+ * also be read against what the memory system delivers.  n must be even, pointers 16-byte aligned. */
+int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,13 @@ __device__ __forceinline__ int wrapi(int i, int n) {
   return i < 0 ? i + n : i;
 }
 
+// zends: bit 0 / bit 1 = local plane 0 / nz-1 is a no-flux wall of a z-line decomposition (mirror bc without the even
+// extension along z): trapezoid weight 1/2 for the wall planes, and no forward z-difference out of the top wall.
+// zends == 0 leaves every product a multiplication by 1.0, i.e. the sums are bitwise those of the unweighted form.
+__device__ __forceinline__ double zweight(int z, int nz, int zends) {
+  return ((z == 0 && (zends & 1)) || (z == nz - 1 && (zends & 2))) ? 0.5 : 1.0;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -59,8 +66,9 @@ __device__ __forceinline__ void block_reduce6(double v[6], double* sh /* 4 waves
 // Generic partial kernel (any nx): one thread per cell, grid-stride; neighbours through the caches.
 __global__ __launch_bounds__(DIAG_BLOCK) void diag_partial_kernel(const double* __restrict__ c,
                                                                  const double* __restrict__ phi, int nx, int ny,
-                                                                 int nz, int ghost, int zwrap, double rho, double ca,
-                                                                 double cb, double* __restrict__ partials) {
+                                                                 int nz, int ghost, int zwrap, int zends, double rho,
+                                                                 double ca, double cb,
+                                                                 double* __restrict__ partials) {
   __shared__ double sh[24];
   const int64_t plane = (int64_t)nx * ny;
   const int64_t total = plane * nz;
@@ -79,10 +87,11 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_partial_kernel(const double* 
     const double dx = p0[(int64_t)y * nx + xp] - w;
     const double dy = p0[(int64_t)yp * nx + x] - w;
     const double dz = pp[(int64_t)y * nx + x] - w;
-    v[0] += w;
-    v[1] += rho * (ab * ab);
-    v[2] += (dx * dx + dy * dy) + dz * dz;
-    if (phi) v[3] += w * phi[(int64_t)(z + ghost) * plane + (int64_t)y * nx + x];
+    const double wz = zweight(z, nz, zends), wd = (z == nz - 1 && (zends & 2)) ? 0.0 : 1.0;
+    v[0] += wz * w;
+    v[1] += wz * (rho * (ab * ab));
+    v[2] += wz * (dx * dx + dy * dy) + wd * (dz * dz);
+    if (phi) v[3] += wz * (w * phi[(int64_t)(z + ghost) * plane + (int64_t)y * nx + x]);
     v[4] = fmin(v[4], w);
     v[5] = fmax(v[5], w);
   }
@@ -98,8 +107,8 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_partial_kernel(const double* 
 constexpr int DS_ROWS = 4;  // rows per 256-thread block
 __global__ __launch_bounds__(DIAG_BLOCK) void diag_stream_kernel(const double* __restrict__ c,
                                                                 const double* __restrict__ phi, int nx, int ny, int nz,
-                                                                int ghost, int zwrap, int ntx, int nty, int zchunk,
-                                                                double rho, double ca, double cb,
+                                                                int ghost, int zwrap, int zends, int ntx, int nty,
+                                                                int zchunk, double rho, double ca, double cb,
                                                                 double* __restrict__ partials) {
   __shared__ double sh[24];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,10 +132,11 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_stream_kernel(const double* _
     double xr = __shfl_down(cur.x, 1, 64);  // lane+1's first cell
     if (lane == 63 || xc + 2 >= nx) xr = p0[ox];
     if (on) {
+      const double wz = zweight(z, nz, zends), wd = (z == nz - 1 && (zends & 2)) ? 0.0 : 1.0;
       double a = cur.x - ca, b = cb - cur.x, ab = a * b;
       double f = rho * (ab * ab);
       double dx = cur.y - cur.x, dy = up.x - cur.x, dz = nxt.x - cur.x;
-      double g = (dx * dx + dy * dy) + dz * dz;
+      double g = wz * (dx * dx + dy * dy) + wd * (dz * dz);
       a = cur.y - ca;
       b = cb - cur.y;
       ab = a * b;
@@ -134,13 +144,13 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_stream_kernel(const double* _
       dx = xr - cur.y;
       dy = up.y - cur.y;
       dz = nxt.y - cur.y;
-      g += (dx * dx + dy * dy) + dz * dz;
-      v[0] += cur.x + cur.y;
-      v[1] += f;
+      g += wz * (dx * dx + dy * dy) + wd * (dz * dz);
+      v[0] += wz * (cur.x + cur.y);
+      v[1] += wz * f;
       v[2] += g;
       if (phi) {
         const double2 ph = *reinterpret_cast<const double2*>(phi + (int64_t)(z + ghost) * plane + o0);
-        v[3] += cur.x * ph.x + cur.y * ph.y;
+        v[3] += wz * (cur.x * ph.x + cur.y * ph.y);
       }
       v[4] = fmin(v[4], fmin(cur.x, cur.y));
       v[5] = fmax(v[5], fmax(cur.x, cur.y));
@@ -183,12 +193,84 @@ __global__ __launch_bounds__(256) void ic_kernel(double* __restrict__ c, int nx,
   }
 }
 
+// z-line decomposition of a no-flux box: the ghost planes outside a wall are the mirror images of the owned planes
+// next to it (node-centred even extension: z = -k <- z = +k, z = nzg-1+k <- z = nzg-1-k, k = 1..ghost).
+__global__ __launch_bounds__(256) void reflect_ghosts_kernel(double* __restrict__ buf, int64_t plane, int nz, int ghost,
+                                                             int ends) {
+  const int k = blockIdx.y % ghost + 1, top = blockIdx.y / ghost;
+  if (!(ends & (1 << top))) return;
+  const int64_t src = top ? (int64_t)(ghost + nz - 1 - k) * plane : (int64_t)(ghost + k) * plane;
+  const int64_t dst = top ? (int64_t)(ghost + nz - 1 + k) * plane : (int64_t)(ghost - k) * plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (int64_t)gridDim.x * 256)
+    buf[dst + i] = buf[src + i];
+}
+
+// plain device copy, 16 B per lane per access: the 1R + 1W HBM ceiling (pfk_stream_copy).
+// CHUNKED = false: grid-stride (consecutive workgroups touch consecutive 4 KB); true: every workgroup owns one
+// contiguous span.  U = independent 16-byte loads in flight per lane.
+template <bool CHUNKED, int U>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst,
+                                                          int64_t n2) {
+  int64_t i, end, stride;
+  if (CHUNKED) {
+    const int64_t per = ((n2 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    i = (int64_t)blockIdx.x * per + threadIdx.x;
+    end = min(n2, (int64_t)(blockIdx.x + 1) * per);
+    stride = 256;
+  } else {
+    i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    end = n2;
+    stride = (int64_t)gridDim.x * 256;
+  }
+  for (; i + (U - 1) * stride < end; i += U * stride) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+  }
+  for (; i < end; i += stride) dst[i] = src[i];
+}
+
+int g_copy_wgs_per_cu = 16, g_copy_mode = 3;  // best stable form of tools/copy_sweep.py (profiles/r01/copy_sweep.txt)
+
 }  // namespace
+
+void set_copy_tuning(int wgs_per_cu, int mode) {
+  if (wgs_per_cu > 0) g_copy_wgs_per_cu = wgs_per_cu;
+  if (mode >= 0) g_copy_mode = mode;
+}
+
+hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t stream) {
+  const int64_t n2 = n / 2;
+  int64_t nb = (n2 + 255) / 256;
+  if (nb > 256 * (int64_t)g_copy_wgs_per_cu) nb = 256 * (int64_t)g_copy_wgs_per_cu;
+  if (nb < 1) nb = 1;
+  auto s2 = reinterpret_cast<const double2*>(src);
+  auto d2 = reinterpret_cast<double2*>(dst);
+  switch (g_copy_mode) {
+    case 1: hipLaunchKernelGGL((stream_copy_kernel<true, 4>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2); break;
+    case 2: hipLaunchKernelGGL((stream_copy_kernel<false, 8>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2); break;
+    case 3: hipLaunchKernelGGL((stream_copy_kernel<true, 8>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2); break;
+    case 4: hipLaunchKernelGGL((stream_copy_kernel<false, 1>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2); break;
+    default: hipLaunchKernelGGL((stream_copy_kernel<false, 4>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, int ends, hipStream_t stream) {
+  if (!ends) return hipSuccess;
+  int64_t nb = (plane + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(reflect_ghosts_kernel, dim3((int)nb, 2 * ghost), dim3(256), 0, stream, buf, plane, nz, ghost,
+                     ends);
+  return hipGetLastError();
+}
 
 int diag_partials_elems() { return DIAG_MAX_BLOCKS * 6; }
 
-hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, double rho,
-                       double ca, double cb, double* partials, double* out6, hipStream_t stream) {
+hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, int zends,
+                       double rho, double ca, double cb, double* partials, double* out6, hipStream_t stream) {
   const int64_t total = (int64_t)nx * ny * nz;
   int64_t nb;
   const bool aligned = (nx % 2 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) &&
@@ -205,7 +287,7 @@ hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int n
     nb = xy * nchunk;
     if (nb <= DIAG_MAX_BLOCKS) {
       hipLaunchKernelGGL(diag_stream_kernel, dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, c, phi, nx, ny, nz, ghost,
-                         zwrap, ntx, nty, zchunk, rho, ca, cb, partials);
+                         zwrap, zends, ntx, nty, zchunk, rho, ca, cb, partials);
       hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(DIAG_BLOCK), 0, stream, (const double*)partials, (int)nb,
                          out6);
       return hipGetLastError();
@@ -215,7 +297,7 @@ hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int n
   if (nb > DIAG_MAX_BLOCKS) nb = DIAG_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(diag_partial_kernel, dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, c, phi, nx, ny, nz, ghost, zwrap,
-                     rho, ca, cb, partials);
+                     zends, rho, ca, cb, partials);
   hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(DIAG_BLOCK), 0, stream, (const double*)partials, (int)nb, out6);
   return hipGetLastError();
 }

@@ -18,6 +18,8 @@ struct Geometry {
   int nx, ny, nzg;   // computational (periodic) lattice
   int z0, nz;        // owned planes of the slab axis
   int ghost, zwrap;
+  int zline;         // mirror bc in slab mode: z is NOT extended; the slabs form a line, walls reflect locally
+  int zends;         // zline: bit 0 / bit 1 = this rank owns the bottom / top wall plane
   int64_t plane;
 };
 
@@ -45,6 +47,7 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
   g->nx = ext(0);
   g->ny = ext(1);
   g->nzg = ext(2);
+  g->zline = g->zends = 0;
   g->plane = (int64_t)g->nx * g->ny;
   if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return bad("bad nranks / rank");
   if (cfg->nranks > 1 || cfg->force_slab == 1) {
@@ -53,8 +56,12 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
       return (int)PF_ERR_UNSUPPORTED;
     }
     if (g->mirror) {
-      if (err) *err = "slab decomposition with mirror bc is not implemented";
-      return (int)PF_ERR_UNSUPPORTED;
+      // a line of slabs over the PHYSICAL planes: no even extension along z, the two wall ranks mirror their own planes
+      // into the ghost layers (launch_reflect_ghosts) instead of receiving them
+      g->nzg = g->np[2];
+      g->zline = 1;
+      if (g->nzg < 3 * cfg->nranks) return bad("mirror bc in slab mode needs >= 3 planes per rank");
+      g->zends = (cfg->rank == 0 ? 1 : 0) | (cfg->rank == cfg->nranks - 1 ? 2 : 0);
     }
     if (g->nzg < 2 * cfg->nranks) return bad("need >= 2 planes per rank");
     pf_slab_partition(g->nzg, cfg->nranks, cfg->rank, &g->z0, &g->nz);
@@ -228,7 +235,7 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 =
       return fail(h, PF_ERR_STATE, "PF_FLAG_BM6_ELIMINATE_PHI in slab mode: call pf_set_mean_c with the global mean first");
     // single rank: mean c from the diagnostics reduction (once per state; the mean is conserved by the scheme)
     const pf_config& cc = h->cfg;
-    PF_HIP(h, launch_diag(h->c[h->cur], nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, cc.rho_s,
+    PF_HIP(h, launch_diag(h->c[h->cur], nullptr, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, 0, cc.rho_s,
                           cc.c_alpha, cc.c_beta, h->partials, h->out6_dev, h->stream));
     PF_HIP(h, hipMemcpyAsync(h->out6_host, h->out6_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
@@ -284,8 +291,9 @@ int run_diag(pf_handle* h, double raw[6]) {
   if (h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI && !h->chat_valid)
     return fail(h, PF_ERR_STATE, "slab spectral: run pf_dist_begin(PF_DIST_OP_REFRESH) before diagnostics");
   const double* phi = h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr;
-  PF_HIP(h, launch_diag(h->c[h->cur], phi, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, c.rho_s, c.c_alpha,
-                        c.c_beta, h->partials, h->out6_dev, h->stream));
+  PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], h->g.plane, h->g.nz, h->g.ghost, h->g.zends, h->stream));
+  PF_HIP(h, launch_diag(h->c[h->cur], phi, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, h->g.zends, c.rho_s,
+                        c.c_alpha, c.c_beta, h->partials, h->out6_dev, h->stream));
   const bool sf_spec = h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI;
   if (h->sp) {
     // spectral scheme: |grad c|^2 summed in k-space (Parseval) instead of forward differences
@@ -310,8 +318,8 @@ void scale_diag(const pf_handle* h, const double raw[6], double out[3]) {
   const pf_config& c = h->cfg;
   double vol = 1.0;
   for (int d = 0; d < c.dim; ++d) vol *= c.h;
-  if (h->g.mirror)
-    for (int d = 0; d < c.dim; ++d) vol *= 0.5;  // even extension counts the domain 2^dim times
+  if (h->g.mirror)  // the even extension counts the domain twice per extended axis (z is not extended in a z-line)
+    for (int d = 0; d < (h->g.zline ? 2 : c.dim); ++d) vol *= 0.5;
   const double felec = 0.5 * c.k * raw[3];
   out[0] = vol * (raw[1] + 0.5 * c.kappa / (c.h * c.h) * raw[2] + (c.model == PF_MODEL_BM6 ? felec : 0.0));
   out[1] = vol * raw[0];
@@ -381,7 +389,7 @@ int64_t pf_field_elems(const pf_config* cfg) {
   if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
   if (cfg->scheme == PF_SCHEME_FEM_BE)
     return (int64_t)g.np[0] * g.np[1] + (int64_t)(g.np[0] - 1) * (g.np[1] - 1);  // corners + centres
-  if (g.mirror) return (int64_t)g.np[0] * g.np[1] * g.np[2];
+  if (g.mirror) return (int64_t)g.np[0] * g.np[1] * (g.zline ? g.nz : g.np[2]);
   return g.plane * (int64_t)g.nz;
 }
 
@@ -401,6 +409,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                 "PF_SCHEME_FEM_BE: 2-D, PF_BC_MIRROR (natural no-flux), square mesh, one GPU");
   const bool slab_fft = (cfg->nranks > 1 || cfg->force_slab == 1) &&
                         (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
+  if (slab_fft && g.mirror)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "mirror bc in slab mode: FD scheme, BM1 only");
   if (slab_fft && slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks) < 0)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "slab FFT modes need ny and nz divisible by nranks");
   if ((cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI) &&
@@ -546,12 +556,12 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
     PF_HIP(h, hipMemcpyAsync(dst, host, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
   } else {
-    if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+    if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * (g.zline ? g.nz : g.np[2]))
       return fail(h, PF_ERR_INVALID, "pf_set_field: wrong element count (mirror: nodes of the physical domain)");
     std::vector<double> ext((size_t)(g.plane * g.nz));
     auto refl = [](int i, int np) { return i < np ? i : 2 * (np - 1) - i; };
     for (int z = 0; z < g.nz; ++z) {
-      const int zs = h->cfg.dim == 3 ? refl(z, g.np[2]) : 0;
+      const int zs = h->cfg.dim == 3 ? (g.zline ? z : refl(z, g.np[2])) : 0;
       for (int y = 0; y < g.ny; ++y) {
         const int ys = refl(y, g.np[1]);
         const double* src = host + ((int64_t)zs * g.np[1] + ys) * g.np[0];
@@ -588,12 +598,13 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
     PF_HIP(h, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
   } else {
-    if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+    const int npz = g.zline ? g.nz : g.np[2];
+    if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * npz)
       return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count (mirror: nodes of the physical domain)");
     std::vector<double> ext((size_t)(g.plane * g.nz));
     PF_HIP(h, hipMemcpyAsync(ext.data(), src, sizeof(double) * ext.size(), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
-    for (int z = 0; z < g.np[2]; ++z)
+    for (int z = 0; z < npz; ++z)
       for (int y = 0; y < g.np[1]; ++y)
         std::memcpy(host + ((int64_t)z * g.np[1] + y) * g.np[0], ext.data() + ((int64_t)z * g.ny + y) * g.nx,
                     sizeof(double) * g.np[0]);
@@ -693,8 +704,8 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out) {
   out->send_lo_off = (int64_t)g.ghost * g.plane;
   out->send_hi_off = (int64_t)g.nz * g.plane;  // planes nz-ghost .. nz-1 live at buffer planes nz .. nz+ghost-1
   out->recv_hi_off = (int64_t)(g.nz + g.ghost) * g.plane;
-  out->rank_lo = (h->cfg.rank + h->cfg.nranks - 1) % h->cfg.nranks;
-  out->rank_hi = (h->cfg.rank + 1) % h->cfg.nranks;
+  out->rank_lo = (g.zends & 1) ? -1 : (h->cfg.rank + h->cfg.nranks - 1) % h->cfg.nranks;  // -1: wall, no neighbour
+  out->rank_hi = (g.zends & 2) ? -1 : (h->cfg.rank + 1) % h->cfg.nranks;
   out->cur_index = h->cur;
   out->reserved0 = 0;
   return PF_OK;
@@ -708,6 +719,7 @@ int pf_step_begin(pf_handle* h, double dt) {
     return fail(h, PF_ERR_STATE, "pf_step_begin: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
   const int g = h->g.ghost, nz = h->g.nz;
+  PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], h->g.plane, nz, g, h->g.zends, h->stream));  // walls (z-line only)
   int rc = launch_step(h, dt, g, nz - g);  // interior planes need owned data only
   if (rc) return rc;
   h->step_open = true;
@@ -857,6 +869,7 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
   }
   // ---- plain FD slab (BM1): ghost refresh [+ a non-overlapped step; pf_step_begin/finish is the overlapped form]
   if (h->d_phase == 0) {
+    PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], g.plane, g.nz, g.ghost, g.zends, h->stream));
     h->d_phase = 1;
     req->kind = PF_DIST_HALO;
     req->n_halo = 1;
@@ -970,6 +983,14 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
   return PF_OK;
 }
 
+int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream) {
+  if (!src || !dst || n < 2 || (n & 1) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
+    return fail(nullptr, PF_ERR_INVALID, "pfk_stream_copy: need even n >= 2 and 16-byte aligned device pointers");
+  hipError_t e = launch_stream_copy(src, dst, n, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_stream_copy: ") + hipGetErrorString(e));
+  return PF_OK;
+}
+
 int pfk_set_tuning(int key, int value) {
   if (key == 0) {
     set_fused_variant(value);
@@ -989,6 +1010,14 @@ int pfk_set_tuning(int key, int value) {
   }
   if (key == 4 && value >= 11 && value <= 46) {  // value = 10 * K + rows-per-wave
     set_2d_rows(value / 10, value % 10);
+    return PF_OK;
+  }
+  if (key == 5 && value > 0) {  // pfk_stream_copy: workgroups per CU
+    set_copy_tuning(value, -1);
+    return PF_OK;
+  }
+  if (key == 6 && value >= 0 && value <= 4) {  // pfk_stream_copy: kernel form (table in csrc/diag_kernels.hip)
+    set_copy_tuning(0, value);
     return PF_OK;
   }
   return PF_ERR_INVALID;

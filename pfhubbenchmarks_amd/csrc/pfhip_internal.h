@@ -37,8 +37,13 @@ void set_2d_rows(int k, int rows);
 // diagnostics: raw sums {sum c, sum f_chem, sum |fwd diff|^2, sum c*phi, min c, max c} -> out6 (device, 6 doubles)
 // partials: device scratch of diag_partials_elems() doubles
 int diag_partials_elems();
-hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, double rho,
-                       double ca, double cb, double* partials, double* out6, hipStream_t stream);
+// zends: bit 0 / bit 1 = local plane 0 / nz-1 is a no-flux wall of a z-line decomposition (trapezoid weights)
+hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, int zends,
+                       double rho, double ca, double cb, double* partials, double* out6, hipStream_t stream);
+// fill the ghost planes outside a no-flux wall with mirror images of the owned planes (ends: same bits as zends)
+void set_copy_tuning(int wgs_per_cu, int mode);  // <= 0 / < 0: keep
+hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t stream);
+hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, int ends, hipStream_t stream);
 
 // initial condition (pfbase.py:187-189 / :332-334), z-extruded; writes owned planes [0, nz) of a ghosted buffer
 // mnx, mny > 0: lattice is the even extension of a no-flux domain with mnx x mny nodes (index reflection)

@@ -94,6 +94,7 @@ SYMBOLS = {
     "pfk_ch_fd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.POINTER(PfkChParams), C.c_int, C.c_void_p]),
     "pfk_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "pfk_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 _lib = None

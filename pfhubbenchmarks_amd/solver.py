@@ -164,11 +164,16 @@ def slab_partition(n_planes, nranks, rank):
 class HipSlabEngine:
     """One rank's slab on one GPU.  Field storage is two torch CUDA tensors (nz_local + 4, ny, nx) handed to
     libpfhip as raw device pointers (pf_config.ext_c), so torch.distributed can send / receive the ghost planes
-    in place.  Kernels run on `self.stream` (a torch stream)."""
+    in place.  Kernels run on `self.stream` (a torch stream).
+
+    bc="periodic": the slabs form a ring.  bc="mirror" (the reference's natural no-flux condition, bench1.py:69;
+    b13d.py in 3-D): n = nodes of the physical box, the slabs form a line over its nz planes, rank_lo / rank_hi are
+    -1 at the walls and the library mirrors the owned planes into those ghost layers; x and y run on the even
+    extension, so a buffer plane is 2(ny-1) x 2(nx-1) while set_local / get_local speak physical nodes."""
 
     ghost = 2
 
-    def __init__(self, n, h, nranks, rank, device, **params):
+    def __init__(self, n, h, nranks, rank, device, bc="periodic", **params):
         import torch
         self.torch = torch
         self._lib = _lib.load()
@@ -177,15 +182,20 @@ class HipSlabEngine:
         cfg.n[0], cfg.n[1], cfg.n[2] = int(nx), int(ny), int(nz)
         cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
         cfg.force_slab = 1          # nranks == 1: the rank is its own ring neighbour (single-GPU tests of this path)
+        cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
         for k, v in params.items():
             setattr(cfg, k, float(v))
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
+        self.bc = bc
         self.z0, self.nz = slab_partition(nz, nranks, rank)
-        self.nx, self.ny, self.nz_global = nx, ny, nz
+        self.nx, self.ny, self.nz_global = nx, ny, nz            # what set_local / get_local speak
+        lx, ly = (2 * (nx - 1), 2 * (ny - 1)) if bc == "mirror" else (nx, ny)
         elems = int(self._lib.pf_field_elems_with_ghosts(C.byref(cfg)))
-        assert elems == (self.nz + 2 * self.ghost) * ny * nx
-        self.buffers = [torch.zeros((self.nz + 2 * self.ghost, ny, nx), dtype=torch.float64, device=self.device)
+        if elems < 0:
+            raise ValueError("invalid slab configuration (mirror bc needs >= 3 planes per rank, periodic >= 2)")
+        assert elems == (self.nz + 2 * self.ghost) * ly * lx
+        self.buffers = [torch.zeros((self.nz + 2 * self.ghost, ly, lx), dtype=torch.float64, device=self.device)
                         for _ in range(2)]
         self.stream = torch.cuda.Stream(device=self.device)
         cfg.stream = C.c_void_p(self.stream.cuda_stream)
@@ -194,8 +204,9 @@ class HipSlabEngine:
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
-        self.rank_lo = (rank - 1) % nranks
-        self.rank_hi = (rank + 1) % nranks
+        lay = _lib.PfHaloLayout()
+        self._ck(self._lib.pf_halo_layout_get(self._h, C.byref(lay)))
+        self.rank_lo, self.rank_hi = lay.rank_lo, lay.rank_hi   # -1 = wall (mirror bc): nothing to exchange there
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -279,12 +290,14 @@ class SlabSolver:
         buf = e.buffers[e.cur]
         send_lo, send_hi = buf[g:2 * g], buf[nz:nz + g]
         recv_lo, recv_hi = buf[0:g], buf[nz + g:nz + 2 * g]
-        # order matters when both neighbours are the same rank (world size 2): "up" message first on both sides
-        ops = [dist.P2POp(dist.isend, send_hi, e.rank_hi, self.group, 1),
-               dist.P2POp(dist.isend, send_lo, e.rank_lo, self.group, 2),
-               dist.P2POp(dist.irecv, recv_lo, e.rank_lo, self.group, 1),
-               dist.P2POp(dist.irecv, recv_hi, e.rank_hi, self.group, 2)]
-        return dist.batch_isend_irecv(ops)
+        # order matters when both neighbours are the same rank (world size 2): "up" message first on both sides;
+        # a neighbour of -1 is a wall of the mirror-bc line (the library fills those ghosts by reflection)
+        ops = [dist.P2POp(dist.isend, send_hi, e.rank_hi, self.group, 1) if e.rank_hi >= 0 else None,
+               dist.P2POp(dist.isend, send_lo, e.rank_lo, self.group, 2) if e.rank_lo >= 0 else None,
+               dist.P2POp(dist.irecv, recv_lo, e.rank_lo, self.group, 1) if e.rank_lo >= 0 else None,
+               dist.P2POp(dist.irecv, recv_hi, e.rank_hi, self.group, 2) if e.rank_hi >= 0 else None]
+        ops = [o for o in ops if o is not None]
+        return dist.batch_isend_irecv(ops) if ops else []
 
     def exchange(self):
         """Blocking ghost refresh of the current buffer (used before diagnostics)."""

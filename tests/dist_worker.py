@@ -1,5 +1,6 @@
 """Worker of tests/test_dist_gloo.py: one rank of a world_size-N gloo job (CPU) running SlabSolver over the
-oracle-backed engine.  Usage: python tests/dist_worker.py <out_prefix> <nsteps>   (env: RANK WORLD_SIZE MASTER_*)"""
+oracle-backed engine.  Usage: python tests/dist_worker.py <out_prefix> <nsteps> [periodic|mirror]
+(env: RANK WORLD_SIZE MASTER_*)"""
 import os
 import sys
 
@@ -17,8 +18,9 @@ def main():
     out, nsteps = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n = (16, 10, 12)
-    eng = OracleSlabEngine(n, 1.0, world, rank)
+    bc = sys.argv[3] if len(sys.argv) > 3 else "periodic"
+    n = (16, 10, 12) if bc == "periodic" else (9, 6, 12)     # mirror: nodes of the no-flux box
+    eng = OracleSlabEngine(n, 1.0, world, rank, bc=bc)
     rng = np.random.default_rng(3)
     full = 0.5 + 0.1 * rng.standard_normal((n[2], n[1], n[0]))
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])

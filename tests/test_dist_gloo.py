@@ -45,6 +45,34 @@ def test_slab_solver_matches_single_domain(world, tmp_path, orc):
     np.testing.assert_array_equal(res["field"], c)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_mirror_bc_line_of_slabs_matches_even_extension(world, tmp_path, orc):
+    """PF_BC_MIRROR in slab mode ('a line with local reflection at the ends'): SlabSolver skips the wall
+    neighbours (-1), the engine mirrors its own planes; result = the whole-domain oracle on the 3-D even extension."""
+    out = str(tmp_path / "res.npz")
+    nsteps = 4
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), out,
+                                       str(nsteps), "mirror"], env=env, cwd=ROOT))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = np.load(out)
+    nz, ny, nx = res["full"].shape
+    e = orc.even_extend(res["full"])
+    F0, C0, _ = orc.diagnostics(e, h=1.0, mirror=True)
+    np.testing.assert_allclose(res["d0"][:2], [F0, C0], rtol=1e-13)
+    for _ in range(nsteps):
+        e = orc.fd_step(e, 1e-3)
+    F1, C1, _ = orc.diagnostics(e, h=1.0, mirror=True)
+    np.testing.assert_allclose(res["d1"][:2], [F1, C1], rtol=1e-13)
+    e = orc.fd_step(e, 1e-3)
+    np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
+
+
 @pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim"])
 def test_fft_slab_solver_matches_single_domain(mode, tmp_path, orc):
     """the all-to-all / halo orchestration of FFTSlabSolver (world size 2, gloo) against the single-domain oracles"""

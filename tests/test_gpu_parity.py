@@ -209,6 +209,54 @@ def test_slab_engines_with_manual_exchange_equal_single_domain(lib, orc):
         e.close()
 
 
+def test_mirror_bc_line_of_slabs_equals_even_extension(lib, orc):
+    """PF_BC_MIRROR in slab mode (b13d.py's no-flux box across GPUs): three slab handles on the one GPU in a LINE,
+    inner ghost planes copied by hand, wall ghosts mirrored by the library; the result is bit for bit the whole-domain
+    run on the 3-D even extension (single-GPU mirror handle and the oracle), diagnostics use trapezoid weights in z."""
+    n = (65, 13, 14)                                       # nodes (x, y, z): lattice planes are 128 x 24
+    rng = np.random.default_rng(29)
+    full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
+    engs = [HipSlabEngine(n, 1.0, 3, r, 0, bc="mirror") for r in range(3)]
+    assert [(e.rank_lo, e.rank_hi) for e in engs] == [(-1, 1), (0, 2), (1, -1)]
+    assert [e.nz for e in engs] == [5, 5, 4]
+    for e in engs:
+        e.set_local(full[e.z0:e.z0 + e.nz])
+
+    def exchange():
+        torch.cuda.synchronize()
+        for lo, hi in ((engs[0], engs[1]), (engs[1], engs[2])):
+            bl, bh = lo.buffers[lo.cur], hi.buffers[hi.cur]
+            bl[lo.nz + 2:lo.nz + 4].copy_(bh[2:4])         # lower slab's hi ghosts <- upper slab's bottom planes
+            bh[0:2].copy_(bl[lo.nz:lo.nz + 2])             # upper slab's lo ghosts <- lower slab's top planes
+        torch.cuda.synchronize()
+
+    ext = orc.even_extend(full)
+    with PhaseFieldSolver(dim=3, n=n, h=1.0, bc="mirror") as whole:
+        whole.set_c(full)
+        for _ in range(3):
+            exchange()
+            for e in engs:
+                e.step_begin(1e-3)
+            for e in engs:
+                e.step_finish()
+            ext = orc.fd_step(ext, 1e-3)
+        whole.step(1e-3, 3)
+        got = np.concatenate([e.get_local() for e in engs], 0)
+        np.testing.assert_array_equal(got, ext[:n[2], :n[1], :n[0]])
+        np.testing.assert_array_equal(got, whole.get_c())
+        exchange()
+        d = np.sum([e.diag_local() for e in engs], 0)
+        Fo, Co, _ = orc.diagnostics(ext, h=1.0, mirror=True)
+        Fw, Cw, _ = whole.diagnostics()
+        assert abs(d[0] - Fo) <= 1e-13 * abs(Fo) and abs(d[1] - Co) <= 1e-13 * abs(Co)
+        assert abs(d[0] - Fw) <= 1e-13 * abs(Fw) and abs(d[1] - Cw) <= 1e-13 * abs(Cw)
+    for e in engs:
+        e.close()
+    # too few planes per rank for the reflection: refused at create time, not a fault later
+    with pytest.raises(Exception):
+        HipSlabEngine((65, 13, 5), 1.0, 2, 0, 0, bc="mirror")
+
+
 def test_full_size_properties_512cubed(lib):
     """BASELINE.json config 3 (512^3): size-independent properties instead of a full CPU comparison --
     z-invariance of the extruded problem (b13d.py:55), bitwise equality with the 2-D run, mass conservation."""
