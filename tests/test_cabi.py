@@ -90,3 +90,21 @@ def test_product_path_fails_loudly_without_gpu():
     rc = lib.pf_create(C.byref(cfg), C.byref(h))
     assert rc == L.PF_ERR_HIP and not h          # no CPU fallback: the handle cannot be created
     assert lib.pf_last_error(None)
+
+
+def test_integration_md_ctypes_stub_matches_the_abi():
+    """the binding a reference maintainer is told to paste must agree with pf_config"""
+    import ctypes as C
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# pfhip_binding.py\n(.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("libpfhip.so")',
+                        'C.CDLL(%r)' % os.path.join(root, "pfhubbenchmarks_amd", "csrc", "libpfhip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    cfg = ns["PfConfig"]()
+    assert ns["lib"].pf_config_default(C.byref(cfg), 2, 201, C.c_double(1.0)) == 0
+    assert C.sizeof(cfg) == cfg.struct_bytes
+    assert (cfg.dim, cfg.n[0], cfg.n[2], cfg.kappa, cfg.M, cfg.k, cfg.eps_r) == (2, 201, 1, 2.0, 5.0, 0.09, 90.0)
