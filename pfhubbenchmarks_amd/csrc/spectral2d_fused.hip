@@ -13,6 +13,8 @@
 // forward), so diagnostics and the resident spectrum are shared with spectral.hip.
 //   c^+_k = (c_k - dt M k^2 N_k) / (1 + dt M kappa k^4),  N = f'(c)       dolfin/pfbase.py:361-383, bench1.py:63-65
 #include <cmath>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "pfhip_internal.h"
@@ -37,6 +39,17 @@ __device__ __forceinline__ int brev(int i, int lg) { return (int)(__brev((unsign
 // LDS index skew: one 16-byte pad slot every 32 elements, so the power-of-two strides of bit-reversed and butterfly
 // accesses do not pile onto one bank
 __device__ __forceinline__ int px(int j) { return j + (j >> 5); }
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  The column kernels give every XCD one
+// contiguous band of column blocks, so that the workgroups sharing a 128-byte line of G / chat / H (8 columns) meet in
+// the same L2 instead of pulling the line into up to four of them (17.9 -> 13.9 us per 512^2 step).  Bijection on
+// [0, gridDim.x) for any grid size.
+__device__ __forceinline__ int xcd_band_block() {
+  const int nb = gridDim.x, per = (nb + 7) / 8, full = nb % 8;
+  const int x = blockIdx.x % 8, r = blockIdx.x / 8;
+  if (full == 0) return x * per + r;
+  return (x < full ? x * per : full * per + (x - full) * (per - 1)) + r;  // `full` XCDs own per, the rest per - 1
+}
 
 // in-place radix-2 DIT FFT of x[0..N) (LDS, bit-reversed input -> natural output) by ONE wave; tw[k] = e^{-2 pi i k/N}.
 // SIGN = -1: forward (e^{-i...}); +1: inverse (unnormalised).  Every stage ends with a workgroup barrier (the waves of
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
   double2* TW = X + CW * NP;
   const int tid = threadIdx.x, lane = tid % CT, wave = tid / CT;  // (thread in column group, column)
   const int N = a.ny, lg = a.lgy;
-  const int kxb = blockIdx.x * CW;
+  const int kxb = xcd_band_block() * CW;
   for (int k = tid; k < N / 2; k += CT * CW) TW[k] = twy_g[k];
   for (int idx = tid; idx < N * CW; idx += CT * CW) {
     const int y = idx / CW, ci = idx % CW, kx = kxb + ci;
@@ -249,6 +262,256 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
   }
 }
 
+// =====================================================================================================================
+// 512-point fast path: ONE wave per transform, 8 points per lane, three radix-8 passes in registers (512 = 8 * 8 * 8)
+// with two wave-private LDS exchanges in between -- no bit reversal, no multi-wave barriers, 2 instead of 9 LDS round
+// trips per transform.
+//   n = l + 64 j          stage A: lane holds x[l + 64 j], j = 0..7 -> radix-8 over j -> y[l][q], times W_512^(l q)
+//   l = l0 + 8 l1         stage B: lane (q, l0) gathers l1 = 0..7 -> radix-8 -> z[q][l0][s], times W_64^(l0 s)
+//   k = q + 8 s + 64 t    stage C: lane (q, s) gathers l0 = 0..7 -> radix-8 -> X[q + 8 s + 64 t], t = 0..7
+// Physical lane p = 8 q + s ends up holding X[T(p) + 64 t] with T(p) = q + 8 s (the two octal digits of p swapped).
+// The input side accepts any lane -> l map m(p) (the twiddles W_512^(m q) come from a table row), so a second transform
+// can consume the first one's output in place with m = T: forward and inverse chain without touching LDS in between.
+// LDS layout of the exchanges: 8 blocks of 72 slots (64 + 8 pad); exchange 1 at [q*72 + l], exchange 2 at
+// [q*72 + 9*l0 + s]: both directions of both exchanges are bank-conflict free per quarter-wave of 16-byte accesses.
+constexpr int W8 = 576;  // double2 slots of LDS per wave (8 * 72)
+constexpr double RSQRT2 = 0.70710678118654752440084436210485;
+
+__device__ __forceinline__ double2 cmul2(double2 w, double2 v) {
+  return make_double2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i (SIGN < 0, forward) or +i (inverse)
+template <int SIGN>
+__device__ __forceinline__ double2 rot90(double2 a) {
+  return SIGN < 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+}
+
+// a[q] <- sum_j a[j] e^{SIGN 2 pi i j q / 8}
+template <int SIGN>
+__device__ __forceinline__ void radix8(double2 (&a)[8]) {
+  const double2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+  const double2 b1 = cadd(a[1], a[5]), d5 = csub(a[1], a[5]);
+  const double2 b2 = cadd(a[2], a[6]), d6 = csub(a[2], a[6]);
+  const double2 b3 = cadd(a[3], a[7]), d7 = csub(a[3], a[7]);
+  // odd branch inputs times W_8^j: W_8 = (1 + SIGN i) / sqrt 2, W_8^2 = SIGN i, W_8^3 = (-1 + SIGN i) / sqrt 2
+  const double2 r5 = rot90<SIGN>(d5), r7 = rot90<SIGN>(d7);
+  const double2 b5 = make_double2((d5.x + r5.x) * RSQRT2, (d5.y + r5.y) * RSQRT2);
+  const double2 b6 = rot90<SIGN>(d6);
+  const double2 b7 = make_double2((r7.x - d7.x) * RSQRT2, (r7.y - d7.y) * RSQRT2);
+  // two 4-point transforms
+  {
+    const double2 e0 = cadd(b0, b2), e1 = csub(b0, b2), e2 = cadd(b1, b3), e3 = rot90<SIGN>(csub(b1, b3));
+    a[0] = cadd(e0, e2);
+    a[4] = csub(e0, e2);
+    a[2] = cadd(e1, e3);
+    a[6] = csub(e1, e3);
+  }
+  {
+    const double2 e0 = cadd(b4, b6), e1 = csub(b4, b6), e2 = cadd(b5, b7), e3 = rot90<SIGN>(csub(b5, b7));
+    a[1] = cadd(e0, e2);
+    a[5] = csub(e0, e2);
+    a[3] = cadd(e1, e3);
+    a[7] = csub(e1, e3);
+  }
+}
+
+// v[j] = x[m + 64 j] on entry (m = this lane's input index, any bijection of the lanes), v[t] = X[T(lane) + 64 t] on
+// exit.  twA[q-1] = e^{-2 pi i m q / 512}, twB[s-1] = e^{-2 pi i (lane & 7) s / 64} (conjugated here for SIGN > 0).
+// L: this wave's 576-slot LDS region.  The barriers are wave-local in effect (the waves of a workgroup own disjoint
+// regions); they order the LDS traffic and keep the compiler from moving accesses across the exchanges.
+template <int SIGN>
+__device__ __forceinline__ void fft512_wave(double2 (&v)[8], double2* L, int m, const double2 (&twA)[7],
+                                            const double2 (&twB)[7], int lane) {
+  const int hi = lane >> 3, lo = lane & 7;
+  radix8<SIGN>(v);
+#pragma unroll
+  for (int q = 1; q < 8; ++q) {
+    double2 w = twA[q - 1];
+    if (SIGN > 0) w.y = -w.y;
+    v[q] = cmul2(w, v[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) L[q * 72 + m] = v[q];
+  __syncthreads();
+#pragma unroll
+  for (int l1 = 0; l1 < 8; ++l1) v[l1] = L[hi * 72 + lo + 8 * l1];
+  radix8<SIGN>(v);
+#pragma unroll
+  for (int s = 1; s < 8; ++s) {
+    double2 w = twB[s - 1];
+    if (SIGN > 0) w.y = -w.y;
+    v[s] = cmul2(w, v[s]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx) L[hi * 72 + 9 * lo + sidx] = v[sidx];
+  __syncthreads();
+#pragma unroll
+  for (int l0 = 0; l0 < 8; ++l0) v[l0] = L[hi * 72 + 9 * l0 + lo];
+  radix8<SIGN>(v);
+}
+
+__device__ __forceinline__ void load_tw(double2 (&tw)[7], const double2* __restrict__ table, int row) {
+#pragma unroll
+  for (int q = 1; q < 8; ++q) tw[q - 1] = table[row * 8 + q];
+}
+
+// Row kernel, nx == 512: one wave per pair of rows; same contract as f2_row_kernel.
+constexpr int RW = 1;  // row pairs (waves) per workgroup
+__global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, const double2* __restrict__ H,
+                                                            const double* __restrict__ c_in,
+                                                            double* __restrict__ c_out, double2* __restrict__ G,
+                                                            const double2* __restrict__ twA_g,
+                                                            const double2* __restrict__ twB_g, int from_spectrum,
+                                                            int use_fprime) {
+  __shared__ __attribute__((aligned(16))) double2 Lall[RW * W8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double2* L = Lall + wave * W8;
+  constexpr int N = 512;
+  const int pair = blockIdx.x * RW + wave;
+  const int y0 = 2 * pair, y1 = y0 + 1;  // ny is even and (ny / 2) % RW == 0 (checked by the launcher)
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  double2 twN[7], twB[7], v[8];
+  load_tw(twN, twA_g, lane);
+  load_tw(twB, twB_g, lane & 7);
+  int m = lane;
+  if (from_spectrum) {
+    double2 twT[7];
+    load_tw(twT, twA_g, T);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lane + 64 * j;
+      const bool upper = k > N / 2;
+      const int kk = upper ? N - k : k;
+      const double2 p = H[(int64_t)y0 * a.nxh + kk], q = H[(int64_t)y1 * a.nxh + kk];
+      // X[k] = p + i q for k <= N/2, conj(p) + i conj(q) beyond (Hermitian rows)
+      v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
+    }
+    fft512_wave<+1>(v, L, lane, twN, twB, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
+      c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
+    }
+    m = T;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) twN[q] = twT[q];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = make_double2(c_in[(int64_t)y0 * N + lane + 64 * j], c_in[(int64_t)y1 * N + lane + 64 * j]);
+  }
+  if (use_fprime) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
+  }
+  fft512_wave<-1>(v, L, m, twN, twB, lane);
+  // Hermitian separation of the two real rows: needs X[k] and X[N - k] -> one more exchange (skewed: k + k / 8)
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int k = T + 64 * t;
+    L[k + (k >> 3)] = v[t];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int k = lane + 64 * t;
+    if (k <= N / 2) {
+      const int km = (N - k) & (N - 1);
+      const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
+      G[(int64_t)y0 * a.nxh + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+      G[(int64_t)y1 * a.nxh + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+    }
+  }
+}
+
+// Column kernel, ny == 512: CWN adjacent k_x columns per workgroup, one wave per column; contract of f2_col_kernel.
+// Every global access is made by the whole workgroup with the column index fastest (CWN * 16 contiguous bytes per row:
+// a full 64-byte sector for CWN = 4) and staged through LDS -- a wave reading "its" column straight from memory touches
+// 64 cache lines per load instruction for 16 useful bytes each, which made this kernel twice as slow as the row kernel.
+// chat is loaded at kernel entry so its latency hides behind the forward transform.
+constexpr int W8C = W8 + 32;  // per-wave LDS region: FFT exchanges (576) or a skewed natural-order column (575) + 4*ci
+template <int CWN>
+__global__ __launch_bounds__(64 * CWN) void f2_col512_kernel(const F2Args a, const double2* __restrict__ G,
+                                                             double2* __restrict__ chat, double2* __restrict__ H,
+                                                             const double2* __restrict__ twA_g,
+                                                             const double2* __restrict__ twB_g, int init_only) {
+  __shared__ __attribute__((aligned(16))) double2 Lall[CWN * W8C];
+  constexpr int N = 512, NT = 64 * CWN, PER = N * CWN / NT;  // PER = 8 elements per thread in the cooperative phases
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double2* L = Lall + wave * W8C + 4 * wave;  // this wave's region (the 4*ci shift de-aliases the columns' banks)
+  const int blk = xcd_band_block();
+  const int kxb = blk * CWN;
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  auto nat = [](int n) { return n + (n >> 3); };  // skewed natural-order slot
+  // cooperative element e = tid + NT * i  ->  (row y = e / CWN, column ci = e % CWN)
+  const int ci = tid % CWN, kx = kxb + ci;
+  const bool on = kx < a.nxh;
+  double2* Lc = Lall + ci * W8C + 4 * ci;
+  double2 twN[7], twB[7], v[8], ch[PER];
+  load_tw(twN, twA_g, lane);
+  load_tw(twB, twB_g, lane & 7);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int y = (tid + NT * i) / CWN;
+    v[i] = on ? G[(int64_t)y * a.nxh + kx] : make_double2(0.0, 0.0);
+    if (!init_only) ch[i] = on ? chat[(int64_t)y * a.nxh + kx] : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) Lc[nat((tid + NT * i) / CWN)] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
+  fft512_wave<-1>(v, L, lane, twN, twB, lane);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
+  __syncthreads();
+  if (init_only) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int ky = (tid + NT * i) / CWN;
+      if (on) chat[(int64_t)ky * a.nxh + kx] = Lc[nat(ky)];
+    }
+    return;
+  }
+  const double kxv = a.kx0 * kx;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ky = (tid + NT * i) / CWN;
+    const int my = 2 * ky > N ? ky - N : ky;
+    const double kyv = a.ky0 * my;
+    const double k2 = (kxv * kxv + kyv * kyv) + 0.0;  // same grouping as spectral.hip's ksq with kz = 0
+    const double num = a.dtM * k2;
+    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+    const double2 gh = Lc[nat(ky)];
+    double2 r;
+    r.x = fma(-num, gh.x, ch[i].x) * den;
+    r.y = fma(-num, gh.y, ch[i].y) * den;
+    if (on) chat[(int64_t)ky * a.nxh + kx] = r;
+    Lc[nat(ky)] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
+  fft512_wave<+1>(v, L, lane, twN, twB, lane);
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int y = (tid + NT * i) / CWN;
+    if (on) H[(int64_t)y * a.nxh + kx] = Lc[nat(y)];
+  }
+}
+
+int g_cw512 = 2;  // columns per workgroup of f2_col512_kernel (PFHIP_FFT512_CW = 1 | 2 | 4 | 8)
+
 int ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;
@@ -260,6 +523,8 @@ int ilog2(int n) {
 struct Fused2D {
   F2Args a;
   double2 *twx = nullptr, *twy = nullptr;
+  double2 *tw8a = nullptr, *tw8b = nullptr;  // radix-8 tables of the 512-point fast path
+  bool row512 = false, col512 = false;
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
   bool g_valid = false;  // G holds the row transform of f'(current c)
@@ -294,6 +559,32 @@ int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream) 
     return hipMemcpy(*dev, t.data(), sizeof(double2) * t.size(), hipMemcpyHostToDevice);
   };
   if (table(nx, &f->twx) != hipSuccess || table(ny, &f->twy) != hipSuccess) return -3;
+  const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
+  const bool allow8 = !(e && std::string(e) == "radix2");
+  f->row512 = allow8 && nx == 512 && (ny / 2) % RW == 0;
+  f->col512 = allow8 && ny == 512;
+  if (const char* cw = getenv("PFHIP_FFT512_CW")) {
+    const int c = std::atoi(cw);
+    if (c == 1 || c == 2 || c == 4 || c == 8) g_cw512 = c;
+  }
+  if (f->row512 || f->col512) {
+    std::vector<double2> ta(512), tb(64);
+    for (int l = 0; l < 64; ++l)
+      for (int q = 0; q < 8; ++q) {
+        const double ang = TWO_PI_F * (double)(l * q) / 512.0;
+        ta[l * 8 + q] = make_double2(std::cos(ang), -std::sin(ang));
+      }
+    for (int l0 = 0; l0 < 8; ++l0)
+      for (int sidx = 0; sidx < 8; ++sidx) {
+        const double ang = TWO_PI_F * (double)(l0 * sidx) / 64.0;
+        tb[l0 * 8 + sidx] = make_double2(std::cos(ang), -std::sin(ang));
+      }
+    if (hipMalloc(&f->tw8a, sizeof(double2) * 512) != hipSuccess ||
+        hipMalloc(&f->tw8b, sizeof(double2) * 64) != hipSuccess ||
+        hipMemcpy(f->tw8a, ta.data(), sizeof(double2) * 512, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(f->tw8b, tb.data(), sizeof(double2) * 64, hipMemcpyHostToDevice) != hipSuccess)
+      return -3;
+  }
   f->lds_row = sizeof(double2) * (nx + nx / 32 + nx / 2);
   f->lds_col = sizeof(double2) * ((size_t)CW * (ny + ny / 32 + 1) + ny / 2);
   if (f->lds_col > 64 * 1024 &&
@@ -307,18 +598,47 @@ void fused2d_destroy(Fused2D* f) {
   if (!f) return;
   if (f->twx) (void)hipFree(f->twx);
   if (f->twy) (void)hipFree(f->twy);
+  if (f->tw8a) (void)hipFree(f->tw8a);
+  if (f->tw8b) (void)hipFree(f->tw8b);
   delete f;
 }
 
 void fused2d_invalidate(Fused2D* f) { f->g_valid = false; }
 
+namespace {
+void launch_row(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
+                int from_spectrum, int use_fprime) {
+  if (f->row512)
+    hipLaunchKernelGGL(f2_row512_kernel, dim3(a.ny / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
+  else
+    hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_row, f->stream, a, H, c_in, c_out, G,
+                       (const double2*)f->twx, from_spectrum, use_fprime);
+}
+void launch_col(const Fused2D* f, const F2Args& a, const double2* G, double2* chat, double2* H, int init_only) {
+  if (f->col512 && g_cw512 == 1)
+    hipLaunchKernelGGL(f2_col512_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else if (f->col512 && g_cw512 == 2)
+    hipLaunchKernelGGL(f2_col512_kernel<2>, dim3((a.nxh + 1) / 2), dim3(128), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else if (f->col512 && g_cw512 == 8)
+    hipLaunchKernelGGL(f2_col512_kernel<8>, dim3((a.nxh + 7) / 8), dim3(512), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else if (f->col512)
+    hipLaunchKernelGGL(f2_col512_kernel<4>, dim3((a.nxh + 3) / 4), dim3(256), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else
+    hipLaunchKernelGGL(f2_col_kernel, dim3((a.nxh + CW - 1) / CW), dim3(CT * CW), f->lds_col, f->stream, a, G, chat, H,
+                       (const double2*)f->twy, init_only);
+}
+}  // namespace
+
 // chat <- 2-D spectrum of c (same as a rocFFT D2Z); G is clobbered
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   const F2Args& a = f->a;
-  hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_row, f->stream, a, (const double2*)nullptr, c,
-                     (double*)nullptr, G, (const double2*)f->twx, 0, 0);
-  hipLaunchKernelGGL(f2_col_kernel, dim3((a.nxh + CW - 1) / CW), dim3(CT * CW), f->lds_col, f->stream, a,
-                     (const double2*)G, chat, (double2*)nullptr, (const double2*)f->twy, 1);
+  launch_row(f, a, nullptr, c, nullptr, G, 0, 0);
+  launch_col(f, a, G, chat, nullptr, 1);
   f->g_valid = false;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -333,12 +653,9 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
   a.dtM = dt * M;
   a.dtMkappa = dt * M * kappa;
   if (!f->g_valid)  // row transform of f'(c_in) (first step, or after the field was replaced)
-    hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_row, f->stream, a, (const double2*)nullptr, c_in,
-                       (double*)nullptr, G, (const double2*)f->twx, 0, 1);
-  hipLaunchKernelGGL(f2_col_kernel, dim3((a.nxh + CW - 1) / CW), dim3(CT * CW), f->lds_col, f->stream, a,
-                     (const double2*)G, chat, H, (const double2*)f->twy, 0);
-  hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_row, f->stream, a, (const double2*)H,
-                     (const double*)nullptr, c_out, G, (const double2*)f->twx, 1, 1);
+    launch_row(f, a, nullptr, c_in, nullptr, G, 0, 1);
+  launch_col(f, a, G, chat, H, 0);
+  launch_row(f, a, H, nullptr, c_out, G, 1, 1);
   f->g_valid = true;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
