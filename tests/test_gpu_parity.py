@@ -278,10 +278,12 @@ def test_full_size_properties_512cubed(lib):
         assert abs(F1 - n * F2) <= 1e-12 * abs(F1)             # F_3D = L_z F_2D
 
 
-@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (1024, 128), (96, 40), (34, 18, 10), (64, 64, 64)])
+@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (1024, 128), (256, 512), (512, 128), (96, 40), (34, 18, 10),
+                                   (64, 64, 64)])
 def test_spectral_scheme_matches_numpy_oracle(lib, shape):
     """BASELINE.json config 2 (512^2 semi-implicit spectral) vs the pocketfft oracle, 1e-11 relative: 2-D power-of-two
-    shapes take the fused LDS-FFT path (csrc/spectral2d_fused.hip), everything else rocFFT."""
+    shapes take the fused LDS-FFT path (csrc/spectral2d_fused.hip: one-wave radix-8 kernels on 512-point axes -- (256, 512)
+    and (512, 128) pair one of them with the generic radix-2^2 kernel of the other axis), everything else rocFFT."""
     from oracle import ch_spectral
     dim = len(shape)
     n = shape[::-1]                      # (nx, ny[, nz])
