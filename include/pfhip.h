@@ -243,6 +243,10 @@ int pfk_set_tuning(int key, int value);
  * also be read against what the memory system delivers.  n must be even, pointers 16-byte aligned. */
 int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream);
 
+/* Measures the cost of one grid-wide barrier (agent-scope release + atomic count-in + acquire) of a cooperative launch
+ * with nblocks x nthreads: the price a persistent multi-phase kernel pays instead of a kernel boundary. */
+int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier);
+
 #ifdef __cplusplus
 }
 #endif

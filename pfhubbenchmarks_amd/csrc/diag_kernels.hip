@@ -232,6 +232,43 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const double2* __restr
   for (; i < end; i += stride) dst[i] = src[i];
 }
 
+// Grid-wide barrier for persistent kernels (all workgroups co-resident: cooperative launch).  Every thread publishes
+// its global writes at agent scope, one thread per workgroup counts in and polls; the spin is BOUNDED (a lost
+// workgroup sets *abort_flag and lets everybody fall through instead of hanging the GPU).
+__device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned target, int* abort_flag) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) {
+        __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+// probe: `iters` grid barriers, each preceded by one global write and followed by one read of a neighbour's slot
+// (so the release / acquire cache maintenance has something real to do)
+__global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned* counter, int* abort_flag, double* slots,
+                                                                 int iters) {
+  const int nb = gridDim.x;
+  double acc = 0.0;
+  for (int it = 0; it < iters; ++it) {
+    if (threadIdx.x < 32) slots[(int64_t)blockIdx.x * 32 + threadIdx.x] = (double)(it + blockIdx.x);
+    grid_barrier(counter, (unsigned)(it + 1) * (unsigned)nb, abort_flag);
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    acc += slots[(int64_t)((blockIdx.x + 17) % nb) * 32 + (threadIdx.x & 31)];
+  }
+  if (threadIdx.x == 0) slots[(int64_t)nb * 32 + blockIdx.x] = acc;
+}
+
 int g_copy_wgs_per_cu = 16, g_copy_mode = 3;  // best stable form of tools/copy_sweep.py (profiles/r01/copy_sweep.txt)
 
 }  // namespace
@@ -256,6 +293,43 @@ hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStre
     default: hipLaunchKernelGGL((stream_copy_kernel<false, 4>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2);
   }
   return hipGetLastError();
+}
+
+// returns milliseconds per barrier in *ms_per_barrier; *ok = 0 if the bounded spin tripped
+hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* ms_per_barrier, int* ok) {
+  unsigned* counter = nullptr;
+  int* flag = nullptr;
+  double* slots = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(&counter, sizeof(unsigned))) != hipSuccess) return e;
+  if ((e = hipMalloc(&flag, sizeof(int))) != hipSuccess) return e;
+  if ((e = hipMalloc(&slots, sizeof(double) * ((size_t)nblocks * 33 + 64))) != hipSuccess) return e;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0.f;
+  for (int rep = 0; rep < 2; ++rep) {  // second repetition is the timed one
+    (void)hipMemset(counter, 0, sizeof(unsigned));
+    (void)hipMemset(flag, 0, sizeof(int));
+    void* args[] = {&counter, &flag, &slots, &iters};
+    (void)hipEventRecord(e0, nullptr);
+    e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(grid_barrier_probe_kernel), dim3(nblocks),
+                                   dim3(nthreads), args, 0, nullptr);
+    if (e != hipSuccess) break;
+    (void)hipEventRecord(e1, nullptr);
+    if ((e = hipEventSynchronize(e1)) != hipSuccess) break;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  int h_flag = 1;
+  if (e == hipSuccess) e = hipMemcpy(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost);
+  *ok = h_flag == 0;
+  *ms_per_barrier = ms / (double)iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(counter);
+  (void)hipFree(flag);
+  (void)hipFree(slots);
+  return e;
 }
 
 hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, int ends, hipStream_t stream) {

@@ -991,6 +991,18 @@ int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream) {
   return PF_OK;
 }
 
+int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier) {
+  if (nblocks < 1 || nblocks > 1024 || nthreads < 64 || nthreads > 256 || iters < 1 || iters > 100000 || !us_per_barrier)
+    return fail(nullptr, PF_ERR_INVALID, "pfk_grid_barrier_probe: bad arguments");
+  double ms = 0.0;
+  int ok = 0;
+  hipError_t e = run_grid_barrier_probe(nblocks, nthreads, iters, &ms, &ok);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_grid_barrier_probe: ") + hipGetErrorString(e));
+  if (!ok) return fail(nullptr, PF_ERR_STATE, "pfk_grid_barrier_probe: the bounded spin tripped (workgroups not co-resident?)");
+  *us_per_barrier = ms * 1e3;
+  return PF_OK;
+}
+
 int pfk_set_tuning(int key, int value) {
   if (key == 0) {
     set_fused_variant(value);

@@ -95,6 +95,7 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.POINTER(PfkChParams), C.c_int, C.c_void_p]),
     "pfk_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "pfk_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pfk_grid_barrier_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
 }
 
 _lib = None
