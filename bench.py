@@ -19,6 +19,10 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
   bm1_fem_be    BASELINE.json config 1: the reference's own algorithm (100x100 crossed P1 mesh, backward Euler, Newton)
                 on the GPU; a "step" is one accepted BE step of the committed run's time grid; metric node-updates/s;
                 cpu_baseline = oracle/fem_be.py (numpy/scipy SuperLU) on the same rows; says whether FEniCS is present
+Why config 3 and not config 2 is the default: BASELINE.json's metric is "cell-updates/s at 512^2 and 512^3, 1/2/4/8
+GPUs" and its roofline target is the fused stencil.  Config 2 (512^2 spectral) is a 14 us, launch-latency-bound step
+that does not shard (replicas only, DESIGN.md section 4), so the N = 1, 2, 4, 8 series is run on the 512^3 stencil;
+the same default run also times both 512^2 workloads and reports them under "also" in the same JSON line.
 Prints ONE JSON line (rank 0).  `value` counts the cell updates of all ranks; inputs are resident in HBM before the
 timed region.  roofline.achieved = 16 B/cell-update x cells per launch / average kernel time from HIP events
 recorded inside libpfhip around every step launch.  cpu_baseline = the CPU oracle (oracle/ch_fd.c, OpenMP) timed on
