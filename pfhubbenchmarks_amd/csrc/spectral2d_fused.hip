@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
 }
 
 // Column kernel, ny == 512: CWN adjacent k_x columns per workgroup, one wave per column; contract of f2_col_kernel.
-// Every global access is made by the whole workgroup with the column index fastest (CWN * 16 contiguous bytes per row:
+// (A/B variant, PFHIP_FFT512_DIRECT=0.)  Every global access is made by the whole workgroup with the column index fastest (CWN * 16 contiguous bytes per row:
 // a full 64-byte sector for CWN = 4) and staged through LDS -- a wave reading "its" column straight from memory touches
 // 64 cache lines per load instruction for 16 useful bytes each, which made this kernel twice as slow as the row kernel.
 // chat is loaded at kernel entry so its latency hides behind the forward transform.
@@ -510,7 +510,67 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_kernel(const F2Args a, con
   }
 }
 
-int g_cw512 = 2;  // columns per workgroup of f2_col512_kernel (PFHIP_FFT512_CW = 1 | 2 | 4 | 8)
+// DEFAULT column kernel, no LDS staging: every wave reads / writes its own column straight from global memory (16-byte
+// accesses, one cache line per lane) and relies on the XCD band to find the line in its L2 after a sibling fetched it
+// -- with the band in place this beats the staged form (fewer LDS round trips and workgroup barriers on the critical
+// path of a latency-bound kernel).  PFHIP_FFT512_DIRECT=0 selects the staged kernel above (A/B).
+template <int CWN>
+__global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args a, const double2* __restrict__ G,
+                                                                    double2* __restrict__ chat,
+                                                                    double2* __restrict__ H,
+                                                                    const double2* __restrict__ twA_g,
+                                                                    const double2* __restrict__ twB_g, int init_only) {
+  __shared__ __attribute__((aligned(16))) double2 Lall[CWN * W8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double2* L = Lall + wave * W8;
+  constexpr int N = 512;
+  const int kx = xcd_band_block() * CWN + wave;
+  const bool on = kx < a.nxh;
+  const int kxc = on ? kx : a.nxh - 1;  // idle waves of the last workgroup shadow a valid column (no stores)
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  double2 twN[7], twT[7], twB[7], v[8], ch[8];
+  load_tw(twN, twA_g, lane);
+  load_tw(twT, twA_g, T);
+  load_tw(twB, twB_g, lane & 7);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = G[(int64_t)(lane + 64 * j) * a.nxh + kxc];
+  if (!init_only) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ch[t] = chat[(int64_t)(T + 64 * t) * a.nxh + kxc];
+  }
+  fft512_wave<-1>(v, L, lane, twN, twB, lane);
+  if (init_only) {
+    if (on) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) chat[(int64_t)(T + 64 * t) * a.nxh + kx] = v[t];
+    }
+    return;
+  }
+  const double kxv = a.kx0 * kxc;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int ky = T + 64 * t;
+    const int my = 2 * ky > N ? ky - N : ky;
+    const double kyv = a.ky0 * my;
+    const double k2 = (kxv * kxv + kyv * kyv) + 0.0;
+    const double num = a.dtM * k2;
+    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+    double2 r;
+    r.x = fma(-num, v[t].x, ch[t].x) * den;
+    r.y = fma(-num, v[t].y, ch[t].y) * den;
+    if (on) chat[(int64_t)ky * a.nxh + kx] = r;
+    v[t] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
+  }
+  __syncthreads();
+  fft512_wave<+1>(v, L, T, twT, twB, lane);
+  if (on) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) H[(int64_t)(T + 64 * t) * a.nxh + kx] = v[t];
+  }
+}
+
+int g_col512_direct = 1;  // measured: direct, 1 column per workgroup 13.05 us/step; staged 13.9 (PFHIP_FFT512_DIRECT=0)
+int g_cw512 = 1;          // columns per workgroup (PFHIP_FFT512_CW = 1 | 2 | 4 | 8; 8: staged kernel only)
 
 int ilog2(int n) {
   int l = 0;
@@ -563,6 +623,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream) 
   const bool allow8 = !(e && std::string(e) == "radix2");
   f->row512 = allow8 && nx == 512 && (ny / 2) % RW == 0;
   f->col512 = allow8 && ny == 512;
+  if (const char* d = getenv("PFHIP_FFT512_DIRECT")) g_col512_direct = std::atoi(d) != 0;
   if (const char* cw = getenv("PFHIP_FFT512_CW")) {
     const int c = std::atoi(cw);
     if (c == 1 || c == 2 || c == 4 || c == 8) g_cw512 = c;
@@ -616,7 +677,16 @@ void launch_row(const Fused2D* f, const F2Args& a, const double2* H, const doubl
                        (const double2*)f->twx, from_spectrum, use_fprime);
 }
 void launch_col(const Fused2D* f, const F2Args& a, const double2* G, double2* chat, double2* H, int init_only) {
-  if (f->col512 && g_cw512 == 1)
+  if (f->col512 && g_col512_direct && g_cw512 == 1)
+    hipLaunchKernelGGL(f2_col512_direct_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else if (f->col512 && g_col512_direct && g_cw512 == 4)
+    hipLaunchKernelGGL(f2_col512_direct_kernel<4>, dim3((a.nxh + 3) / 4), dim3(256), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else if (f->col512 && g_col512_direct)
+    hipLaunchKernelGGL(f2_col512_direct_kernel<2>, dim3((a.nxh + 1) / 2), dim3(128), 0, f->stream, a, G, chat, H,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
+  else if (f->col512 && g_cw512 == 1)
     hipLaunchKernelGGL(f2_col512_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
   else if (f->col512 && g_cw512 == 2)
