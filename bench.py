@@ -159,8 +159,10 @@ def measured_traffic(workload, variant):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="default 200 (bm1_fem_be: 100)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="default 50: the first ~25 steps after an idle GPU run 30 %% slower (tools/cold_start_ramp.py); "
+                         "bm1_fem_be: 10")
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
                              "bm1_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
@@ -172,6 +174,10 @@ def main():
                     help="N = 1 only: run the multi-GPU code path (RCCL process group of size 1, ghost planes, overlapped "
                          "exchange with itself) to measure its overhead against the plain single-GPU path")
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 100 if a.workload == "bm1_fem_be" else 200
+    if a.warmup is None:
+        a.warmup = 10 if a.workload == "bm1_fem_be" else 50
 
     import torch
     from pfhubbenchmarks_amd import lib as L
@@ -326,8 +332,9 @@ def main():
         # the same 8 B read + 8 B write per cell as a plain device copy (pfk_stream_copy): what the memory system
         # delivers for this traffic pattern, measured in the same process (SURVEY 8d "confirm with a device memcpy")
         import ctypes as C
-        src = torch.ones(local_cells, dtype=torch.float64, device="cuda")
-        dst = torch.empty_like(src)
+        gap = local_cells + 8192            # dst starts 64 KB (mod 512 KB) after src ends: pfhip.h, pf_ext_buffer_offset
+        blk = torch.ones(gap + local_cells, dtype=torch.float64, device="cuda")
+        src, dst = blk[:local_cells], blk[gap:]
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(23):
@@ -339,9 +346,10 @@ def main():
         torch.cuda.synchronize()
         copy_gbs = 16.0 * local_cells * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         assert bool((dst[:: max(1, local_cells // 1000)] == 1.0).all())
-        del src, dst
+        del src, dst, blk
         out["roofline"]["device_copy"] = {"achieved": copy_gbs, "unit": "GB/s", "frac_of_peak": copy_gbs / HBM_PEAK_GBS,
-                                          "kernel": "pfk_stream_copy, %d doubles, 20 launches" % local_cells}
+                                          "kernel": "pfk_stream_copy (one 16-byte element per thread), %d doubles, 20 launches"
+                                                    % local_cells}
         out["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
     if model == "bm6":
         pass          # no CPU leg for the BM6 box (the BM6 oracle is a test checker, minutes per step at this size)

@@ -168,6 +168,13 @@ int64_t pf_field_elems_with_ghosts(const pf_config* cfg);
 /* doubles of one rank's owned part of a field (what pf_set_field / pf_get_field move) */
 int64_t pf_field_elems(const pf_config* cfg);
 
+/* Recommended distance, in doubles, from ext_c[0] to ext_c[1] (which = 1) or to ext_phi (which = 2) when the caller
+ * carves them out of ONE allocation: on MI355X the read and the write stream of the fused step collide in the HBM
+ * channel map when the buffers sit 200-330 KB (mod 512 KB) apart -- 0.41 instead of 0.366 ms per 512^3 step
+ * (profiles/r01/buffer_offset.log); separately allocated buffers land anywhere.  Library-owned buffers follow the
+ * same rule.  >= pf_field_elems_with_ghosts(); <0: invalid config. */
+int64_t pf_ext_buffer_offset(const pf_config* cfg, int which);
+
 /* doubles per all-to-all buffer of the slab FFT modes for this config (<0: box not divisible by nranks) */
 int64_t pf_a2a_buffer_doubles(const pf_config* cfg);
 

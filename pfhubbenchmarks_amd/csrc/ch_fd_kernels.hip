@@ -564,7 +564,18 @@ hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream) {
     case 6: return launch_fused_t<4, 4, 1>(a, stream);
     case 7: return launch_fused_t<8, 2, 2, 1>(a, stream);
     case 8: return launch_fused_t<8, 2, 2, 2>(a, stream);
-    default: return launch_fused_t<8, 2, 2>(a, stream);
+    case 9: return launch_fused_t<8, 1, 2>(a, stream);   // 8-row tiles: 256 tiles per 512^2 plane, one z-chunk
+    case 10: return launch_fused_t<8, 1, 3>(a, stream);
+    case 11: return launch_fused_t<4, 2, 3>(a, stream);
+    case 12: return launch_fused_t<4, 2, 4>(a, stream);
+    case 13: return launch_fused_t<8, 2, 4>(a, stream);
+    case 14: return launch_fused_t<8, 2, 2>(a, stream);  // the default until the depth A/B of profiles/r01/depth_ab.log
+    case 15: return launch_fused_t<8, 2, 1, 1>(a, stream);
+    case 16: return launch_fused_t<8, 2, 1, 2>(a, stream);
+    // default <8,2,1>: in-process A/B on the same buffers (tools/variant_ab.py, profiles/r01/variant_ab*.log) ranks the
+    // prefetch depths 1 > 4 > 3 > 2 (0.372 / 0.379 / 0.387 / 0.402 ms at 512^3; 3.08 vs 3.35 ms at 1024^3 for 1 vs 2).
+    // Earlier process-per-variant sweeps could not see this: run-to-run placement noise is +-5 %.
+    default: return launch_fused_t<8, 2, 1>(a, stream);
   }
 }
 

@@ -269,7 +269,14 @@ __global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned* count
   if (threadIdx.x == 0) slots[(int64_t)nb * 32 + blockIdx.x] = acc;
 }
 
-int g_copy_wgs_per_cu = 16, g_copy_mode = 3;  // best stable form of tools/copy_sweep.py (profiles/r01/copy_sweep.txt)
+// one 16-byte element per thread, one short-lived workgroup per 4 KB: the dispatcher walks the buffer in address order
+__global__ __launch_bounds__(256) void stream_copy_flat_kernel(const double2* __restrict__ src,
+                                                               double2* __restrict__ dst, int64_t n2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n2) dst[i] = src[i];
+}
+
+int g_copy_wgs_per_cu = 16, g_copy_mode = 5;  // flat: 6.2 TB/s vs 5.2-5.7 for the looping forms (profiles/r01/copy_sweep.txt)
 
 }  // namespace
 
@@ -285,6 +292,12 @@ hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStre
   if (nb < 1) nb = 1;
   auto s2 = reinterpret_cast<const double2*>(src);
   auto d2 = reinterpret_cast<double2*>(dst);
+  if (g_copy_mode == 5) {
+    const int64_t nflat = (n2 + 255) / 256;
+    if (nflat > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stream_copy_flat_kernel, dim3((unsigned)nflat), dim3(256), 0, stream, s2, d2, n2);
+    return hipGetLastError();
+  }
   switch (g_copy_mode) {
     case 1: hipLaunchKernelGGL((stream_copy_kernel<true, 4>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2); break;
     case 2: hipLaunchKernelGGL((stream_copy_kernel<false, 8>), dim3((int)nb), dim3(256), 0, stream, s2, d2, n2); break;

@@ -76,6 +76,18 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
   return PF_OK;
 }
 
+// Relative placement of the streamed buffers.  Measured on MI355X (tools/buffer_offset_ab.py,
+// profiles/r01/buffer_offset.log): with power-of-two planes the fused step runs at 0.366 ms when the output buffer
+// starts 0-100 KB (mod 512 KB) after the input buffer and at 0.41 ms when the distance is 200-330 KB (mod 512 KB) --
+// the read and the write stream then collide in the HBM channel/bank map.  Separate hipMallocs land anywhere, which made
+// the same binary 10 % faster or slower from process to process.  So the buffers of one handle come from ONE block at
+// fixed distances (mod 512 KB): c[1] at +64 KB, phi at -64 KB.
+constexpr int64_t kPlacePeriod = 512 * 1024;
+int64_t placed_offset_bytes(int64_t elems, int which) {  // which: 1 = c[1], 2 = phi; relative to c[0]
+  const int64_t a = ((elems * (int64_t)sizeof(double) + kPlacePeriod - 1) / kPlacePeriod) * kPlacePeriod;
+  return which == 1 ? a + 64 * 1024 : 2 * a + kPlacePeriod - 64 * 1024;
+}
+
 }  // namespace
 
 struct pf_handle {
@@ -83,6 +95,7 @@ struct pf_handle {
   Geometry g;
   double* c[2] = {nullptr, nullptr};
   bool own_c = false;
+  void* block = nullptr;   // one allocation behind the library-owned c[0], c[1] (and phi): see placed_offset_bytes
   int cur = 0;
   bool have_prev = false;
   double* mu_scratch = nullptr;
@@ -384,6 +397,12 @@ int64_t pf_field_elems_with_ghosts(const pf_config* cfg) {
   return g.plane * (int64_t)(g.nz + 2 * g.ghost);
 }
 
+int64_t pf_ext_buffer_offset(const pf_config* cfg, int which) {
+  Geometry g;
+  if (resolve(cfg, &g, nullptr) != PF_OK || (which != 1 && which != 2)) return PF_ERR_INVALID;
+  return placed_offset_bytes(g.plane * (int64_t)(g.nz + 2 * g.ghost), which) / (int64_t)sizeof(double);
+}
+
 int64_t pf_field_elems(const pf_config* cfg) {
   Geometry g;
   if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
@@ -455,8 +474,12 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->c[1] = cfg->ext_c[1];
   } else {
     h->own_c = true;
-    PF_HIP_C(hipMalloc(&h->c[0], sizeof(double) * elems));
-    PF_HIP_C(hipMalloc(&h->c[1], sizeof(double) * elems));
+    const bool with_phi = cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_FEM_BE && !cfg->ext_phi;
+    const int64_t bytes = placed_offset_bytes(elems, with_phi ? 2 : 1) + (int64_t)sizeof(double) * elems;
+    PF_HIP_C(hipMalloc(&h->block, (size_t)bytes));
+    h->c[0] = static_cast<double*>(h->block);
+    h->c[1] = h->c[0] + placed_offset_bytes(elems, 1) / (int64_t)sizeof(double);
+    if (with_phi) h->phi = h->c[0] + placed_offset_bytes(elems, 2) / (int64_t)sizeof(double);
   }
   PF_HIP_C(hipMemsetAsync(h->c[0], 0, sizeof(double) * elems, h->stream));
   PF_HIP_C(hipMemsetAsync(h->c[1], 0, sizeof(double) * elems, h->stream));
@@ -470,14 +493,16 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   } else if (cfg->model == PF_MODEL_BM6 && slab_fft) {
     if (cfg->ext_phi) {
       h->phi = cfg->ext_phi;
-    } else {
+    } else if (!h->phi) {  // caller-owned c buffers without a phi buffer: phi is on its own
       PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
       h->own_phi = true;
     }
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
   } else if (cfg->model == PF_MODEL_BM6) {
-    PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
-    h->own_phi = true;
+    if (!h->phi) {
+      PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
+      h->own_phi = true;
+    }
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
     int prc = poisson_create(&h->po, cfg->dim, g.nx, g.ny, g.nzg, g.mirror ? g.np[0] : 0, g.mirror ? g.np[1] : 0,
                              cfg->h, cfg->k, cfg->eps_r, h->stream, &h->err);
@@ -505,10 +530,7 @@ int pf_destroy(pf_handle* h) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
   }
-  if (h->own_c) {
-    if (h->c[0]) (void)hipFree(h->c[0]);
-    if (h->c[1]) (void)hipFree(h->c[1]);
-  }
+  if (h->block) (void)hipFree(h->block);
   if (h->mu_scratch) (void)hipFree(h->mu_scratch);
   if (h->sp) spectral_destroy(h->sp);
   if (h->po) poisson_destroy(h->po);
@@ -1028,7 +1050,7 @@ int pfk_set_tuning(int key, int value) {
     set_copy_tuning(value, -1);
     return PF_OK;
   }
-  if (key == 6 && value >= 0 && value <= 4) {  // pfk_stream_copy: kernel form (table in csrc/diag_kernels.hip)
+  if (key == 6 && value >= 0 && value <= 5) {  // pfk_stream_copy: kernel form (table in csrc/diag_kernels.hip)
     set_copy_tuning(0, value);
     return PF_OK;
   }

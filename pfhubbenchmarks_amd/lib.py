@@ -71,6 +71,7 @@ SYMBOLS = {
     "pf_slab_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_field_elems_with_ghosts": (C.c_int64, [C.POINTER(PfConfig)]),
     "pf_field_elems": (C.c_int64, [C.POINTER(PfConfig)]),
+    "pf_ext_buffer_offset": (C.c_int64, [C.POINTER(PfConfig), C.c_int]),
     "pf_a2a_buffer_doubles": (C.c_int64, [C.POINTER(PfConfig)]),
     "pf_dist_begin": (C.c_int, [_H, C.c_int, C.c_double]),
     "pf_dist_advance": (C.c_int, [_H, C.POINTER(PfDistRequest)]),

@@ -161,6 +161,20 @@ def slab_partition(n_planes, nranks, rank):
     return f.value, c.value
 
 
+def _placed_buffers(torch, lib, cfg, shape, device, with_phi=False):
+    """The two time-level buffers (and phi) of one rank as views of ONE torch allocation, at the distances
+    pf_ext_buffer_offset recommends (MI355X: the read and the write stream of the fused step collide in the HBM channel
+    map at some relative placements; separately allocated tensors land anywhere -- pfhip.h)."""
+    elems = int(np.prod(shape))
+    off1 = int(lib.pf_ext_buffer_offset(C.byref(cfg), 1))
+    off2 = int(lib.pf_ext_buffer_offset(C.byref(cfg), 2))
+    if off1 < elems or off2 < off1 + elems:
+        raise ValueError("pf_ext_buffer_offset: invalid configuration")
+    block = torch.zeros((off2 if with_phi else off1) + elems, dtype=torch.float64, device=device)
+    views = [block[o:o + elems].view(shape) for o in ((0, off1, off2) if with_phi else (0, off1))]
+    return block, views
+
+
 class HipSlabEngine:
     """One rank's slab on one GPU.  Field storage is two torch CUDA tensors (nz_local + 4, ny, nx) handed to
     libpfhip as raw device pointers (pf_config.ext_c), so torch.distributed can send / receive the ghost planes
@@ -195,8 +209,8 @@ class HipSlabEngine:
         if elems < 0:
             raise ValueError("invalid slab configuration (mirror bc needs >= 3 planes per rank, periodic >= 2)")
         assert elems == (self.nz + 2 * self.ghost) * ly * lx
-        self.buffers = [torch.zeros((self.nz + 2 * self.ghost, ly, lx), dtype=torch.float64, device=self.device)
-                        for _ in range(2)]
+        self._block, self.buffers = _placed_buffers(torch, self._lib, cfg, (self.nz + 2 * self.ghost, ly, lx),
+                                                    self.device)
         self.stream = torch.cuda.Stream(device=self.device)
         cfg.stream = C.c_void_p(self.stream.cuda_stream)
         cfg.ext_c[0] = C.c_void_p(self.buffers[0].data_ptr())
@@ -373,7 +387,9 @@ class HipFFTSlabEngine(HipSlabEngine):
         self.nx, self.ny, self.nz_global = nx, ny, nz
         self.h = float(h)
         mk = lambda shape: torch.zeros(shape, dtype=torch.float64, device=self.device)  # noqa: E731
-        self.buffers = [mk((self.nz + 2 * self.ghost, ny, nx)) for _ in range(2)]
+        self._block, views = _placed_buffers(torch, self._lib, cfg, (self.nz + 2 * self.ghost, ny, nx), self.device,
+                                             with_phi=(model == "bm6"))
+        self.buffers = views[:2]
         self.stream = torch.cuda.Stream(device=self.device)
         cfg.stream = C.c_void_p(self.stream.cuda_stream)
         cfg.ext_c[0] = C.c_void_p(self.buffers[0].data_ptr())
@@ -386,7 +402,7 @@ class HipFFTSlabEngine(HipSlabEngine):
             cfg.ext_a2a[1] = C.c_void_p(self.a2a[1].data_ptr())
             self.tensors.update({t.data_ptr(): t for t in self.a2a})
         if model == "bm6":
-            self.phi = mk((self.nz + 2 * self.ghost, ny, nx))
+            self.phi = views[2]
             cfg.ext_phi = C.c_void_p(self.phi.data_ptr())
             self.tensors[self.phi.data_ptr()] = self.phi
         self.cfg = cfg

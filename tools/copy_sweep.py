@@ -30,8 +30,8 @@ def main():
     dst = torch.empty_like(src)
     st = torch.cuda.current_stream()
     res = {}
-    for mode in range(5):
-        for wgs in (2, 4, 8, 16, 32, 64):
+    for mode in range(6):
+        for wgs in ((2, 4, 8, 16, 32, 64) if mode < 5 else (1,)):
             lib.pfk_set_tuning(6, mode)
             lib.pfk_set_tuning(5, wgs)
             t = timed(lambda: L.check(lib.pfk_stream_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n,

@@ -1,0 +1,64 @@
+"""Builds summary_<workload>.json from the three rocprofv3 passes of tools/profile_workload.sh (per-launch averages of
+the dominant kernel: duration, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE) and trims the raw
+CSVs to the rows of that kernel."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out, workload, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+CELLS = {"bm1_fd_512c": 512 ** 3, "bm1_fd_1024c": 1024 ** 3, "bm6_fd_512c_elim": 512 ** 3}[workload]
+
+
+def one(pattern):
+    f = sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+    if not f:
+        sys.exit("missing " + pattern)
+    return f[-1]
+
+
+stats = list(csv.DictReader(open(one("stats/**/*kernel_stats.csv"))))
+fused = max((r for r in stats if "ch_fd3d_fused_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+name = fused["Name"]
+
+
+def counter(passdir, cname):
+    rows = [r for r in csv.DictReader(open(one(passdir + "/**/*counter_collection.csv")))
+            if r["Kernel_Name"] == name and r["Counter_Name"] == cname]
+    vals = [float(r["Counter_Value"]) for r in rows][5:]          # skip the first launches (cold caches)
+    with open(os.path.join(out, "bench_%s_pmc_%s.csv" % (tag, cname)), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    return sum(vals) / len(vals)
+
+
+fetch_kb = counter("fetch", "FETCH_SIZE")
+write_kb = counter("write", "WRITE_SIZE")
+with open(os.path.join(out, "bench_%s_kernel_stats.csv" % tag), "w") as fh:
+    fh.write(open(one("stats/**/*kernel_stats.csv")).read())
+trace = [r for r in csv.DictReader(open(one("stats/**/*kernel_trace.csv"))) if r["Kernel_Name"] == name]
+trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace]
+steady = durs[40:] if len(durs) > 60 else durs
+steady_avg_ns = sum(steady) / len(steady)
+alg = 16 * CELLS
+fetch_b, write_b = fetch_kb * 1024 * 2, write_kb * 1024
+avg_ns = float(fused["AverageNs"])
+s = {"round": 1, "workload": workload, "kernel": name, "calls": int(fused["Calls"]), "avg_ns": avg_ns,
+     "steady_avg_ns": steady_avg_ns, "steady_launches": len(steady),
+     "steady_note": "kernel_trace durations after the 40th launch: the first ~25 launches after an idle GPU run up to "
+                    "40 % slower (clock / TLB warm-up, tools/cold_start_ramp.py); bench.py's default warm-up is 50 steps",
+     "achieved_algorithmic_GBps_steady": alg / steady_avg_ns,
+     "cells_per_launch": CELLS, "algorithmic_bytes_per_launch": alg,
+     "FETCH_SIZE_KB_raw": fetch_kb, "fetch_bytes_corrected_x2": fetch_b, "WRITE_SIZE_KB_raw": write_kb,
+     "write_bytes": write_b, "traffic_bytes_per_launch": fetch_b + write_b,
+     "traffic_over_algorithmic": (fetch_b + write_b) / alg,
+     "achieved_algorithmic_GBps_under_rocprof": alg / avg_ns, "hbm_GBps_under_rocprof": (fetch_b + write_b) / avg_ns,
+     "note": "tools/profile_workload.sh: separate rocprofv3 passes (--kernel-trace --stats; --pmc FETCH_SIZE; --pmc "
+             "WRITE_SIZE); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of 16-B/lane streaming "
+             "reads); WRITE_SIZE exact; the average includes the cold first launches of the stats pass"}
+with open(os.path.join(out, "summary_%s.json" % workload), "w") as fh:
+    json.dump(s, fh, indent=1)
+print(json.dumps(s, indent=1))
