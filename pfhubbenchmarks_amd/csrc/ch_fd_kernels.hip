@@ -572,10 +572,14 @@ hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream) {
     case 14: return launch_fused_t<8, 2, 2>(a, stream);  // the default until the depth A/B of profiles/r01/depth_ab.log
     case 15: return launch_fused_t<8, 2, 1, 1>(a, stream);
     case 16: return launch_fused_t<8, 2, 1, 2>(a, stream);
-    // default <8,2,1>: in-process A/B on the same buffers (tools/variant_ab.py, profiles/r01/variant_ab*.log) ranks the
-    // prefetch depths 1 > 4 > 3 > 2 (0.372 / 0.379 / 0.387 / 0.402 ms at 512^3; 3.08 vs 3.35 ms at 1024^3 for 1 vs 2).
-    // Earlier process-per-variant sweeps could not see this: run-to-run placement noise is +-5 %.
-    default: return launch_fused_t<8, 2, 1>(a, stream);
+    case 17: return launch_fused_t<8, 2, 1>(a, stream);
+    // default <8,2,1> + non-temporal stores: in-process A/B on the same buffers (tools/variant_ab.py,
+    // profiles/r01/variant_ab*.log) ranks the prefetch depths 1 > 4 > 3 > 2 (0.367 / 0.374 / 0.387 / 0.387 ms at 512^3),
+    // and with the buffers placed (pfhip_api.hip: placed_offset_bytes) the streaming stores are worth another 2.4 % at
+    // 512^3 (0.358 ms) and 8 % at 1024^3 (2.90 vs 3.15 ms): the output is never re-read inside the launch, so it
+    // should not evict the input halos from L2 / MALL.  Non-temporal LOADS lose the halo reuse (variant 16).
+    // Earlier process-per-variant sweeps could not see any of this: run-to-run placement noise was +-5 %.
+    default: return launch_fused_t<8, 2, 1, 1>(a, stream);
   }
 }
 

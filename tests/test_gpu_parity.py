@@ -14,7 +14,7 @@ torch = pytest.importorskip("torch")
 from pfhubbenchmarks_amd import lib as L  # noqa: E402
 from pfhubbenchmarks_amd.solver import HipSlabEngine, PhaseFieldSolver  # noqa: E402
 
-FUSED_VARIANTS = [0, 1, 2, 3, 4, 5, 6, 9, 11, 13, 14]
+FUSED_VARIANTS = [0, 1, 2, 3, 4, 5, 6, 9, 11, 13, 14, 16, 17]
 
 
 @pytest.fixture(scope="module")
