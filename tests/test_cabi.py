@@ -108,3 +108,19 @@ def test_integration_md_ctypes_stub_matches_the_abi():
     assert ns["lib"].pf_config_default(C.byref(cfg), 2, 201, C.c_double(1.0)) == 0
     assert C.sizeof(cfg) == cfg.struct_bytes
     assert (cfg.dim, cfg.n[0], cfg.n[2], cfg.kappa, cfg.M, cfg.k, cfg.eps_r) == (2, 201, 1, 2.0, 5.0, 0.09, 90.0)
+
+
+def test_ext_buffer_offsets_follow_the_placement_rule():
+    """pf_ext_buffer_offset (host logic only): c[1] sits 64 KB and phi -64 KB (mod 512 KB) from c[0], beyond the buffer"""
+    import ctypes as C
+    from pfhubbenchmarks_amd import lib as L
+    lib = L.load()
+    for n, nranks in ((512, 1), (200, 1), (96, 3), (34, 2)):
+        cfg = L.default_config(3, n, 1.0)
+        cfg.nranks, cfg.rank = nranks, 0
+        elems = lib.pf_field_elems_with_ghosts(C.byref(cfg))
+        o1, o2 = lib.pf_ext_buffer_offset(C.byref(cfg), 1), lib.pf_ext_buffer_offset(C.byref(cfg), 2)
+        assert o1 >= elems and o2 >= o1 + elems
+        assert (o1 * 8) % (512 * 1024) == 64 * 1024 and (o2 * 8) % (512 * 1024) == 448 * 1024
+        assert o1 * 8 < elems * 8 + 576 * 1024 + 64 * 1024          # no more than one period of padding
+    assert lib.pf_ext_buffer_offset(C.byref(cfg), 3) < 0
