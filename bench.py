@@ -169,10 +169,14 @@ def main():
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
     ap.add_argument("--min-chunk", type=int, default=0, help="pfk_set_tuning key 2")
+    ap.add_argument("--push-wgs", type=int, default=0, help="pfk_set_tuning key 7 (ipc transport)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true",
                     help="N = 1 only: run the multi-GPU code path (RCCL process group of size 1, ghost planes, overlapped "
                          "exchange with itself) to measure its overhead against the plain single-GPU path")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "ipc"],
+                    help="ghost-plane exchange of the FD slab path: RCCL send/recv (default) or peer-mapped ghost planes "
+                         "written by a side-stream kernel (pfhubbenchmarks_amd.solver.IpcHaloTransport; one node)")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 100 if a.workload == "bm1_fem_be" else 200
@@ -201,6 +205,8 @@ def main():
         lib.pfk_set_tuning(1, a.target_wgs)
     if a.min_chunk > 0:
         lib.pfk_set_tuning(2, a.min_chunk)
+    if a.push_wgs > 0:
+        lib.pfk_set_tuning(7, a.push_wgs)
 
     if a.workload == "bm1_fem_be":
         return bench_fem_be(a, world)
@@ -255,7 +261,7 @@ def main():
         else:
             eng = HipSlabEngine(gn, h, world, rank, local_rank)
             eng.set_ic_bm1(0.5, 0.05)
-            solver = SlabSolver(eng)
+            solver = SlabSolver(eng, transport=a.transport)
         timer = eng
         local_cells = gn[0] * gn[1] * eng.nz
 
@@ -318,7 +324,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
                    "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
-                   "parallelism": "slab%d%s" % (world, "-forced" if a.slab else "")},
+                   "parallelism": "slab%d%s%s" % (world, "-forced" if a.slab else "",
+                                                  "-ipc" if (dist is not None and a.transport == "ipc") else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(a.workload, a.variant) if world == 1 else None,

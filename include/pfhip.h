@@ -241,7 +241,7 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
 /* tuning hooks for benchmarks: key 0 = fused-kernel variant (table in csrc/ch_fd_kernels.hip);
  * key 1 = target number of workgroups for the z-chunk split; key 2 = minimum planes per z-chunk;
  * key 3 = largest number of 2-D time steps fused into one launch (1, 2 or 4); key 4 = 10 K + rows per wave of the 2-D
- * K-step kernel; keys 5 / 6 = workgroups per CU / kernel form of pfk_stream_copy */
+ * K-step kernel; keys 5 / 6 = workgroups per CU / kernel form of pfk_stream_copy; key 7 = workgroups per pfk_push_planes message */
 int pfk_set_tuning(int key, int value);
 
 /* Device copy dst[i] = src[i], n doubles, 16-byte accesses: the measured HBM ceiling for a 1-read + 1-write stream
@@ -249,6 +249,17 @@ int pfk_set_tuning(int key, int value);
  * roofline.frac (against the 8 TB/s datasheet peak, SURVEY 8d: "confirm with a device memcpy/triad on the box") can
  * also be read against what the memory system delivers.  n must be even, pointers 16-byte aligned. */
 int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream);
+
+/* Peer-copy halo transport (an alternative to RCCL send/recv inside one node; pfhubbenchmarks_amd/solver.py:
+ * IpcHaloTransport).  RCCL's send/recv kernel is starved beside the HBM-saturating stencil and finishes with it
+ * (+27 us per step); here the sender writes the neighbour's ghost planes directly:
+ *   pfk_push_planes: dst[0..n) = src[0..n) (dst may be a peer-mapped IPC pointer), then *flag = seq with system-scope
+ *                    release, by the last workgroup to finish; `ticket` = zero-initialised uint32 owned by the sender.
+ *   pfk_wait_flag:   stream-ordered wait until *flag >= seq (one polling lane; gives up after ~2 s and sets *timeout).
+ * Sequence numbers are monotonic per neighbour pair, so no host-side ordering of record / wait calls is needed. */
+int pfk_push_planes(const double* src, double* dst, int64_t n, int64_t* flag, int64_t seq, uint32_t* ticket,
+                    void* stream);
+int pfk_wait_flag(const int64_t* flag, int64_t seq, int32_t* timeout, void* stream);
 
 /* Measures the cost of one grid-wide barrier (agent-scope release + atomic count-in + acquire) of a cooperative launch
  * with nblocks x nthreads: the price a persistent multi-phase kernel pays instead of a kernel boundary. */

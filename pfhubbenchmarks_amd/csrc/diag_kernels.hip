@@ -269,6 +269,37 @@ __global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned* count
   if (threadIdx.x == 0) slots[(int64_t)nb * 32 + blockIdx.x] = acc;
 }
 
+// ---- peer-copy halo transport (pfk_push_planes / pfk_wait_flag) --------------------------------------------------
+// push: copy n doubles into a (possibly peer-mapped, IPC) destination, then publish `seq` in the destination rank's
+// flag word -- written by whichever workgroup finishes last, after a system-scope release, so a reader that sees
+// flag >= seq also sees the planes.  `ticket` is a zero-initialised counter owned by the sender (reset for reuse).
+__global__ __launch_bounds__(256) void push_planes_kernel(const double2* __restrict__ src, double2* __restrict__ dst,
+                                                          int64_t n2, long long* flag, long long seq,
+                                                          unsigned* ticket) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the stores above are visible to the peer
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// wait: one lane polls this rank's own flag word until the neighbour has published `seq`.  BOUNDED: after about two
+// seconds it gives up, raises *timeout and lets the stream continue (a lost neighbour must not hang the GPU).
+__global__ void wait_flag_kernel(const long long* flag, long long seq, int* timeout) {
+  if (threadIdx.x != 0) return;
+  for (int spins = 0; spins < (1 << 25); ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= seq) return;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // one 16-byte element per thread, one short-lived workgroup per 4 KB: the dispatcher walks the buffer in address order
 __global__ __launch_bounds__(256) void stream_copy_flat_kernel(const double2* __restrict__ src,
                                                                double2* __restrict__ dst, int64_t n2) {
@@ -283,6 +314,28 @@ int g_copy_wgs_per_cu = 16, g_copy_mode = 5;  // flat: 6.2 TB/s vs 5.2-5.7 for t
 void set_copy_tuning(int wgs_per_cu, int mode) {
   if (wgs_per_cu > 0) g_copy_wgs_per_cu = wgs_per_cu;
   if (mode >= 0) g_copy_mode = mode;
+}
+
+int g_push_wgs = 16;  // one GPU, self-exchange beside the 512^3 stencil: 1 WG 0.97 ms/step, 4: 0.456, 8: 0.423, 16: 0.419, 64: 0.438
+void set_push_wgs(int n) {
+  if (n > 0) g_push_wgs = n;
+}
+
+hipError_t launch_push_planes(const double* src, double* dst, int64_t n, long long* flag, long long seq,
+                              unsigned* ticket, hipStream_t stream) {
+  const int64_t n2 = n / 2;
+  int64_t nb = (n2 + 255) / 256;
+  if (nb > g_push_wgs) nb = g_push_wgs;  // few workgroups: the message has a whole interior launch to arrive, and
+                                          // every CU it borrows turns into a straggler of the 1-WG-per-CU stencil
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(push_planes_kernel, dim3((int)nb), dim3(256), 0, stream, reinterpret_cast<const double2*>(src),
+                     reinterpret_cast<double2*>(dst), n2, flag, seq, ticket);
+  return hipGetLastError();
+}
+
+hipError_t launch_wait_flag(const long long* flag, long long seq, int* timeout, hipStream_t stream) {
+  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, stream, flag, seq, timeout);
+  return hipGetLastError();
 }
 
 hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t stream) {

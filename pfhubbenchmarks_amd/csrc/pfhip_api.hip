@@ -1013,6 +1013,25 @@ int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream) {
   return PF_OK;
 }
 
+int pfk_push_planes(const double* src, double* dst, int64_t n, int64_t* flag, int64_t seq, uint32_t* ticket,
+                    void* stream) {
+  if (!src || !dst || !flag || !ticket || n < 2 || (n & 1) ||
+      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
+    return fail(nullptr, PF_ERR_INVALID, "pfk_push_planes: need even n >= 2, 16-byte aligned pointers, flag and ticket");
+  hipError_t e = launch_push_planes(src, dst, n, reinterpret_cast<long long*>(flag), (long long)seq, ticket,
+                                    reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_push_planes: ") + hipGetErrorString(e));
+  return PF_OK;
+}
+
+int pfk_wait_flag(const int64_t* flag, int64_t seq, int32_t* timeout, void* stream) {
+  if (!flag || !timeout) return fail(nullptr, PF_ERR_INVALID, "pfk_wait_flag: null pointer");
+  hipError_t e = launch_wait_flag(reinterpret_cast<const long long*>(flag), (long long)seq, timeout,
+                                  reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_wait_flag: ") + hipGetErrorString(e));
+  return PF_OK;
+}
+
 int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier) {
   if (nblocks < 1 || nblocks > 1024 || nthreads < 64 || nthreads > 256 || iters < 1 || iters > 100000 || !us_per_barrier)
     return fail(nullptr, PF_ERR_INVALID, "pfk_grid_barrier_probe: bad arguments");
@@ -1048,6 +1067,10 @@ int pfk_set_tuning(int key, int value) {
   }
   if (key == 5 && value > 0) {  // pfk_stream_copy: workgroups per CU
     set_copy_tuning(value, -1);
+    return PF_OK;
+  }
+  if (key == 7 && value > 0 && value <= 1024) {  // pfk_push_planes: workgroups per message
+    set_push_wgs(value);
     return PF_OK;
   }
   if (key == 6 && value >= 0 && value <= 5) {  // pfk_stream_copy: kernel form (table in csrc/diag_kernels.hip)

@@ -42,6 +42,10 @@ hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int n
                        double rho, double ca, double cb, double* partials, double* out6, hipStream_t stream);
 // fill the ghost planes outside a no-flux wall with mirror images of the owned planes (ends: same bits as zends)
 void set_copy_tuning(int wgs_per_cu, int mode);  // <= 0 / < 0: keep
+hipError_t launch_push_planes(const double* src, double* dst, int64_t n, long long* flag, long long seq,
+                              unsigned* ticket, hipStream_t stream);
+void set_push_wgs(int n);
+hipError_t launch_wait_flag(const long long* flag, long long seq, int* timeout, hipStream_t stream);
 hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* ms_per_barrier, int* ok);
 hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t stream);
 hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, int ends, hipStream_t stream);

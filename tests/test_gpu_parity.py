@@ -616,6 +616,51 @@ def test_nccl_path_single_rank(lib):
     assert p.returncode == 0 and "NCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+@pytest.mark.parametrize("world,bc", [(2, "periodic"), (3, "periodic"), (3, "mirror")])
+def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, world, bc, tmp_path):
+    """2 and 3 ranks as separate processes sharing the GPU: HipSlabEngine + SlabSolver(transport="ipc") -- ghost planes
+    pushed into the neighbour's buffer through CUDA IPC, flag-ordered (pfk_push_planes / pfk_wait_flag); must equal the
+    whole-domain oracle bit for bit (27 steps, so every buffer parity and sequence number is exercised)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = str(tmp_path / "res.npz")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "ipc_slab_worker.py"), out, bc],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+    res = np.load(out)
+    c = res["full"]
+    nz, ny, nx = c.shape
+    mirror = bc == "mirror"
+    e = orc.even_extend(c) if mirror else c
+    F0, C0, _ = orc.diagnostics(e, h=1.0, mirror=mirror)
+    np.testing.assert_allclose(res["d0"][:2], [F0, C0], rtol=1e-13)
+    for _ in range(25):
+        e = orc.fd_step(e, 1e-3)
+    F1, C1, _ = orc.diagnostics(e, h=1.0, mirror=mirror)
+    np.testing.assert_allclose(res["d1"][:2], [F1, C1], rtol=1e-13)
+    for _ in range(2):
+        e = orc.fd_step(e, 1e-3)
+    np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
+
+
 def test_bench_contract_json_line():
     """bench.py prints exactly one JSON line with the fields the driver reads (short run of the default workload)"""
     import json
