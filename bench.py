@@ -292,7 +292,9 @@ def main():
     sync()
     # per-launch HIP events cost a few us each: fine beside a 0.4 ms kernel, not beside a 2-D step of a few us -> the
     # launch-bound 2-D workloads are timed by the wall clock alone (kernel_ms_per_step is then the wall time per step)
-    per_launch_events = dim == 3
+    # ... and the multi-GPU (slab) path is timed by the wall clock too: its two launches per step would need four event
+    # records per step, each a barrier packet on the compute queue (10-15 us per step beside the cross-stream waits)
+    per_launch_events = dim == 3 and dist is None
     timer.timing(per_launch_events)
     t0 = time.perf_counter()
     run(a.steps)
