@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
     ap.add_argument("--min-chunk", type=int, default=0, help="pfk_set_tuning key 2")
+    ap.add_argument("--fused-slab", action="store_true",
+                    help="with --transport ipc: one launch per step (pf_step_slab_fused)")
     ap.add_argument("--push-wgs", type=int, default=0, help="pfk_set_tuning key 7 (ipc transport)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slab", action="store_true",
@@ -261,7 +263,7 @@ def main():
         else:
             eng = HipSlabEngine(gn, h, world, rank, local_rank)
             eng.set_ic_bm1(0.5, 0.05)
-            solver = SlabSolver(eng, transport=a.transport)
+            solver = SlabSolver(eng, transport=a.transport, fused=a.fused_slab)
         timer = eng
         local_cells = gn[0] * gn[1] * eng.nz
 
@@ -327,7 +329,8 @@ def main():
         "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
                    "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
                    "parallelism": "slab%d%s%s" % (world, "-forced" if a.slab else "",
-                                                  "-ipc" if (dist is not None and a.transport == "ipc") else "")},
+                                                  ("-ipc-fused" if a.fused_slab else "-ipc")
+                                                  if (dist is not None and a.transport == "ipc") else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": measured_traffic(a.workload, a.variant) if world == 1 else None,

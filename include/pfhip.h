@@ -205,6 +205,14 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
 int pf_step_begin(pf_handle* h, double dt);
 int pf_step_finish(pf_handle* h);
 
+/* slab mode, one step in ONE launch (peer-copy transport): the interior chunks are dispatched first; the workgroups
+ * of the two boundary strips are dispatched last and poll flag_lo / flag_hi (device words the neighbours publish `seq`
+ * in once their planes have landed: pfk_push_planes) before they read the ghost planes -- no second launch, no
+ * cross-stream event on the critical path.  Null flag = no neighbour on that side (ignored at a mirror-bc wall
+ * anyway).  The poll is bounded (~1 s); *timeout is set to 1 if it gives up.  Needs > 2 * ghost planes per rank. */
+int pf_step_slab_fused(pf_handle* h, double dt, const int64_t* flag_lo, const int64_t* flag_hi, int64_t seq,
+                       int32_t* timeout);
+
 /* slab FFT modes and ghost refresh: see pf_dist_request above */
 int pf_dist_begin(pf_handle* h, int op, double dt);
 int pf_dist_advance(pf_handle* h, pf_dist_request* req);

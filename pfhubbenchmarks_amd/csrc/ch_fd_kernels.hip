@@ -34,6 +34,9 @@ struct KArgs {
   int ntx, nty, nchunk, zchunk, ntiles;
   int nchunk1;  // chunks [0, nchunk1) cover [zlo, zhi); chunks [nchunk1, nchunk) cover the second range [zlo2, zhi2)
   int zchunk2;
+  int grid1;    // blocks [0, grid1) take first-range tiles in XCD order; blocks >= grid1 take second-range tiles in
+                // block order, i.e. they are dispatched LAST (they may have to wait for ghost planes to arrive)
+  int ntiles1;
 };
 
 __device__ __forceinline__ int wrapi(int i, int n) {
@@ -126,9 +129,15 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
 
   // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD one contiguous run of
   // tiles (x fastest, then y, then z-chunk) so that tiles sharing halos hit the same L2.  Speed only.
-  const int per = gridDim.x >> 3;
-  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (t >= k.ntiles) return;
+  int t;
+  if ((int)blockIdx.x < k.grid1) {
+    const int per = k.grid1 >> 3;
+    t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= k.ntiles1) return;
+  } else {
+    t = k.ntiles1 + ((int)blockIdx.x - k.grid1);
+    if (t >= k.ntiles) return;
+  }
   const int tx = t % k.ntx;
   const int ty = (t / k.ntx) % k.nty;
   const int ch = t / (k.ntx * k.nty);
@@ -136,8 +145,29 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
   const int w = min(TXW, a.nx - x0);   // valid tile width (even)
   const int hgt = min(TY, a.ny - y0);  // valid tile height
   const bool second = ch >= k.nchunk1;
-  const int zs = second ? a.zlo2 + (ch - k.nchunk1) * k.zchunk2 : a.zlo + ch * k.zchunk;
-  const int ze = second ? min(a.zhi2, zs + k.zchunk2) : min(a.zhi, zs + k.zchunk);
+  const int zs = second ? a.zlo2 + (ch - k.nchunk1) * (a.zstride2 ? a.zstride2 : k.zchunk2)
+                        : a.zlo + ch * k.zchunk;
+  const int ze = second ? (a.zstride2 ? zs + k.zchunk2 : min(a.zhi2, zs + k.zchunk2)) : min(a.zhi, zs + k.zchunk);
+  if (second && a.wait_seq > 0) {
+    // single-launch slab step: this strip reads ghost planes that a neighbour is writing during this launch.
+    // One lane polls the arrival flag(s) (system scope, bounded); everybody else parks at the barrier.
+    if (threadIdx.x == 0) {
+      const long long* need[2] = {zs - 2 < 0 ? a.wait_lo : nullptr, ze + 2 > a.nz ? a.wait_hi : nullptr};
+      for (int q = 0; q < 2; ++q) {
+        if (!need[q]) continue;
+        int spins = 0;
+        while (__hip_atomic_load(need[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.wait_seq) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1 << 24)) {
+            __hip_atomic_store(a.wait_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // loads below must not be served from lines cached before arrival
+  }
   const int niter = (ze - zs) + 4;
   const int64_t plane = (int64_t)a.nx * a.ny;
   const uint32_t plane_bytes = (uint32_t)(plane * 8);
@@ -528,12 +558,14 @@ hipError_t launch_fused_t(const FdArgs& a, hipStream_t stream) {
   k.nchunk1 = (nzr + k.zchunk - 1) / k.zchunk;
   k.nchunk = k.nchunk1;
   k.zchunk2 = 1;
-  if (a.zhi2 > a.zlo2) {  // second range (slab mode: the two boundary strips in one launch): one chunk
+  if (a.zhi2 > a.zlo2) {  // second range (slab mode: the boundary strips in the same launch): nchunk2 chunks
     k.zchunk2 = a.zhi2 - a.zlo2;
-    k.nchunk += 1;
+    k.nchunk += a.zstride2 ? a.nchunk2 : 1;
   }
+  k.ntiles1 = xy * k.nchunk1;
   k.ntiles = xy * k.nchunk;
-  const int grid = ((k.ntiles + 7) / 8) * 8;
+  k.grid1 = ((k.ntiles1 + 7) / 8) * 8;
+  const int grid = k.grid1 + (k.ntiles - k.ntiles1);
   const size_t lds = sizeof(double) * (2 * (TY + 4) + 1) * PITCH;  // + dummy row
   if (a.phi)
     hipLaunchKernelGGL((ch_fd3d_fused_kernel<NW, S, DEPTH, true, NT>), dim3(grid), dim3(64 * NW), lds, stream, k);

@@ -224,7 +224,15 @@ int g_max_k2d = 4;  // pfk_set_tuning key 3: largest number of 2-D steps fused i
 // One FD step on planes [zlo, zhi) (and optionally [zlo2, zhi2): the second boundary strip of a slab, same launch) of the
 // current buffer into the other buffer; K > 1: K steps in one launch (2-D only).  Spectral scheme: one whole-domain
 // semi-implicit step, the plane ranges are ignored.
-int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 = 0, int zhi2 = 0) {
+struct StripWait {  // single-launch slab step: see FdArgs::wait_*
+  int zstride2, nchunk2;
+  const long long *lo, *hi;
+  long long seq;
+  int* timeout;
+};
+
+int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 = 0, int zhi2 = 0,
+                const StripWait* sw = nullptr) {
   if (h->sp) {
     std::pair<hipEvent_t, hipEvent_t>* e = nullptr;
     if (h->timing) {
@@ -260,10 +268,20 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 =
   if (impl == PF_KERNEL_AUTO) impl = ch_fd_fused_supported(a) ? PF_KERNEL_FUSED : PF_KERNEL_TWOPASS;
   if (impl == PF_KERNEL_FUSED && !ch_fd_fused_supported(a))
     return fail(h, PF_ERR_UNSUPPORTED, "fused FD kernel needs even nx and 16-byte aligned buffers");
+  if (sw && impl != PF_KERNEL_FUSED)
+    return fail(h, PF_ERR_UNSUPPORTED, "pf_step_slab_fused needs the fused FD kernel (even nx, 16-byte aligned buffers)");
   if (zhi2 > zlo2) {
     if (impl == PF_KERNEL_FUSED) {
       a.zlo2 = zlo2;  // both strips in one launch
       a.zhi2 = zhi2;
+      if (sw) {
+        a.zstride2 = sw->zstride2;
+        a.nchunk2 = sw->nchunk2;
+        a.wait_lo = sw->lo;
+        a.wait_hi = sw->hi;
+        a.wait_seq = sw->seq;
+        a.wait_timeout = sw->timeout;
+      }
     } else {          // two-pass fallback: one launch pair per strip
       int rc = launch_step(h, dt, zlo2, zhi2);
       if (rc) return rc;
@@ -763,6 +781,29 @@ int pf_step_finish(pf_handle* h) {
   }
   swap_buffers(h);
   h->step_open = false;
+  return PF_OK;
+}
+
+int pf_step_slab_fused(pf_handle* h, double dt, const int64_t* flag_lo, const int64_t* flag_hi, int64_t seq,
+                       int32_t* timeout) {
+  if (!h) return PF_ERR_INVALID;
+  if (!(dt > 0.0) || seq <= 0 || !timeout) return fail(h, PF_ERR_INVALID, "pf_step_slab_fused: need dt > 0, seq > 0, timeout");
+  if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: not in slab mode");
+  if (h->sf && !h->elim) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: this mode steps through pf_dist_begin / pf_dist_advance");
+  if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: a begin / finish step is open");
+  const int g = h->g.ghost, nz = h->g.nz;
+  if (nz - g <= g) return fail(h, PF_ERR_UNSUPPORTED, "pf_step_slab_fused: needs more than 2 * ghost planes per rank");
+  PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], h->g.plane, nz, g, h->g.zends, h->stream));  // walls (z-line only)
+  StripWait sw;
+  sw.zstride2 = nz - g;  // strips [0, g) and [nz - g, nz)
+  sw.nchunk2 = 2;
+  sw.lo = (h->g.zends & 1) ? nullptr : reinterpret_cast<const long long*>(flag_lo);
+  sw.hi = (h->g.zends & 2) ? nullptr : reinterpret_cast<const long long*>(flag_hi);
+  sw.seq = (long long)seq;
+  sw.timeout = timeout;
+  int rc = launch_step(h, dt, g, nz - g, 1, 0, g, &sw);  // interior chunks first, the two strips dispatched last
+  if (rc) return rc;
+  swap_buffers(h);
   return PF_OK;
 }
 

@@ -22,6 +22,15 @@ struct FdArgs {
   int zlo2, zhi2;     // optional second output range of the same launch (fused kernel only; empty if zhi2 <= zlo2)
   double ca, cb, two_rho, kh2, amh2, kphi;
   double gq, cbar;    // BM6 with phi eliminated: cnew += gq (c - cbar); gq == 0: off
+  // second range as SEVERAL chunks of (zhi2 - zlo2) planes, zstride2 apart (0: one chunk) -- the two boundary strips of
+  // a slab -- dispatched after all chunks of the first range; and, for the single-launch slab step, the arrival flags
+  // of the ghost planes: a second-range workgroup polls wait_lo / wait_hi (whichever its planes touch; null = no
+  // neighbour on that side) until it holds wait_seq, bounded, before it reads anything
+  int zstride2 = 0, nchunk2 = 1;
+  const long long* wait_lo = nullptr;
+  const long long* wait_hi = nullptr;
+  long long wait_seq = 0;
+  int* wait_timeout = nullptr;
 };
 
 // launchers (return hipError_t of the launch); all asynchronous on `stream`

@@ -88,6 +88,7 @@ SYMBOLS = {
     "pf_halo_layout_get": (C.c_int, [_H, C.POINTER(PfHaloLayout)]),
     "pf_step_begin": (C.c_int, [_H, C.c_double]),
     "pf_step_finish": (C.c_int, [_H]),
+    "pf_step_slab_fused": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_diagnostics": (C.c_int, [_H, _D]),
     "pf_diagnostics_local": (C.c_int, [_H, _D]),
     "pf_timing_enable": (C.c_int, [_H, C.c_int]),

@@ -264,6 +264,12 @@ class HipSlabEngine:
     def step_finish(self):
         self._ck(self._lib.pf_step_finish(self._h))
 
+    def step_fused(self, dt, flags, seq, timeout):
+        """one step in one launch; the boundary-strip workgroups poll flags[0] / flags[1] (int64 device tensor) for seq"""
+        self._ck(self._lib.pf_step_slab_fused(self._h, float(dt), C.c_void_p(flags.data_ptr()),
+                                              C.c_void_p(flags.data_ptr() + 8), int(seq),
+                                              C.c_void_p(timeout.data_ptr())))
+
     def diag_local(self):
         out = (C.c_double * 3)()
         self._ck(self._lib.pf_diagnostics_local(self._h, out))
@@ -371,7 +377,7 @@ class SlabSolver:
                 pf_step_finish  -> planes [0,2) and [nz-2,nz), buffer swap
     """
 
-    def __init__(self, engine, group=None, transport="rccl"):
+    def __init__(self, engine, group=None, transport="rccl", fused=False):
         import torch.distributed as dist
         self.dist = dist
         self.engine = engine
@@ -381,6 +387,11 @@ class SlabSolver:
         # "rccl": torch.distributed isend / irecv (any backend, incl. gloo in the CPU tests);
         # "ipc":  peer-mapped ghost planes written by a side-stream kernel (one node, IpcHaloTransport)
         self.transport = IpcHaloTransport(engine, group) if transport == "ipc" else None
+        # fused: one launch per step -- the boundary-strip workgroups wait for the neighbours' flags inside the kernel
+        # (pf_step_slab_fused); needs the flag words of the peer-copy transport
+        if fused and self.transport is None:
+            raise ValueError("SlabSolver(fused=True) needs transport='ipc'")
+        self.fused = bool(fused)
 
     def _post_exchange(self):
         if self.transport is not None:
@@ -410,7 +421,15 @@ class SlabSolver:
 
     def step(self, dt, nsteps=1):
         e = self.engine
-        for _ in range(nsteps):
+        for _ in range(nsteps if self.fused else 0):
+            tr = self.transport
+            with e.stream_context():
+                if not self.ghosts_fresh:
+                    tr.post()                 # fresh ghosts: the flags already hold tr.seq, the strips will not wait
+                e.step_fused(dt, tr.flags, tr.seq, tr.timeout)
+            self.ghosts_fresh = False
+            self.t += dt
+        for _ in range(0 if self.fused else nsteps):
             with e.stream_context():
                 reqs = [] if self.ghosts_fresh else self._post_exchange()
                 e.step_begin(dt)

@@ -1,7 +1,7 @@
 """One rank of a multi-process slab run on ONE GPU with the peer-copy halo transport (IpcHaloTransport): real HIP
 kernels, real inter-process ghost exchange (CUDA IPC), gloo only for bootstrap / reductions -- the 2- and 3-rank GPU
 coverage that RCCL cannot give on a 1-GPU box (it refuses two ranks on one device).
-Usage: python tests/ipc_slab_worker.py <out.npz> <bc>      (env: RANK WORLD_SIZE MASTER_*)"""
+Usage: python tests/ipc_slab_worker.py <out.npz> <bc> [fused]      (env: RANK WORLD_SIZE MASTER_*)"""
 import os
 import sys
 
@@ -24,7 +24,7 @@ def main():
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
     eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc)
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])
-    s = SlabSolver(eng, transport="ipc")
+    s = SlabSolver(eng, transport="ipc", fused=len(sys.argv) > 3 and sys.argv[3] == "fused")
     d0 = s.diagnostics()
     s.step(1e-3, 25)
     d1 = s.diagnostics()

@@ -616,11 +616,14 @@ def test_nccl_path_single_rank(lib):
     assert p.returncode == 0 and "NCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("world,bc", [(2, "periodic"), (3, "periodic"), (3, "mirror")])
-def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, world, bc, tmp_path):
+@pytest.mark.parametrize("world,bc,mode", [(2, "periodic", "split"), (3, "periodic", "split"), (3, "mirror", "split"),
+                                           (2, "periodic", "fused"), (3, "periodic", "fused"), (3, "mirror", "fused")])
+def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, world, bc, mode, tmp_path):
     """2 and 3 ranks as separate processes sharing the GPU: HipSlabEngine + SlabSolver(transport="ipc") -- ghost planes
     pushed into the neighbour's buffer through CUDA IPC, flag-ordered (pfk_push_planes / pfk_wait_flag); must equal the
-    whole-domain oracle bit for bit (27 steps, so every buffer parity and sequence number is exercised)."""
+    whole-domain oracle bit for bit (27 steps, so every buffer parity and sequence number is exercised).
+    mode "fused": one launch per step, the boundary-strip workgroups poll the arrival flags inside the kernel
+    (pf_step_slab_fused)."""
     import os
     import socket
     import subprocess
@@ -634,7 +637,7 @@ def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, w
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "ipc_slab_worker.py"), out, bc],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "ipc_slab_worker.py"), out, bc, mode],
                                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
