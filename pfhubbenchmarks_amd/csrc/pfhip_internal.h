@@ -79,8 +79,8 @@ const char* spectral_error(const Spectral* sp);
 
 // fused LDS-FFT spectral step for 2-D power-of-two grids (spectral2d_fused.hip); same spectrum layout as rocFFT D2Z
 struct Fused2D;
-bool fused2d_supported(int dim, int nx, int ny);
-int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream);
+bool fused2d_supported(int dim, int nx, int ny, int nz);  // 2-D power-of-two grids, or the 512^3 cube
+int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream);
 void fused2d_destroy(Fused2D* f);
 void fused2d_invalidate(Fused2D* f);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);

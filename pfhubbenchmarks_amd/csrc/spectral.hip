@@ -198,8 +198,8 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
     SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 2049));
     const char* e = getenv("PFHIP_SPECTRAL_2D");  // "rocfft" forces the library path (A/B comparison)
-    if (fused2d_supported(dim, nx, ny) && !(e && std::string(e) == "rocfft")) {
-      if (fused2d_create(&sp->fast, nx, ny, h, stream) != 0) {
+    if (fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e && std::string(e) == "rocfft")) {
+      if (fused2d_create(&sp->fast, nx, ny, sp->nz, h, stream) != 0) {
         sp->err = "fused2d_create failed";
         return -3;
       }

@@ -33,6 +33,8 @@ struct F2Args {
   int nx, ny, nxh, lgx, lgy;
   double ca, cb, two_rho;
   double dtM, dtMkappa, kx0, ky0, inv_n;
+  int nz = 1;        // 3-D path (512^3) only
+  double kz0 = 0.0;
 };
 
 __device__ __forceinline__ int brev(int i, int lg) { return (int)(__brev((unsigned)i) >> (32 - lg)); }
@@ -569,6 +571,117 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
   }
 }
 
+// =====================================================================================================================
+// 3-D (512^3): the same one-wave radix-8 transforms applied along y and along z of the [z][y][kx] half spectrum.
+// A workgroup owns 8 adjacent k_x columns (one full 128-byte line per row of the column) of one "batch" (a z-plane for
+// the y pass, a y-row for the z pass), moves them cooperatively with the column index fastest and stages them through
+// LDS; one wave transforms one column.  Passes per step (4 launches, 11.9 GB of traffic instead of rocFFT's ~18 GB):
+//   Z: forward z-FFT of G -> k-space update of the resident spectrum -> inverse z-FFT -> H      (MODE 2)
+//   Y: inverse y-FFT of H in place                                                              (MODE 1)
+//   X: f2_row512_kernel over all ny*nz rows: inverse x-FFT -> c stored -> f'(c) -> forward x-FFT -> G
+//   Y: forward y-FFT of G in place                                                              (MODE 0)
+// MODE 3 = forward z-FFT stored as the resident spectrum (initialisation).
+template <int MODE, int CW3>
+__global__ __launch_bounds__(64 * CW3, MODE == 2 ? 3 : 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
+                                                             double2* __restrict__ chat, double2* __restrict__ H,
+                                                             int64_t col_stride, int64_t batch_stride, int nblk,
+                                                             int nitems, const double2* __restrict__ twA_g,
+                                                             const double2* __restrict__ twB_g) {
+  __shared__ __attribute__((aligned(16))) double2 Lall[CW3 * W8C];
+  constexpr int N = 512, NT = 64 * CW3, PER = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double2* L = Lall + wave * W8C + 4 * wave;
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  auto nat = [](int n) { return n + (n >> 3); };
+  const int ci = tid % CW3;
+  double2* Lc = Lall + ci * W8C + 4 * ci;
+  double2 twN[7], twB[7], v[8], ch[PER];
+  load_tw(twN, twA_g, lane);
+  load_tw(twB, twB_g, lane & 7);
+  // One work item (batch b, block of CW3 k_x columns) per workgroup.  (A persistent, software-pipelined form -- next
+  // item's loads in flight during the transforms -- was measured and is slower: 3.85 vs 3.25 ms per step; its extra 32
+  // VGPRs cost a wave per SIMD, and short-lived workgroups already overlap through the dispatcher.)
+  // CW3 = 4: a 128-byte line holds two items' columns; items i and i + 8 are taken by workgroups on the same XCD back
+  // to back (round-robin dispatch), so give THEM the two halves of one line.
+  {
+    const int item = blockIdx.x;
+    int lb = item;
+    if (CW3 == 4) {
+      const int grp = lb >> 4, r = lb & 15;
+      if ((grp << 4) + 16 <= nitems) lb = (grp << 4) + ((r & 7) << 1) + (r >> 3);  // ragged last group: identity
+    }
+    const int b = lb / nblk, kx = (lb % nblk) * CW3 + ci;
+    const bool on = kx < a.nxh;
+    const int64_t base = (int64_t)b * batch_stride + kx;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int r = (tid + NT * i) / CW3;
+      v[i] = on ? A[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) Lc[nat((tid + NT * i) / CW3)] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
+    if (MODE == 1)
+      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+    else
+      fft512_wave<-1>(v, L, lane, twN, twB, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
+    if (MODE == 2) {  // the resident spectrum is fetched only now: holding it across the transform costs a wave per SIMD
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int r = (tid + NT * i) / CW3;
+        ch[i] = on ? chat[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+      }
+    }
+    __syncthreads();
+    if (MODE == 0 || MODE == 1 || MODE == 3) {
+      double2* dst = MODE == 3 ? chat : A;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int r = (tid + NT * i) / CW3;
+        if (on) dst[base + (int64_t)r * col_stride] = Lc[nat(r)];
+      }
+    } else {
+      // MODE 2: this is the z pass -- b is the y index, the row along the column is k_z
+      const int my = 2 * b > a.ny ? b - a.ny : b;
+      const double kxv = a.kx0 * kx, kyv = a.ky0 * my;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int kz = (tid + NT * i) / CW3;
+        const int mz = 2 * kz > N ? kz - N : kz;
+        const double kzv = a.kz0 * mz;
+        const double k2 = (kxv * kxv + kyv * kyv) + kzv * kzv;  // same grouping as spectral.hip's ksq
+        const double num = a.dtM * k2;
+        const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+        const double2 gh = Lc[nat(kz)];
+        double2 r;
+        r.x = fma(-num, gh.x, ch[i].x) * den;
+        r.y = fma(-num, gh.y, ch[i].y) * den;
+        if (on) chat[base + (int64_t)kz * col_stride] = r;
+        Lc[nat(kz)] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
+      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int r = (tid + NT * i) / CW3;
+        if (on) H[base + (int64_t)r * col_stride] = Lc[nat(r)];
+      }
+    }
+  }
+}
+
+int g_cw3 = 8;  // k_x columns per workgroup of the 3-D column passes (PFHIP_FFT3D_CW = 4 | 8); 8: 2.95 ms, 4: 3.15 ms
 int g_col512_direct = 1;  // measured: direct, 1 column per workgroup 13.05 us/step; staged 13.9 (PFHIP_FFT512_DIRECT=0)
 int g_cw512 = 1;          // columns per workgroup (PFHIP_FFT512_CW = 1 | 2 | 4 | 8; 8: staged kernel only)
 
@@ -585,21 +698,29 @@ struct Fused2D {
   double2 *twx = nullptr, *twy = nullptr;
   double2 *tw8a = nullptr, *tw8b = nullptr;  // radix-8 tables of the 512-point fast path
   bool row512 = false, col512 = false;
+  bool cube512 = false;  // 3-D 512^3: x rows by f2_row512_kernel, y / z columns by f3_col512_kernel
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
   bool g_valid = false;  // G holds the row transform of f'(current c)
 };
 
-bool fused2d_supported(int dim, int nx, int ny) {
+bool fused2d_supported(int dim, int nx, int ny, int nz) {
+  if (dim == 3) {
+    const char* e = getenv("PFHIP_SPECTRAL_3D");  // "rocfft" forces the library path (A/B comparison)
+    return nx == 512 && ny == 512 && nz == 512 && !(e && std::string(e) == "rocfft");
+  }
   const int lx = ilog2(nx), ly = ilog2(ny);
   return dim == 2 && lx >= 7 && lx <= 10 && ly >= 7 && ly <= 10;
 }
 
-int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream) {
+int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream) {
   Fused2D* f = new Fused2D();
   *out = f;
   f->stream = stream;
   F2Args& a = f->a;
+  f->cube512 = nz > 1;
+  a.nz = nz;
+  a.kz0 = nz > 1 ? TWO_PI_F / (nz * h) : 0.0;
   a.nx = nx;
   a.ny = ny;
   a.nxh = nx / 2 + 1;
@@ -607,7 +728,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream) 
   a.lgy = ilog2(ny);
   a.kx0 = TWO_PI_F / (nx * h);
   a.ky0 = TWO_PI_F / (ny * h);
-  a.inv_n = 1.0 / ((double)nx * ny);
+  a.inv_n = 1.0 / ((double)nx * ny * nz);
   auto table = [&](int N, double2** dev) -> hipError_t {
     std::vector<double2> t(N / 2);
     for (int k = 0; k < N / 2; ++k) {
@@ -621,9 +742,11 @@ int fused2d_create(Fused2D** out, int nx, int ny, double h, hipStream_t stream) 
   if (table(nx, &f->twx) != hipSuccess || table(ny, &f->twy) != hipSuccess) return -3;
   const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
   const bool allow8 = !(e && std::string(e) == "radix2");
-  f->row512 = allow8 && nx == 512 && (ny / 2) % RW == 0;
-  f->col512 = allow8 && ny == 512;
+  f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
+  f->col512 = (allow8 || f->cube512) && ny == 512;
   if (const char* d = getenv("PFHIP_FFT512_DIRECT")) g_col512_direct = std::atoi(d) != 0;
+  if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : 8;
+
   if (const char* cw = getenv("PFHIP_FFT512_CW")) {
     const int c = std::atoi(cw);
     if (c == 1 || c == 2 || c == 4 || c == 8) g_cw512 = c;
@@ -704,9 +827,43 @@ void launch_col(const Fused2D* f, const F2Args& a, const double2* G, double2* ch
 }
 }  // namespace
 
+namespace {
+// 3-D passes (512^3).  Rows: f2_row512_kernel over ny*nz/2 row pairs (its row index is the flattened (z, y) index).
+void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
+                 int from_spectrum, int use_fprime) {
+  hipLaunchKernelGGL(f2_row512_kernel, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
+                     (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
+}
+template <int MODE, int CW3>
+void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
+  const int nblk = (a.nxh + CW3 - 1) / CW3;
+  const int64_t row = a.nxh, plane = (int64_t)a.nxh * a.ny;
+  // axis 1: columns along y (stride one x-row), one batch per z-plane; axis 2: columns along z, one batch per y-row
+  const int64_t col_stride = axis == 1 ? row : plane, batch_stride = axis == 1 ? plane : row;
+  const int nbatch = axis == 1 ? a.nz : a.ny;
+  const int nitems = nblk * nbatch;
+  hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
+                     col_stride, batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b);
+}
+template <int MODE>
+void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
+  if (g_cw3 == 4)
+    launch_col3_t<MODE, 4>(f, a, A, chat, H, axis);
+  else
+    launch_col3_t<MODE, 8>(f, a, A, chat, H, axis);
+}
+}  // namespace
+
 // chat <- 2-D spectrum of c (same as a rocFFT D2Z); G is clobbered
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   const F2Args& a = f->a;
+  if (f->cube512) {
+    launch_row3(f, a, nullptr, c, nullptr, G, 0, 0);
+    launch_col3<0>(f, a, G, nullptr, nullptr, 1);
+    launch_col3<3>(f, a, G, chat, nullptr, 2);
+    f->g_valid = false;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   launch_row(f, a, nullptr, c, nullptr, G, 0, 0);
   launch_col(f, a, G, chat, nullptr, 1);
   f->g_valid = false;
@@ -722,6 +879,18 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
   a.two_rho = two_rho;
   a.dtM = dt * M;
   a.dtMkappa = dt * M * kappa;
+  if (f->cube512) {
+    if (!f->g_valid) {  // x- and y-transform of f'(c_in) (first step, or after the field was replaced)
+      launch_row3(f, a, nullptr, c_in, nullptr, G, 0, 1);
+      launch_col3<0>(f, a, G, nullptr, nullptr, 1);
+    }
+    launch_col3<2>(f, a, G, chat, H, 2);        // z: forward, k-space update of chat, inverse -> H
+    launch_col3<1>(f, a, H, nullptr, nullptr, 1);  // y: inverse, in place
+    launch_row3(f, a, H, nullptr, c_out, G, 1, 1);  // x: inverse -> c_out, f'(c_out), forward -> G
+    launch_col3<0>(f, a, G, nullptr, nullptr, 1);  // y: forward, in place (ready for the next step's z pass)
+    f->g_valid = true;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   if (!f->g_valid)  // row transform of f'(c_in) (first step, or after the field was replaced)
     launch_row(f, a, nullptr, c_in, nullptr, G, 0, 1);
   launch_col(f, a, G, chat, H, 0);

@@ -316,6 +316,39 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape):
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
 
 
+def test_spectral_512cubed_lds_fft_passes_equal_the_rocfft_path(lib):
+    """512^3 semi-implicit spectral step: the hand-written passes (x rows by f2_row512_kernel, y and z columns by
+    f3_col512_kernel, 4 launches per step) against the rocFFT path of the same library (PFHIP_SPECTRAL_3D=rocfft, itself
+    checked against the numpy oracle at small sizes above) on the same random field: fields to 1e-12, diagnostics to
+    1e-12, mass conserved, rollback consistent."""
+    import os
+    rng = np.random.default_rng(77)
+    c0 = 0.5 + 0.05 * rng.standard_normal((512, 512, 512))
+    out = {}
+    for name, env in (("lds", None), ("rocfft", "rocfft")):
+        os.environ.pop("PFHIP_SPECTRAL_3D", None)
+        if env:
+            os.environ["PFHIP_SPECTRAL_3D"] = env
+        try:
+            with PhaseFieldSolver(dim=3, n=512, h=1.0, scheme="spectral") as s:
+                s.set_c(c0)
+                d0 = s.diagnostics()
+                s.step(1e-2, 4)
+                d1 = s.diagnostics()
+                s.step(1e-2, 1)
+                s.rollback()
+                d2 = s.diagnostics()
+                out[name] = (s.get_c(), d0, d1, d2)
+        finally:
+            os.environ.pop("PFHIP_SPECTRAL_3D", None)
+    a, b = out["lds"], out["rocfft"]
+    assert np.abs(a[0] - b[0]).max() <= 1e-12
+    for k in (1, 2, 3):
+        assert abs(a[k][0] - b[k][0]) <= 1e-12 * abs(b[k][0]) and abs(a[k][1] - b[k][1]) <= 1e-13 * abs(b[k][1])
+    assert abs(a[2][1] - a[1][1]) <= 1e-12 * abs(a[1][1])          # mass conserved
+    assert abs(a[3][0] - a[2][0]) <= 1e-12 * abs(a[2][0])          # rollback restores the state before the last step
+
+
 def test_bench1_driver_rows_against_fixture_and_oracle(lib, orc, golden_dir, tmp_path):
     """bench1 driver end to end on the GPU (first rows): CSV format identical to the reference's, rows at the
     fixture's times, values = the FD oracle's to 1e-12 and within the documented physical distance of the fixture."""
