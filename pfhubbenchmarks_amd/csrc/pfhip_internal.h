@@ -83,6 +83,7 @@ bool fused2d_supported(int dim, int nx, int ny, int nz);  // 2-D power-of-two gr
 int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream);
 void fused2d_destroy(Fused2D* f);
 void fused2d_invalidate(Fused2D* f);
+int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
                  double M, double kappa, double ca, double cb, double two_rho);

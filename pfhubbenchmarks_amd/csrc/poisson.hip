@@ -101,6 +101,7 @@ struct Poisson {
   bool have_plans = false;
   double* rhs = nullptr;
   double2* ph = nullptr;
+  Fused2D* fast = nullptr;  // 512^3 periodic box: hand-written LDS-FFT passes (spectral2d_fused.hip) instead of rocFFT
   std::string err;
 };
 
@@ -154,6 +155,11 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
     PO_FFT(hipfftSetStream(po->inv, stream));
     PO_HIP(hipMalloc(&po->ph, sizeof(double2) * po->nh));
     if (npx > 0) PO_HIP(hipMalloc(&po->rhs, sizeof(double) * po->n));
+    if (npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz) &&
+        fused2d_create(&po->fast, nx, ny, a.nz, h, stream) != 0) {
+      po->err = "fused2d_create failed";
+      return -3;
+    }
     return 0;
   };
   int rc = body();
@@ -169,6 +175,7 @@ void poisson_destroy(Poisson* po) {
   }
   if (po->rhs) (void)hipFree(po->rhs);
   if (po->ph) (void)hipFree(po->ph);
+  if (po->fast) fused2d_destroy(po->fast);
   delete po;
 }
 
@@ -181,6 +188,11 @@ int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream)
     hipLaunchKernelGGL(invert_laplacian_kernel, dim3(grid_for_p(po->nh)), dim3(256), 0, stream, po->ph, po->nh, a, 0);
     PO_FFT(hipfftExecZ2D(po->inv, reinterpret_cast<hipfftDoubleComplex*>(po->ph), phi));
     hipLaunchKernelGGL(fixup_dirichlet_kernel, dim3(grid_for_p(po->n)), dim3(256), 0, stream, phi, a);
+  } else if (po->fast) {
+    if (fused3d_poisson(po->fast, c, phi, po->ph, a.k_over_eps, a.inv_h2) != 0) {
+      po->err = "fused3d_poisson launch failed";
+      return -3;
+    }
   } else {
     PO_FFT(hipfftExecD2Z(po->fwd, const_cast<double*>(c), reinterpret_cast<hipfftDoubleComplex*>(po->ph)));
     hipLaunchKernelGGL(invert_laplacian_kernel, dim3(grid_for_p(po->nh)), dim3(256), 0, stream, po->ph, po->nh, a, 1);

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
       c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
       c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
     }
+    if (from_spectrum == 2) return;  // inverse only (Poisson solve): no forward transform of the result
     m = T;
 #pragma unroll
     for (int q = 0; q < 7; ++q) twN[q] = twT[q];
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
 //   Y: forward y-FFT of G in place                                                              (MODE 0)
 // MODE 3 = forward z-FFT stored as the resident spectrum (initialisation).
 template <int MODE, int CW3>
-__global__ __launch_bounds__(64 * CW3, MODE == 2 ? 3 : 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
+__global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
                                                              double2* __restrict__ chat, double2* __restrict__ H,
                                                              int64_t col_stride, int64_t batch_stride, int nblk,
                                                              int nitems, const double2* __restrict__ twA_g,
@@ -638,7 +639,33 @@ __global__ __launch_bounds__(64 * CW3, MODE == 2 ? 3 : 4) void f3_col512_kernel(
       }
     }
     __syncthreads();
-    if (MODE == 0 || MODE == 1 || MODE == 3) {
+    if (MODE == 4) {
+      // Poisson solve, z pass: multiply by 1 / eigenvalue of the 7-point Laplacian (tables sym[0..512) per axis hold
+      // 2 cos(2 pi m / n) - 2; `chat` carries the three tables back to back), zero mode -> 0; then inverse z in place
+      const double* sym = reinterpret_cast<const double*>(chat);
+      const double cxy = sym[kx < a.nxh ? kx : 0] + sym[N + b];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int kz = (tid + NT * i) / CW3;
+        const double lam = (cxy + sym[2 * N + kz]) * a.dtM;          // dtM = 1 / h^2 here
+        const double sc = (kx == 0 && b == 0 && kz == 0) ? 0.0 : (a.inv_n / lam) * a.dtMkappa;  // dtMkappa = -k / eps
+        const double2 gh = Lc[nat(kz)];
+        Lc[nat(kz)] = make_double2(gh.x * sc, gh.y * sc);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
+      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int r = (tid + NT * i) / CW3;
+        if (on) A[base + (int64_t)r * col_stride] = Lc[nat(r)];
+      }
+    } else if (MODE == 0 || MODE == 1 || MODE == 3) {
       double2* dst = MODE == 3 ? chat : A;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
@@ -698,6 +725,7 @@ struct Fused2D {
   double2 *twx = nullptr, *twy = nullptr;
   double2 *tw8a = nullptr, *tw8b = nullptr;  // radix-8 tables of the 512-point fast path
   bool row512 = false, col512 = false;
+  double* sym = nullptr;  // 512^3 Poisson: 3 x 512 doubles, 2 cos(2 pi m / n) - 2 per axis
   bool cube512 = false;  // 3-D 512^3: x rows by f2_row512_kernel, y / z columns by f3_col512_kernel
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
@@ -784,6 +812,7 @@ void fused2d_destroy(Fused2D* f) {
   if (f->twy) (void)hipFree(f->twy);
   if (f->tw8a) (void)hipFree(f->tw8a);
   if (f->tw8b) (void)hipFree(f->tw8b);
+  if (f->sym) (void)hipFree(f->sym);
   delete f;
 }
 
@@ -853,6 +882,29 @@ void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, d
     launch_col3_t<MODE, 8>(f, a, A, chat, H, axis);
 }
 }  // namespace
+
+// 512^3 periodic Poisson solve lap_h(phi) = -(k/eps) c with the same passes: x forward, y forward, z (forward, divide
+// by the Laplacian's eigenvalue, inverse), y inverse, x inverse only.  W: nh complex work array.
+int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2) {
+  if (!f->cube512) return -3;
+  if (!f->sym) {
+    std::vector<double> t(3 * 512);
+    for (int d = 0; d < 3; ++d)
+      for (int m = 0; m < 512; ++m) t[d * 512 + m] = 2.0 * std::cos(TWO_PI_F * m / 512.0) - 2.0;
+    if (hipMalloc(&f->sym, sizeof(double) * t.size()) != hipSuccess ||
+        hipMemcpy(f->sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice) != hipSuccess)
+      return -3;
+  }
+  F2Args a = f->a;
+  a.dtM = inv_h2;
+  a.dtMkappa = -k_over_eps;
+  launch_row3(f, a, nullptr, c, nullptr, W, 0, 0);
+  launch_col3<0>(f, a, W, nullptr, nullptr, 1);
+  launch_col3<4>(f, a, W, reinterpret_cast<double2*>(f->sym), nullptr, 2);
+  launch_col3<1>(f, a, W, nullptr, nullptr, 1);
+  launch_row3(f, a, W, nullptr, phi, nullptr, 2, 0);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 
 // chat <- 2-D spectrum of c (same as a rocFFT D2Z); G is clobbered
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {

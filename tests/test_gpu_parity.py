@@ -349,6 +349,33 @@ def test_spectral_512cubed_lds_fft_passes_equal_the_rocfft_path(lib):
     assert abs(a[3][0] - a[2][0]) <= 1e-12 * abs(a[2][0])          # rollback restores the state before the last step
 
 
+def test_bm6_512cubed_poisson_lds_fft_passes_equal_the_rocfft_path(lib):
+    """BM6 in the 512^3 periodic box: the Poisson solve by the hand-written passes (x, y, z with the division by the
+    7-point Laplacian's eigenvalue, y, x) against the rocFFT solve of the same library (checked against the numpy
+    oracle at small sizes in test_bm6_periodic_box_3d): phi to 1e-12, then two coupled steps."""
+    import os
+    rng = np.random.default_rng(78)
+    c0 = 0.5 + 0.04 * rng.standard_normal((512, 512, 512))
+    out = {}
+    for name, env in (("lds", None), ("rocfft", "rocfft")):
+        os.environ.pop("PFHIP_SPECTRAL_3D", None)
+        if env:
+            os.environ["PFHIP_SPECTRAL_3D"] = env
+        try:
+            with PhaseFieldSolver(dim=3, n=512, h=1.0, model="bm6") as s:
+                s.set_c(c0)
+                phi = s.get_phi()
+                s.step(5e-4, 2)
+                out[name] = (phi, s.get_c(), s.diagnostics())
+        finally:
+            os.environ.pop("PFHIP_SPECTRAL_3D", None)
+    a, b = out["lds"], out["rocfft"]
+    assert np.abs(b[0]).max() > 1e-5 and abs(b[0].mean()) < 1e-15
+    assert np.abs(a[0] - b[0]).max() <= 1e-11 * np.abs(b[0]).max()
+    assert np.abs(a[1] - b[1]).max() <= 1e-12
+    assert abs(a[2][0] - b[2][0]) <= 1e-12 * abs(b[2][0]) and abs(a[2][2] - b[2][2]) <= 1e-10 * abs(b[2][2])
+
+
 def test_bench1_driver_rows_against_fixture_and_oracle(lib, orc, golden_dir, tmp_path):
     """bench1 driver end to end on the GPU (first rows): CSV format identical to the reference's, rows at the
     fixture's times, values = the FD oracle's to 1e-12 and within the documented physical distance of the fixture."""
