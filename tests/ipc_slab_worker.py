@@ -19,7 +19,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n = (128, 24, 18) if bc == "periodic" else (65, 13, 18)
+    nzg = int(os.environ.get("PF_TEST_NZ", "18"))
+    n = (128, 24, nzg) if bc == "periodic" else (65, 13, nzg)
     rng = np.random.default_rng(41)
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
     eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc)
@@ -31,9 +32,13 @@ def main():
     s.step(1e-3, 2)               # steps right after diagnostics re-use the fresh ghosts
     eng.sync()
     s.transport.check()
-    field = s.gather_field()
-    if rank == 0:
-        np.savez(out, field=field, d0=np.array(d0), d1=np.array(d1), full=full)
+    if nzg % world == 0:
+        field = s.gather_field()
+        if rank == 0:
+            np.savez(out, field=field, d0=np.array(d0), d1=np.array(d1), full=full)
+    else:          # unequal slabs: every rank reports its own planes
+        np.savez(out + ".rank%d.npz" % rank, local=eng.get_local(), z0=eng.z0, d0=np.array(d0), d1=np.array(d1),
+                 full=full)
     dist.barrier()
     eng.close()
     dist.destroy_process_group()

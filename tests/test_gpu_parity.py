@@ -724,6 +724,45 @@ def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, w
     np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
 
 
+def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
+    """20 planes over 3 ranks (7 + 7 + 6): the neighbours' buffers have different sizes and time-level offsets, which
+    the peer-copy transport must take from the neighbour's own layout (fused single-launch step)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = str(tmp_path / "res")
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PF_TEST_NZ="20")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "ipc_slab_worker.py"), out,
+                                       "periodic", "fused"], env=env, cwd=root, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+    parts = [np.load(out + ".rank%d.npz" % r) for r in range(3)]
+    e = parts[0]["full"]
+    assert [int(p["z0"]) for p in parts] == [0, 7, 14] and [p["local"].shape[0] for p in parts] == [7, 7, 6]
+    for _ in range(27):
+        e = orc.fd_step(e, 1e-3)
+    for p in parts:
+        z0 = int(p["z0"])
+        np.testing.assert_array_equal(p["local"], e[z0:z0 + p["local"].shape[0]])
+
+
 def test_bench_contract_json_line():
     """bench.py prints exactly one JSON line with the fields the driver reads (short run of the default workload)"""
     import json
