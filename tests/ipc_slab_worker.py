@@ -25,13 +25,18 @@ def main():
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
     eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc)
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])
-    s = SlabSolver(eng, transport="ipc", fused=len(sys.argv) > 3 and sys.argv[3] == "fused")
+    mode = sys.argv[3] if len(sys.argv) > 3 else "split"
+    if mode == "p2p":             # torch.distributed isend / irecv of the GPU ghost planes (gloo stages them on the host)
+        s = SlabSolver(eng, transport="rccl")
+    else:
+        s = SlabSolver(eng, transport="ipc", fused=mode == "fused")
     d0 = s.diagnostics()
     s.step(1e-3, 25)
     d1 = s.diagnostics()
     s.step(1e-3, 2)               # steps right after diagnostics re-use the fresh ghosts
     eng.sync()
-    s.transport.check()
+    if s.transport is not None:
+        s.transport.check()
     if nzg % world == 0:
         field = s.gather_field()
         if rank == 0:

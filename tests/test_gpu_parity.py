@@ -677,13 +677,16 @@ def test_nccl_path_single_rank(lib):
 
 
 @pytest.mark.parametrize("world,bc,mode", [(2, "periodic", "split"), (3, "periodic", "split"), (3, "mirror", "split"),
-                                           (2, "periodic", "fused"), (3, "periodic", "fused"), (3, "mirror", "fused")])
+                                           (2, "periodic", "fused"), (3, "periodic", "fused"), (3, "mirror", "fused"),
+                                           (2, "periodic", "p2p"), (3, "mirror", "p2p")])
 def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, world, bc, mode, tmp_path):
     """2 and 3 ranks as separate processes sharing the GPU: HipSlabEngine + SlabSolver(transport="ipc") -- ghost planes
     pushed into the neighbour's buffer through CUDA IPC, flag-ordered (pfk_push_planes / pfk_wait_flag); must equal the
     whole-domain oracle bit for bit (27 steps, so every buffer parity and sequence number is exercised).
     mode "fused": one launch per step, the boundary-strip workgroups poll the arrival flags inside the kernel
-    (pf_step_slab_fused)."""
+    (pf_step_slab_fused).  mode "p2p": the DEFAULT exchange code (batch_isend_irecv of the GPU ghost planes, the path
+    RCCL serves on a multi-GPU node) over gloo -- two ranks, so both neighbours are the same peer and the message
+    order matters."""
     import os
     import socket
     import subprocess
