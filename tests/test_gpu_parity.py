@@ -727,6 +727,36 @@ def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, w
     np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
 
 
+@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim"])
+def test_multi_process_fft_slab_modes_on_one_gpu(lib, mode):
+    """the slab-FFT modes with TWO ranks as separate processes sharing the GPU: real engines, the library's request
+    protocol (pf_dist_begin / pf_dist_advance) served by gloo collectives on the GPU tensors (all_to_all_single + ghost
+    exchange); rank 0 compares the gathered field with the single-domain solver (1e-12)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "fft_slab_gpu_worker.py"), mode],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs) and "FFT_SLAB_GPU_OK" in logs[0], "\n".join(l[-2000:] for l in logs)
+
+
 def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
     """20 planes over 3 ranks (7 + 7 + 6): the neighbours' buffers have different sizes and time-level offsets, which
     the peer-copy transport must take from the neighbour's own layout (fused single-launch step)."""
