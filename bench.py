@@ -192,6 +192,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # REHEARSAL ONLY (tests/test_gpu_parity.py): run the N > 1 launch contract on a 1-GPU box -- every rank on device 0,
+    # gloo instead of RCCL (which refuses two ranks on one device).  The numbers of such a run mean nothing.
+    rehearsal = os.environ.get("PFHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
@@ -255,7 +260,10 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
         from pfhubbenchmarks_amd.solver import FFTSlabSolver, HipFFTSlabEngine
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if scheme == "spectral" or model == "bm6":
             eng = HipFFTSlabEngine(gn, h, world, rank, local_rank, scheme=scheme, model=model, eliminate_phi=elim)
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
@@ -307,7 +315,7 @@ def main():
     if not per_launch_events:
         k_ms, k_launches = el / a.steps * 1e3, a.steps
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     F1, C1, _ = solver.diagnostics()
@@ -328,7 +336,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
                    "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
-                   "parallelism": "slab%d%s%s" % (world, "-forced" if a.slab else "",
+                   "parallelism": "slab%d%s%s%s" % (world, "-forced" if a.slab else "", "-REHEARSAL-one-device-gloo" if rehearsal else "",
                                                   ("-ipc-fused" if a.fused_slab else "-ipc")
                                                   if (dist is not None and a.transport == "ipc") else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

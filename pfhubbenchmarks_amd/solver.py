@@ -393,9 +393,18 @@ class SlabSolver:
             raise ValueError("SlabSolver(fused=True) needs transport='ipc'")
         self.fused = bool(fused)
 
+    def _host_ordered(self):
+        """RCCL collectives are ordered after the kernels already queued on the current stream.  Any other backend
+        (gloo in the tests and in the 1-GPU rehearsal of the multi-rank launch) reads GPU tensors from the host side
+        whenever it likes, so the engine's stream has to drain first -- correctness only, never on the RCCL path."""
+        e = self.engine
+        if getattr(e, "device", None) is not None and self.dist.get_backend(self.group) != "nccl":
+            e.sync()
+
     def _post_exchange(self):
         if self.transport is not None:
             return self.transport.post()
+        self._host_ordered()
         dist, e = self.dist, self.engine
         g, nz = e.ghost, e.nz
         buf = e.buffers[e.cur]
@@ -549,6 +558,7 @@ class FFTSlabSolver(SlabSolver):
         self._mean_set = False
 
     def _halo(self, buf):
+        self._host_ordered()
         dist, e = self.dist, self.engine
         g, nz = e.ghost, e.nz
         ops = [dist.P2POp(dist.isend, buf[nz:nz + g], e.rank_hi, self.group, 1),
@@ -567,6 +577,7 @@ class FFTSlabSolver(SlabSolver):
                 if req[0] == "done":
                     break
                 if req[0] == "alltoall":
+                    self._host_ordered()
                     self.dist.all_to_all_single(req[1], req[2], group=self.group)
                 else:
                     for buf in req[1]:

@@ -796,6 +796,36 @@ def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
         np.testing.assert_array_equal(p["local"], e[z0:z0 + p["local"].shape[0]])
 
 
+def test_bench_multi_rank_launch_contract_rehearsal():
+    """The driver's N > 1 command line (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2) on the
+    1-GPU box: both ranks on device 0 over gloo (PFHIP_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).
+    Checks the launch contract only: env parsing, one JSON line from rank 0, whole-job value, weak scaling grid."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, PFHIP_BENCH_REHEARSAL="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "6", "--warmup", "3"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["grid"] == [512, 512, 1024] and "REHEARSAL" in d["config"]["parallelism"]
+    assert abs(d["value"] - 512 ** 3 * 2 * 6 / (d["ms_per_step"] * 1e-3 * 6)) <= 1e-6 * d["value"]
+    assert d["check"]["C_rel_drift"] < 1e-12 and d["check"]["F_after"] < d["check"]["F_before"]
+    assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None
+
+
 def test_bench_contract_json_line():
     """bench.py prints exactly one JSON line with the fields the driver reads (short run of the default workload)"""
     import json
