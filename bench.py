@@ -14,6 +14,7 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
                 GPUs (512 x 512 x 512 N box, slab FFT: one RCCL all-to-all each way per transform)
   bm6_fd_512c / _256c   BM6 (BASELINE.json config 5) in a periodic box: FFT Poisson solve + coupled fused FD step per
                 step; N > 1: slab FFT Poisson (2 all-to-alls) + ghost exchange of c and phi
+  bm6_spectral_512c     BM6 with the semi-implicit spectral scheme (phi eliminated in Fourier space; 1 GPU)
   bm6_fd_512c_elim      the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c) exactly): the step is
                 the fused kernel alone, no transform in the time loop (phi is solved only for diagnostics)
   bm1_fem_be    BASELINE.json config 1: the reference's own algorithm (100x100 crossed P1 mesh, backward Euler, Newton)
@@ -164,7 +165,7 @@ def main():
                     help="default 50: the first ~25 steps after an idle GPU run 30 %% slower (tools/cold_start_ramp.py); "
                          "bm1_fem_be: 10")
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
-                             "bm1_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
+                             "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
@@ -231,6 +232,13 @@ def main():
         nn = 512 if a.workload.endswith("512c") else 256
         dim, gn, scaling = 3, (nn, nn, nn * world), "weak"
         dt = 5e-4
+    elif a.workload == "bm6_spectral_512c":
+        # BM6 with the spectral scheme: phi eliminated in Fourier space, same passes as bm1_spectral_512c (one GPU)
+        scheme, model, bytes_per_cell = "spectral", "bm6", 72.0
+        dim, gn, scaling = 3, (512, 512, 512), "weak"
+        dt = 1e-2
+        if world > 1:
+            sys.exit("bm6_spectral_512c is single-GPU")
     elif a.workload == "bm1_spectral_512c":
         scheme, bytes_per_cell = "spectral", 72.0
         dim, gn, scaling = 3, (512, 512, 512 * world), "weak"

@@ -321,7 +321,7 @@ int run_diag(pf_handle* h, double raw[6]) {
   }
   if (h->sf && h->cfg.scheme == PF_SCHEME_SPECTRAL_SI && !h->chat_valid)
     return fail(h, PF_ERR_STATE, "slab spectral: run pf_dist_begin(PF_DIST_OP_REFRESH) before diagnostics");
-  const double* phi = h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr;
+  const double* phi = h->cfg.model == PF_MODEL_BM6 ? h->phi : nullptr;  // null for BM6 + spectral (see below)
   PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], h->g.plane, h->g.nz, h->g.ghost, h->g.zends, h->stream));
   PF_HIP(h, launch_diag(h->c[h->cur], phi, h->g.nx, h->g.ny, h->g.nz, h->g.ghost, h->g.zwrap, h->g.zends, c.rho_s,
                         c.c_alpha, c.c_beta, h->partials, h->out6_dev, h->stream));
@@ -341,6 +341,8 @@ int run_diag(pf_handle* h, double raw[6]) {
     // (slab mode: this rank's share of the k-space sum, normalised by the GLOBAL lattice size)
     const int64_t n = h->g.plane * (int64_t)h->g.nzg;
     raw[2] = h->out6_host[6] / (double)n * (h->cfg.h * h->cfg.h);
+    // BM6 + spectral: sum_x c phi = (k/eps) / N * sum_{k != 0} w |c_k|^2 / k^2 (Parseval, phi_k = (k/eps) c_k / k^2)
+    if (h->sp && h->cfg.model == PF_MODEL_BM6) raw[3] = (h->cfg.k / h->cfg.eps_r) / (double)n * h->out6_host[7];
   }
   return PF_OK;
 }
@@ -455,8 +457,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     return fail(nullptr, PF_ERR_INVALID, "PF_FLAG_BM6_ELIMINATE_PHI: BM6, periodic box, FD scheme only");
   if ((cfg->ext_a2a[0] == nullptr) != (cfg->ext_a2a[1] == nullptr))
     return fail(nullptr, PF_ERR_INVALID, "ext_a2a: give both buffers or none");
-  if (cfg->model == PF_MODEL_BM6 && cfg->scheme == PF_SCHEME_SPECTRAL_SI)
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "BM6 is implemented for the FD and FEM_BE schemes");
+  if (cfg->model == PF_MODEL_BM6 && cfg->scheme == PF_SCHEME_SPECTRAL_SI &&
+      (cfg->bc != PF_BC_PERIODIC || cfg->nranks > 1 || cfg->force_slab == 1))
+    return fail(nullptr, PF_ERR_UNSUPPORTED,
+                "BM6 with the spectral scheme: periodic box on one GPU only (phi is eliminated in Fourier space)");
   if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
   if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
     return fail(nullptr, PF_ERR_INVALID, "ext_c: give both buffers or none");
@@ -492,7 +496,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->c[1] = cfg->ext_c[1];
   } else {
     h->own_c = true;
-    const bool with_phi = cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_FEM_BE && !cfg->ext_phi;
+    const bool with_phi = cfg->model == PF_MODEL_BM6 && cfg->scheme == PF_SCHEME_FD_EXPLICIT && !cfg->ext_phi;
     const int64_t bytes = placed_offset_bytes(elems, with_phi ? 2 : 1) + (int64_t)sizeof(double) * elems;
     PF_HIP_C(hipMalloc(&h->block, (size_t)bytes));
     h->c[0] = static_cast<double*>(h->block);
@@ -516,7 +520,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
       h->own_phi = true;
     }
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
-  } else if (cfg->model == PF_MODEL_BM6) {
+  } else if (cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_SPECTRAL_SI) {
     if (!h->phi) {
       PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
       h->own_phi = true;
@@ -533,6 +537,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   } else if (cfg->scheme == PF_SCHEME_SPECTRAL_SI) {
     int src = spectral_create(&h->sp, cfg->dim, g.nx, g.ny, g.nzg, cfg->h, h->stream, &h->err);
     if (src != 0) return bail(PF_ERR_HIP);
+    // BM6: lap(k phi) = -(k^2/eps)(c - mean c) exactly in Fourier space -> one more implicit term, no Poisson solve
+    if (cfg->model == PF_MODEL_BM6) spectral_set_screening(h->sp, cfg->k * cfg->k / cfg->eps_r);
   }
   PF_HIP_C(hipStreamSynchronize(h->stream));
 #undef PF_HIP_C
@@ -626,7 +632,8 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
     return PF_OK;
   }
   if (field != PF_FIELD_C && !(field == PF_FIELD_PHI && h->po))
-    return fail(h, PF_ERR_UNSUPPORTED, "pf_get_field: PF_FIELD_C (or PF_FIELD_PHI for BM6) only; mu is never stored");
+    return fail(h, PF_ERR_UNSUPPORTED,
+                "pf_get_field: PF_FIELD_C (or PF_FIELD_PHI for BM6 with the FD scheme) only; mu is never stored");
   const Geometry& g = h->g;
   if (field == PF_FIELD_PHI) {
     int prc = ensure_phi(h);

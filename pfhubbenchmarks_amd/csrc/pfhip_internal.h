@@ -71,7 +71,8 @@ void set_fused_chunking(int target_wgs, int min_chunk);
 struct Spectral;
 int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, hipStream_t stream, std::string* err);
 void spectral_destroy(Spectral* sp);
-void spectral_invalidate(Spectral* sp);  // call whenever the real-space field changed behind the scheme's back
+void spectral_invalidate(Spectral* sp);
+void spectral_set_screening(Spectral* sp, double gq);  // BM6: gq = k^2 / eps; the step then treats -M gq (c - mean) implicitly  // call whenever the real-space field changed behind the scheme's back
 int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
                   double cb, double two_rho, hipStream_t stream);
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
@@ -86,7 +87,7 @@ void fused2d_invalidate(Fused2D* f);
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
-                 double M, double kappa, double ca, double cb, double two_rho);
+                 double M, double kappa, double ca, double cb, double two_rho, double gam);
 
 // Poisson solve of BM6 (poisson.hip): lap(phi) = -k c / eps on the lattice; npx, npy > 0 = the reference's
 // Dirichlet-x / no-flux-y boundary conditions on the even extension of an npx x npy-node domain, 0 = periodic box

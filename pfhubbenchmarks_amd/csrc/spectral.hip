@@ -45,6 +45,7 @@ struct KsArgs {
   int nx;            // full x extent
   double kx0, ky0, kz0;  // 2 pi / (n h) per axis
   double dtM, dtMkappa, inv_n;
+  double gam = 0.0;  // BM6: dt M k_c^2 / eps, the screened-Poisson term treated implicitly (0 for BM1)
 };
 
 __device__ __forceinline__ double ksq(const KsArgs& a, int64_t idx) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void kspace_update_kernel(double2* __restrict_
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (int64_t)gridDim.x * 256) {
     const double k2 = ksq(a, i);
     const double num = a.dtM * k2;
-    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
     const double2 ch = chat[i], gh = ghat[i];
     double2 o;
     o.x = fma(-num, gh.x, ch.x) * den;
@@ -74,35 +75,60 @@ __global__ __launch_bounds__(256) void kspace_update_kernel(double2* __restrict_
   }
 }
 
-// sum_k w_k k^2 |chat_k|^2 over the half spectrum (w = 1 on the self-conjugate x-columns mx = 0 and mx = nx/2,
-// 2 elsewhere) -> per-block partials -> final (fixed order, deterministic)
+// sum_k w_k k^2 |chat_k|^2 and sum_{k != 0} w_k |chat_k|^2 / k^2 over the half spectrum (w = 1 on the self-conjugate
+// x-columns mx = 0 and mx = nx/2, 2 elsewhere) -> per-block partials -> final (fixed order, deterministic).  The second
+// sum is the electrostatic energy of BM6 in the spectral scheme: sum_x c phi = (k/eps) / N * it.
 __global__ __launch_bounds__(256) void kspace_grad_energy_kernel(const double2* __restrict__ chat, int64_t nh,
                                                                  const KsArgs a, double* __restrict__ partials) {
-  __shared__ double sh[4];
-  double acc = 0.0;
+  __shared__ double sh[8];
+  double acc = 0.0, acc2 = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (int64_t)gridDim.x * 256) {
     const int mx = (int)(i % a.nxh);
     const double w = (mx == 0 || 2 * mx == a.nx) ? 1.0 : 2.0;
     const double2 ch = chat[i];
-    acc += w * ksq(a, i) * (ch.x * ch.x + ch.y * ch.y);
+    const double k2 = ksq(a, i), m2 = ch.x * ch.x + ch.y * ch.y;
+    acc += w * k2 * m2;
+    if (k2 > 0.0) acc2 += w * m2 / k2;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  for (int o = 32; o > 0; o >>= 1) {
+    acc += __shfl_down(acc, o, 64);
+    acc2 += __shfl_down(acc2, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = acc;
+    sh[4 + (threadIdx.x >> 6)] = acc2;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    partials[2 * blockIdx.x + 1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  }
 }
 
+// out[0], out[1] <- the two sums of the n per-block partial pairs
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int n,
                                                            double* __restrict__ out) {
-  __shared__ double sh[4];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  __shared__ double sh[8];
+  double acc = 0.0, acc2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    acc += partials[2 * i];
+    acc2 += partials[2 * i + 1];
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  for (int o = 32; o > 0; o >>= 1) {
+    acc += __shfl_down(acc, o, 64);
+    acc2 += __shfl_down(acc2, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = acc;
+    sh[4 + (threadIdx.x >> 6)] = acc2;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    out[1] = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  }
 }
 
 int grid_for(int64_t n) {
@@ -133,7 +159,8 @@ struct Spectral {
   bool have_plans = false;
   double2 *chat = nullptr, *ghat = nullptr, *scratch = nullptr;
   double* g = nullptr;
-  double* partials = nullptr;  // 2048 + 1 doubles
+  double* partials = nullptr;  // 2 x 2048 doubles
+  double gq = 0.0;             // BM6: k_c^2 / eps (spectral_set_screening)
   bool chat_valid = false;
   Fused2D* fast = nullptr;  // 2-D power-of-two grids: hand-written LDS FFT path (2 launches per step)
   KsArgs ks;
@@ -196,7 +223,7 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     SP_HIP(hipMalloc(&sp->ghat, sizeof(double2) * sp->nh));
     SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * sp->nh));
     SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
-    SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 2049));
+    SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 4096));
     const char* e = getenv("PFHIP_SPECTRAL_2D");  // "rocfft" forces the library path (A/B comparison)
     if (fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e && std::string(e) == "rocfft")) {
       if (fused2d_create(&sp->fast, nx, ny, sp->nz, h, stream) != 0) {
@@ -224,6 +251,8 @@ void spectral_destroy(Spectral* sp) {
   delete sp;
 }
 
+void spectral_set_screening(Spectral* sp, double gq) { sp->gq = gq; }
+
 void spectral_invalidate(Spectral* sp) {
   sp->chat_valid = false;
   if (sp->fast) fused2d_invalidate(sp->fast);
@@ -250,7 +279,8 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   int rc = ensure_chat(sp, c_in);
   if (rc) return rc;
   if (sp->fast) {
-    if (fused2d_step(sp->fast, c_in, c_out, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho) != 0) {
+    if (fused2d_step(sp->fast, c_in, c_out, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho,
+                     dt * M * sp->gq) != 0) {
       sp->err = "fused2d_step launch failed";
       return -3;
     }
@@ -261,6 +291,7 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   KsArgs ks = sp->ks;
   ks.dtM = dt * M;
   ks.dtMkappa = dt * M * kappa;
+  ks.gam = dt * M * sp->gq;
   hipLaunchKernelGGL(kspace_update_kernel, dim3(grid_for(sp->nh)), dim3(256), 0, stream, sp->chat,
                      (const double2*)sp->ghat, sp->scratch, sp->nh, ks);
   SP_FFT(hipfftExecZ2D(sp->inv, reinterpret_cast<hipfftDoubleComplex*>(sp->scratch), c_out));
@@ -268,7 +299,8 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   return 0;
 }
 
-// sum_k w_k k^2 |c_k|^2 / N  (= sum over the lattice of |grad c|^2 by Parseval) -> out_dev[0]
+// sum_k w_k k^2 |c_k|^2  (= N sum over the lattice of |grad c|^2 by Parseval) -> out_dev[0];
+// sum_{k != 0} w_k |c_k|^2 / k^2 -> out_dev[1]
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream) {
   int rc = ensure_chat(sp, c);
   if (rc) return rc;

@@ -35,6 +35,7 @@ struct F2Args {
   double dtM, dtMkappa, kx0, ky0, inv_n;
   int nz = 1;        // 3-D path (512^3) only
   double kz0 = 0.0;
+  double gam = 0.0;  // BM6: dt M k_c^2 / eps added to the implicit denominator for k != 0
 };
 
 __device__ __forceinline__ int brev(int i, int lg) { return (int)(__brev((unsigned)i) >> (32 - lg)); }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
           const double kxv = a.kx0 * kx, kyv = a.ky0 * my;
           const double k2 = (kxv * kxv + kyv * kyv) + 0.0;  // same grouping as spectral.hip's ksq with kz = 0
           const double num = a.dtM * k2;
-          const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+          const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
           const double2 ch = chat[(int64_t)ky * a.nxh + kx];
           double2 r;
           r.x = fma(-num, gh.x, ch.x) * den;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_kernel(const F2Args a, con
     const double kyv = a.ky0 * my;
     const double k2 = (kxv * kxv + kyv * kyv) + 0.0;  // same grouping as spectral.hip's ksq with kz = 0
     const double num = a.dtM * k2;
-    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
     const double2 gh = Lc[nat(ky)];
     double2 r;
     r.x = fma(-num, gh.x, ch[i].x) * den;
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
     const double kyv = a.ky0 * my;
     const double k2 = (kxv * kxv + kyv * kyv) + 0.0;
     const double num = a.dtM * k2;
-    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
     double2 r;
     r.x = fma(-num, v[t].x, ch[t].x) * den;
     r.y = fma(-num, v[t].y, ch[t].y) * den;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
         const double kzv = a.kz0 * mz;
         const double k2 = (kxv * kxv + kyv * kyv) + kzv * kzv;  // same grouping as spectral.hip's ksq
         const double num = a.dtM * k2;
-        const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0);
+        const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
         const double2 gh = Lc[nat(kz)];
         double2 r;
         r.x = fma(-num, gh.x, ch[i].x) * den;
@@ -932,13 +933,14 @@ int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
 
 // one semi-implicit step c_in -> c_out; chat (resident, valid for c_in) is advanced; G, H are work arrays
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
-                 double M, double kappa, double ca, double cb, double two_rho) {
+                 double M, double kappa, double ca, double cb, double two_rho, double gam) {
   F2Args a = f->a;
   a.ca = ca;
   a.cb = cb;
   a.two_rho = two_rho;
   a.dtM = dt * M;
   a.dtMkappa = dt * M * kappa;
+  a.gam = gam;
   if (f->cube512) {
     if (!f->g_valid) {  // x- and y-transform of f'(c_in) (first step, or after the field was replaced)
       launch_row3(f, a, nullptr, c_in, nullptr, G, 0, 1);

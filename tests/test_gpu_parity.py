@@ -316,6 +316,34 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape):
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
 
 
+@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10)])
+def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape):
+    """BM6 with the semi-implicit spectral scheme in a periodic box: phi eliminated in Fourier space (one more implicit
+    term in the k-space update, every kernel form: radix-8 LDS FFT, radix-2^2 LDS FFT, rocFFT 2-D and 3-D), f_elec by
+    Parseval; against oracle/ch_spectral.py (1e-11); and consistent with the FD scheme's phi-eliminated step in the
+    small-dt limit is left to the convergence study."""
+    from oracle import ch_spectral
+    dim = len(shape)
+    rng = np.random.default_rng(sum(shape) + 1)
+    c = 0.5 + 0.04 * rng.standard_normal(shape)
+    sp = ch_spectral.SpectralCH(c, h=1.0, bm6=True)
+    with PhaseFieldSolver(dim=dim, n=shape[::-1], h=1.0, scheme="spectral", model="bm6") as s:
+        s.set_c(c)
+        F, Ctot, E = s.diagnostics()
+        Fo, Co, Eo = sp.diagnostics()
+        assert abs(F - Fo) <= 1e-11 * abs(Fo) and abs(Ctot - Co) <= 1e-13 * abs(Co) and abs(E - Eo) <= 1e-10 * abs(Eo)
+        assert Eo > 0.0
+        for k in (1, 9):
+            s.step(1e-2, k)
+            sp.step(1e-2, k)
+            assert np.abs(s.get_c() - sp.c).max() <= 1e-11 * np.abs(sp.c).max()
+        F, Ctot, E = s.diagnostics()
+        Fo, Co, Eo = sp.diagnostics()
+        assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(Ctot - Co) <= 1e-12 * abs(Co) and abs(E - Eo) <= 1e-9 * abs(Eo)
+    with pytest.raises(Exception):          # reference boundary conditions need the FD scheme's Dirichlet Poisson solve
+        PhaseFieldSolver(dim=2, n=65, h=1.0, bc="mirror", scheme="spectral", model="bm6")
+
+
 def test_spectral_512cubed_lds_fft_passes_equal_the_rocfft_path(lib):
     """512^3 semi-implicit spectral step: the hand-written passes (x rows by f2_row512_kernel, y and z columns by
     f3_col512_kernel, 4 launches per step) against the rocFFT path of the same library (PFHIP_SPECTRAL_3D=rocfft, itself
