@@ -96,3 +96,21 @@ def test_spectral_oracle_conserves_mass_and_matches_fd_for_smooth_data():
     assert np.abs(cf - sp.c).max() < 2e-4          # FD's O(h^2) dispersion error on k = 1, 2 modes at n = 64
     Ff, Cf, _ = ch_fd.diagnostics(cf, h=h)
     assert abs(Ff - F1) / F1 < 1e-3
+
+
+def test_bm6_spectral_oracle_agrees_with_the_fd_phi_eliminated_oracle():
+    """two restatements of BM6 in a periodic box -- phi eliminated in Fourier space (oracle/ch_spectral.py) and through
+    the discrete Laplacian (oracle/bm6_fd.py) -- solve the same PDE: on a smooth field they differ by the spatial
+    discretisation error only, and both conserve mass"""
+    from oracle import bm6_fd, ch_spectral
+    n = 64
+    x = np.arange(n)
+    c = 0.5 + 0.04 * np.cos(2 * np.pi * x[None, :] / n) * np.cos(4 * np.pi * x[:, None] / n)
+    a = ch_spectral.SpectralCH(c, h=1.0, bm6=True)
+    b = bm6_fd.BM6FD(c, 1.0, eliminate_phi=True)
+    a.step(1e-4, 200)
+    b.step(1e-4, 200)
+    assert np.abs(a.c - b.c).max() < 2e-6
+    Fa, Ca, Ea = a.diagnostics()
+    Fb, Cb, Eb = b.diagnostics()
+    assert abs(Ca - Cb) < 1e-9 and abs(Fa - Fb) < 1e-4 * abs(Fb) and abs(Ea - Eb) < 1e-2 * abs(Eb)
