@@ -441,91 +441,15 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
   }
 }
 
-// Column kernel, ny == 512: CWN adjacent k_x columns per workgroup, one wave per column; contract of f2_col_kernel.
-// (A/B variant, PFHIP_FFT512_DIRECT=0.)  Every global access is made by the whole workgroup with the column index fastest (CWN * 16 contiguous bytes per row:
-// a full 64-byte sector for CWN = 4) and staged through LDS -- a wave reading "its" column straight from memory touches
-// 64 cache lines per load instruction for 16 useful bytes each, which made this kernel twice as slow as the row kernel.
-// chat is loaded at kernel entry so its latency hides behind the forward transform.
-constexpr int W8C = W8 + 32;  // per-wave LDS region: FFT exchanges (576) or a skewed natural-order column (575) + 4*ci
-template <int CWN>
-__global__ __launch_bounds__(64 * CWN) void f2_col512_kernel(const F2Args a, const double2* __restrict__ G,
-                                                             double2* __restrict__ chat, double2* __restrict__ H,
-                                                             const double2* __restrict__ twA_g,
-                                                             const double2* __restrict__ twB_g, int init_only) {
-  __shared__ __attribute__((aligned(16))) double2 Lall[CWN * W8C];
-  constexpr int N = 512, NT = 64 * CWN, PER = N * CWN / NT;  // PER = 8 elements per thread in the cooperative phases
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double2* L = Lall + wave * W8C + 4 * wave;  // this wave's region (the 4*ci shift de-aliases the columns' banks)
-  const int blk = xcd_band_block();
-  const int kxb = blk * CWN;
-  const int T = (lane >> 3) + 8 * (lane & 7);
-  auto nat = [](int n) { return n + (n >> 3); };  // skewed natural-order slot
-  // cooperative element e = tid + NT * i  ->  (row y = e / CWN, column ci = e % CWN)
-  const int ci = tid % CWN, kx = kxb + ci;
-  const bool on = kx < a.nxh;
-  double2* Lc = Lall + ci * W8C + 4 * ci;
-  double2 twN[7], twB[7], v[8], ch[PER];
-  load_tw(twN, twA_g, lane);
-  load_tw(twB, twB_g, lane & 7);
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int y = (tid + NT * i) / CWN;
-    v[i] = on ? G[(int64_t)y * a.nxh + kx] : make_double2(0.0, 0.0);
-    if (!init_only) ch[i] = on ? chat[(int64_t)y * a.nxh + kx] : make_double2(0.0, 0.0);
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) Lc[nat((tid + NT * i) / CWN)] = v[i];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
-  fft512_wave<-1>(v, L, lane, twN, twB, lane);
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
-  __syncthreads();
-  if (init_only) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int ky = (tid + NT * i) / CWN;
-      if (on) chat[(int64_t)ky * a.nxh + kx] = Lc[nat(ky)];
-    }
-    return;
-  }
-  const double kxv = a.kx0 * kx;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int ky = (tid + NT * i) / CWN;
-    const int my = 2 * ky > N ? ky - N : ky;
-    const double kyv = a.ky0 * my;
-    const double k2 = (kxv * kxv + kyv * kyv) + 0.0;  // same grouping as spectral.hip's ksq with kz = 0
-    const double num = a.dtM * k2;
-    const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
-    const double2 gh = Lc[nat(ky)];
-    double2 r;
-    r.x = fma(-num, gh.x, ch[i].x) * den;
-    r.y = fma(-num, gh.y, ch[i].y) * den;
-    if (on) chat[(int64_t)ky * a.nxh + kx] = r;
-    Lc[nat(ky)] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
-  fft512_wave<+1>(v, L, lane, twN, twB, lane);
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int y = (tid + NT * i) / CWN;
-    if (on) H[(int64_t)y * a.nxh + kx] = Lc[nat(y)];
-  }
-}
+constexpr int W8C = W8 + 32;  // per-wave LDS region of the staged column kernels: FFT exchanges (576) or a skewed
+                              // natural-order column (575) + 4 * column index
 
-// DEFAULT column kernel, no LDS staging: every wave reads / writes its own column straight from global memory (16-byte
-// accesses, one cache line per lane) and relies on the XCD band to find the line in its L2 after a sibling fetched it
-// -- with the band in place this beats the staged form (fewer LDS round trips and workgroup barriers on the critical
-// path of a latency-bound kernel).  PFHIP_FFT512_DIRECT=0 selects the staged kernel above (A/B).
+// Column kernel, ny == 512 (2-D): one wave per k_x column, contract of f2_col_kernel.  No LDS staging: every wave reads /
+// writes its own column straight from global memory (16-byte accesses, one cache line per lane) and relies on the XCD
+// band to find the line in its L2 after a sibling fetched it.  A form that staged every access through LDS with the
+// column index fastest (full 64-byte sectors) was measured once the band was in place and is slower, 13.9 vs 13.05 us
+// per step (extra LDS round trips and workgroup barriers on the critical path of a latency-bound kernel); the 512^3
+// passes below, which stream from HBM, do stage (f3_col512_kernel).
 template <int CWN>
 __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args a, const double2* __restrict__ G,
                                                                     double2* __restrict__ chat,
@@ -718,8 +642,7 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
 }
 
 int g_cw3 = 8;  // k_x columns per workgroup of the 3-D column passes (PFHIP_FFT3D_CW = 4 | 8); 8: 2.95 ms, 4: 3.15 ms
-int g_col512_direct = 1;  // measured: direct, 1 column per workgroup 13.05 us/step; staged 13.9 (PFHIP_FFT512_DIRECT=0)
-int g_cw512 = 1;          // columns per workgroup (PFHIP_FFT512_CW = 1 | 2 | 4 | 8; 8: staged kernel only)
+int g_cw512 = 1;  // columns per workgroup of the 2-D column kernel (PFHIP_FFT512_CW = 1 | 2 | 4): 13.05 / 14.3 / 17.5 us
 
 int ilog2(int n) {
   int l = 0;
@@ -781,12 +704,11 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   const bool allow8 = !(e && std::string(e) == "radix2");
   f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
   f->col512 = (allow8 || f->cube512) && ny == 512;
-  if (const char* d = getenv("PFHIP_FFT512_DIRECT")) g_col512_direct = std::atoi(d) != 0;
   if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : 8;
 
   if (const char* cw = getenv("PFHIP_FFT512_CW")) {
     const int c = std::atoi(cw);
-    if (c == 1 || c == 2 || c == 4 || c == 8) g_cw512 = c;
+    if (c == 1 || c == 2 || c == 4) g_cw512 = c;
   }
   if (f->row512 || f->col512) {
     std::vector<double2> ta(512), tb(64);
@@ -838,26 +760,14 @@ void launch_row(const Fused2D* f, const F2Args& a, const double2* H, const doubl
                        (const double2*)f->twx, from_spectrum, use_fprime);
 }
 void launch_col(const Fused2D* f, const F2Args& a, const double2* G, double2* chat, double2* H, int init_only) {
-  if (f->col512 && g_col512_direct && g_cw512 == 1)
-    hipLaunchKernelGGL(f2_col512_direct_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
-                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512 && g_col512_direct && g_cw512 == 4)
+  if (f->col512 && g_cw512 == 4)
     hipLaunchKernelGGL(f2_col512_direct_kernel<4>, dim3((a.nxh + 3) / 4), dim3(256), 0, f->stream, a, G, chat, H,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512 && g_col512_direct)
+  else if (f->col512 && g_cw512 == 2)
     hipLaunchKernelGGL(f2_col512_direct_kernel<2>, dim3((a.nxh + 1) / 2), dim3(128), 0, f->stream, a, G, chat, H,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512 && g_cw512 == 1)
-    hipLaunchKernelGGL(f2_col512_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
-                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512 && g_cw512 == 2)
-    hipLaunchKernelGGL(f2_col512_kernel<2>, dim3((a.nxh + 1) / 2), dim3(128), 0, f->stream, a, G, chat, H,
-                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512 && g_cw512 == 8)
-    hipLaunchKernelGGL(f2_col512_kernel<8>, dim3((a.nxh + 7) / 8), dim3(512), 0, f->stream, a, G, chat, H,
-                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
   else if (f->col512)
-    hipLaunchKernelGGL(f2_col512_kernel<4>, dim3((a.nxh + 3) / 4), dim3(256), 0, f->stream, a, G, chat, H,
+    hipLaunchKernelGGL(f2_col512_direct_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
   else
     hipLaunchKernelGGL(f2_col_kernel, dim3((a.nxh + CW - 1) / CW), dim3(CT * CW), f->lds_col, f->stream, a, G, chat, H,
