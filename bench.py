@@ -327,6 +327,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     F1, C1, _ = solver.diagnostics()
+    if getattr(solver, "transport", None) is not None:
+        solver.transport.check()       # peer-copy transport: a wait that gave up means wrong ghosts -- fail loudly
 
     total_cells = gn[0] * gn[1] * gn[2]
     value = total_cells * a.steps / el

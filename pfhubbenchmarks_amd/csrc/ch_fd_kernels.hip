@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void ch_fd3d_fused_kernel(const KArgs k) {
         int spins = 0;
         while (__hip_atomic_load(need[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.wait_seq) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1 << 24)) {
+          if (++spins > (1 << 20)) {  // ~1-2 us per poll -> 1-2 s
             __hip_atomic_store(a.wait_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
           }

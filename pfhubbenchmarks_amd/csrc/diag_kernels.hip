@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void push_planes_kernel(const double2* __restr
 // seconds it gives up, raises *timeout and lets the stream continue (a lost neighbour must not hang the GPU).
 __global__ void wait_flag_kernel(const long long* flag, long long seq, int* timeout) {
   if (threadIdx.x != 0) return;
-  for (int spins = 0; spins < (1 << 25); ++spins) {
+  for (int spins = 0; spins < (1 << 20); ++spins) {  // ~1-2 us per poll (a system-scope load) -> 1-2 s
     if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= seq) return;
     __builtin_amdgcn_s_sleep(2);
   }
