@@ -605,6 +605,9 @@ hipError_t launch_ch_fd_fused(const FdArgs& a, hipStream_t stream) {
     case 15: return launch_fused_t<8, 2, 1, 1>(a, stream);
     case 16: return launch_fused_t<8, 2, 1, 2>(a, stream);
     case 17: return launch_fused_t<8, 2, 1>(a, stream);
+    case 18: return launch_fused_t<8, 2, 3, 1>(a, stream);
+    case 19: return launch_fused_t<8, 2, 4, 1>(a, stream);
+    case 20: return launch_fused_t<4, 4, 1, 1>(a, stream);
     // default <8,2,1> + non-temporal stores: in-process A/B on the same buffers (tools/variant_ab.py,
     // profiles/r01/variant_ab*.log) ranks the prefetch depths 1 > 4 > 3 > 2 (0.367 / 0.374 / 0.387 / 0.387 ms at 512^3),
     // and with the buffers placed (pfhip_api.hip: placed_offset_bytes) the streaming stores are worth another 2.4 % at
