@@ -24,6 +24,13 @@ Why config 3 and not config 2 is the default: BASELINE.json's metric is "cell-up
 GPUs" and its roofline target is the fused stencil.  Config 2 (512^2 spectral) is a 14 us, launch-latency-bound step
 that does not shard (replicas only, DESIGN.md section 4), so the N = 1, 2, 4, 8 series is run on the 512^3 stencil;
 the same default run also times both 512^2 workloads and reports them under "also" in the same JSON line.
+Timed region (DESIGN.md section 6 "power transient"): the chip answers an HBM-heavy load that starts from
+idle (>= 3-10 ms without work) by dropping its shader clock from 2.4 to ~1.7 GHz for ~25 ms (tools/ramp_probe.py,
+profiles/r02/ramp_probe_512.log), which a 20-step / 9 ms timed region sits entirely inside.  So the run first does a
+DECLARED, untimed pre-heat of the same step by wall time (--preheat-s, default 0.5 s; reported as preheat_ms /
+preheat_steps), then the W counted warm-up steps, then times EXACTLY K steps between device syncs (+ barrier); when
+K steps take less than 0.25 s that K-step block is repeated (`repeats`, at most 25) and the MEDIAN block is reported
+(all block times are in `block_ms_per_step`).  --preheat-s 0 --repeats 1 gives the raw cold measurement.
 Prints ONE JSON line (rank 0).  `value` counts the cell updates of all ranks; inputs are resident in HBM before the
 timed region.  roofline.achieved = 16 B/cell-update x cells per launch / average kernel time from HIP events
 recorded inside libpfhip around every step launch.  cpu_baseline = the CPU oracle (oracle/ch_fd.c, OpenMP) timed on
@@ -79,8 +86,11 @@ def cpu_baseline_spectral(n, dt, steps):
                                                                                              steps, el)}
 
 
-def bench_fem_be(a, world):
-    """config 1 (reference's own discretisation): accepted backward-Euler steps on the committed time grid."""
+def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
+    """config 1 (reference's own discretisation): accepted backward-Euler steps on the committed time grid.
+    Returns the JSON dict (the caller prints it, or nests it under `also`)."""
+    steps = a.steps if steps is None else steps
+    warmup = warmup if warmup is None else warmup
     import importlib.util
     import numpy as np
     import torch
@@ -89,17 +99,17 @@ def bench_fem_be(a, world):
     if world != 1:
         sys.exit("bm1_fem_be is a single-GPU workload")
     times = report_times("bench1")
-    steps = min(a.steps, len(times) - a.warmup)
+    steps = min(steps, len(times) - warmup)
     nodes = 20201
     with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:
         s.set_ic_bm1()
         tprev, its = 0.0, 0
-        for i in range(a.warmup):
+        for i in range(warmup):
             s.step(times[i] - tprev, 1, check=True)
             tprev = times[i]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(a.warmup, a.warmup + steps):
+        for i in range(warmup, warmup + steps):
             ok, _, _ = s.step(times[i] - tprev, 1, check=True)
             assert ok
             its += s.last_iters
@@ -108,11 +118,11 @@ def bench_fem_be(a, world):
         el = time.perf_counter() - t0
         F, C, _ = s.diagnostics()
     out = {"metric": "node-updates/sec on PFHub BM1, reference algorithm (P1 crossed mesh, backward Euler, Newton)",
-           "value": nodes * steps / el, "unit": "node-updates/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup,
+           "value": nodes * steps / el, "unit": "node-updates/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "bm1_fem_be", "mesh": "100x100 crossed, 20201 nodes, 40402 dofs",
-                      "time_grid": "rows %d..%d of results/bench1_out.csv" % (a.warmup, a.warmup + steps - 1),
+                      "time_grid": "rows %d..%d of results/bench1_out.csv" % (warmup, warmup + steps - 1),
                       "newton_iterations": its, "linear_solver": "block cyclic reduction, strided-batched rocSOLVER/rocBLAS "
                                        "(PFHIP_FEM_SOLVER=thomas: sequential block Thomas)"},
            "roofline": None,
@@ -123,12 +133,12 @@ def bench_fem_be(a, world):
         from oracle import fem_be
         o = fem_be.FemBE("bm1")
         tp = 0.0
-        for i in range(a.warmup):
+        for i in range(warmup):
             o.step(times[i] - tp)
             tp = times[i]
-        ncpu = min(steps, 6)
+        ncpu = min(steps, ncpu_max)
         t0 = time.perf_counter()
-        for i in range(a.warmup, a.warmup + ncpu):
+        for i in range(warmup, warmup + ncpu):
             o.step(times[i] - tp)
             tp = times[i]
         elc = time.perf_counter() - t0
@@ -136,9 +146,9 @@ def bench_fem_be(a, world):
         out["cpu_baseline"] = {"value": nodes * ncpu / elc, "unit": "node-updates/s", "cores": ch_fd.host_cores(),
                                "kind": "port", "sample": "%d accepted BE steps (rows %d..%d), oracle/fem_be.py "
                                "(scipy SuperLU), %.1f s; FEniCS itself: %s" % (
-                                   ncpu, a.warmup, a.warmup + ncpu - 1, elc,
+                                   ncpu, warmup, warmup + ncpu - 1, elc,
                                    "present" if out["fenics_on_host"] else "unavailable on host")}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def measured_traffic(workload, variant):
@@ -161,9 +171,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 200 (bm1_fem_be: 100)")
-    ap.add_argument("--warmup", type=int, default=None,
-                    help="default 50: the first ~25 steps after an idle GPU run 30 %% slower (tools/cold_start_ramp.py); "
-                         "bm1_fem_be: 10")
+    ap.add_argument("--warmup", type=int, default=None, help="counted untimed steps after the pre-heat; default 20 "
+                                                             "(bm1_fem_be: 10)")
+    ap.add_argument("--preheat-s", type=float, default=0.5,
+                    help="declared untimed pre-heat of the same step, by wall time, before the counted warm-up: a load "
+                         "starting from an idle GPU runs ~25 ms at a reduced shader clock (tools/ramp_probe.py)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed K-step blocks (median reported); 0 = as many as needed for 0.25 s of timed work, <= 25")
+    ap.add_argument("--no-also", action="store_true", help="default workload only: skip the side measurements")
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
                              "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
@@ -184,7 +199,7 @@ def main():
     if a.steps is None:
         a.steps = 100 if a.workload == "bm1_fem_be" else 200
     if a.warmup is None:
-        a.warmup = 10 if a.workload == "bm1_fem_be" else 50
+        a.warmup = 10 if a.workload == "bm1_fem_be" else 20
 
     import torch
     from pfhubbenchmarks_amd import lib as L
@@ -217,49 +232,8 @@ def main():
         lib.pfk_set_tuning(7, a.push_wgs)
 
     if a.workload == "bm1_fem_be":
-        return bench_fem_be(a, world)
-    h = 1.0
-    scheme, bytes_per_cell = "fd", BYTES_PER_CELL_UPDATE
-    model, elim = "bm1", False
-    if a.workload == "bm6_fd_512c_elim":
-        # BM6 with phi eliminated algebraically (PF_FLAG_BM6_ELIMINATE_PHI): the step is the fused CH kernel alone
-        model, elim, bytes_per_cell = "bm6", True, BYTES_PER_CELL_UPDATE
-        dim, gn, scaling = 3, (512, 512, 512 * world), "weak"
-        dt = 5e-4
-    elif a.workload in ("bm6_fd_512c", "bm6_fd_256c"):
-        # CH kernel 16 B + phi read 8 B + Poisson transform pair idealised at 48 B (r2c 16, invert 16, c2r 16)
-        model, bytes_per_cell = "bm6", 72.0
-        nn = 512 if a.workload.endswith("512c") else 256
-        dim, gn, scaling = 3, (nn, nn, nn * world), "weak"
-        dt = 5e-4
-    elif a.workload == "bm6_spectral_512c":
-        # BM6 with the spectral scheme: phi eliminated in Fourier space, same passes as bm1_spectral_512c (one GPU)
-        scheme, model, bytes_per_cell = "spectral", "bm6", 72.0
-        dim, gn, scaling = 3, (512, 512, 512), "weak"
-        dt = 1e-2
-        if world > 1:
-            sys.exit("bm6_spectral_512c is single-GPU")
-    elif a.workload == "bm1_spectral_512c":
-        scheme, bytes_per_cell = "spectral", 72.0
-        dim, gn, scaling = 3, (512, 512, 512 * world), "weak"
-        dt = 1e-2
-    elif a.workload in ("bm1_spectral_512s", "bm1_spectral_256c"):
-        # BASELINE.json config 2: semi-implicit spectral; 72 B/cell-update = one-pass-per-transform idealisation
-        # (f' 16 + r2c 16 + k-space 24 + c2r 16) -- 512^2 is launch-latency bound, not HBM bound
-        scheme, bytes_per_cell = "spectral", 72.0
-        dim, gn, scaling = (2, (512, 512, 1), "weak") if a.workload.endswith("512s") else (3, (256, 256, 256), "weak")
-        dt = 1e-2
-        if world > 1:
-            sys.exit("this 2-D / small spectral workload is single-GPU; use bm1_spectral_512c for N > 1")
-    elif a.workload == "bm1_fd_512s":
-        dim, gn, scaling = 2, (512, 512, 1), "weak"
-        dt = 1e-3
-    elif a.workload == "bm1_fd_512c":
-        dim, gn, scaling = 3, (512, 512, 512 * world), "weak"
-        dt = 5e-4
-    else:
-        dim, gn, scaling = 3, (1024, 1024, 1024), "strong"
-        dt = 5e-4
+        print(json.dumps(bench_fem_be(a, world)), flush=True)
+        return
 
     dist = None
     if world > 1 or a.slab:
@@ -267,11 +241,78 @@ def main():
         if a.slab and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        from pfhubbenchmarks_amd.solver import FFTSlabSolver, HipFFTSlabEngine
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctx = {"world": world, "rank": rank, "local_rank": local_rank, "rehearsal": rehearsal, "dist": dist, "lib": lib}
+    out = bench_grid(a, a.workload, ctx, a.steps, a.warmup, cpu=not a.no_cpu_baseline, copy_ceiling=True)
+    if rank == 0 and world == 1 and a.workload == "bm1_fd_512c" and not a.no_also:
+        out["also"] = side_measurements(a, ctx)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def workload_table(workload, world):
+    """-> dict(scheme, model, elim, bytes_per_cell, dim, gn, scaling, dt)"""
+    w = {"scheme": "fd", "model": "bm1", "elim": False, "bytes_per_cell": BYTES_PER_CELL_UPDATE, "dim": 3,
+         "scaling": "weak", "dt": 5e-4}
+    if workload == "bm6_fd_512c_elim":
+        # BM6 with phi eliminated algebraically (PF_FLAG_BM6_ELIMINATE_PHI): the step is the fused CH kernel alone
+        w.update(model="bm6", elim=True, gn=(512, 512, 512 * world))
+    elif workload in ("bm6_fd_512c", "bm6_fd_256c"):
+        # CH kernel 16 B + phi read 8 B + Poisson transform pair idealised at 48 B (r2c 16, invert 16, c2r 16)
+        nn = 512 if workload.endswith("512c") else 256
+        w.update(model="bm6", bytes_per_cell=72.0, gn=(nn, nn, nn * world))
+    elif workload == "bm6_spectral_512c":
+        # BM6 with the spectral scheme: phi eliminated in Fourier space, same passes as bm1_spectral_512c (one GPU)
+        w.update(scheme="spectral", model="bm6", bytes_per_cell=72.0, gn=(512, 512, 512), dt=1e-2)
+        if world > 1:
+            sys.exit("bm6_spectral_512c is single-GPU")
+    elif workload == "bm1_spectral_512c":
+        w.update(scheme="spectral", bytes_per_cell=72.0, gn=(512, 512, 512 * world), dt=1e-2)
+    elif workload in ("bm1_spectral_512s", "bm1_spectral_256c"):
+        # BASELINE.json config 2: semi-implicit spectral; 72 B/cell-update = one-pass-per-transform idealisation
+        # (f' 16 + r2c 16 + k-space 24 + c2r 16; SURVEY.md 8d) -- 512^2 is launch-latency bound, not HBM bound
+        w.update(scheme="spectral", bytes_per_cell=72.0, dt=1e-2)
+        w.update(dim=2, gn=(512, 512, 1)) if workload.endswith("512s") else w.update(gn=(256, 256, 256))
+        if world > 1:
+            sys.exit("this 2-D / small spectral workload is single-GPU; use bm1_spectral_512c for N > 1")
+    elif workload == "bm1_fd_512s":
+        w.update(dim=2, gn=(512, 512, 1), dt=1e-3)
+    elif workload == "bm1_fd_512c":
+        w.update(gn=(512, 512, 512 * world))
+    elif workload == "bm1_fd_1024c":
+        w.update(gn=(1024, 1024, 1024), scaling="strong")
+    else:
+        sys.exit("unknown workload %r" % workload)
+    return w
+
+
+def _median_index(vals):
+    """index of the (lower) median element: an actual block, not an average of two"""
+    order = sorted(range(len(vals)), key=lambda i: vals[i])
+    return order[(len(vals) - 1) // 2]
+
+
+def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
+    """One grid workload: pre-heat, warm-up, R timed K-step blocks; returns the JSON dict."""
+    import math
+    import torch
+    from pfhubbenchmarks_amd import lib as L
+    from pfhubbenchmarks_amd.solver import HipSlabEngine, PhaseFieldSolver, SlabSolver
+    world, rank, local_rank, rehearsal, dist, lib = (ctx[k] for k in ("world", "rank", "local_rank", "rehearsal",
+                                                                     "dist", "lib"))
+    w = workload_table(workload, world)
+    scheme, model, elim, bytes_per_cell = w["scheme"], w["model"], w["elim"], w["bytes_per_cell"]
+    dim, gn, scaling, dt = w["dim"], w["gn"], w["scaling"], w["dt"]
+    h = 1.0
+    slab = dist is not None
+    if slab:
+        from pfhubbenchmarks_amd.solver import FFTSlabSolver, HipFFTSlabEngine
         if scheme == "spectral" or model == "bm6":
             eng = HipFFTSlabEngine(gn, h, world, rank, local_rank, scheme=scheme, model=model, eliminate_phi=elim)
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
@@ -305,68 +346,111 @@ def main():
             s.sync()
             torch.cuda.synchronize()
 
+    def max_over_ranks(vals):
+        if dist is None:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().tolist()
+
     F0, C0, _ = solver.diagnostics()
-    run(a.warmup)
+    sync()
+    # ---- declared pre-heat by wall time (untimed): every rank runs the SAME number of steps (the slab path exchanges
+    # ghost planes every step), decided from a probe block timed with the max over ranks
+    t_pre = time.perf_counter()
+    preheat_steps = 0
+    if a.preheat_s > 0:
+        probe = 5
+        t0 = time.perf_counter()
+        run(probe)
+        sync()
+        per = max_over_ranks([(time.perf_counter() - t0) / probe])[0]
+        preheat_steps = probe
+        rest = max(0, min(int(math.ceil(a.preheat_s / max(per, 1e-7))) - probe, 200000))
+        while rest > 0:
+            k = min(rest, 200)
+            run(k)
+            sync()
+            preheat_steps += k
+            rest -= k
+    preheat_ms = (time.perf_counter() - t_pre) * 1e3
+    run(warmup)
     sync()
     # per-launch HIP events cost a few us each: fine beside a 0.4 ms kernel, not beside a 2-D step of a few us -> the
     # launch-bound 2-D workloads are timed by the wall clock alone (kernel_ms_per_step is then the wall time per step)
     # ... and the multi-GPU (slab) path is timed by the wall clock too: its two launches per step would need four event
     # records per step, each a barrier packet on the compute queue (10-15 us per step beside the cross-stream waits)
     per_launch_events = dim == 3 and dist is None
-    timer.timing(per_launch_events)
-    t0 = time.perf_counter()
-    run(a.steps)
-    sync()
-    el = time.perf_counter() - t0
-    k_ms, k_launches = timer.timing_read()
-    timer.timing(False)
+    blocks = []          # (wall seconds, kernel ms per launch, launches)
+    repeats = a.repeats if a.repeats > 0 else None
+    while True:
+        timer.timing(per_launch_events)
+        t0 = time.perf_counter()
+        run(steps)
+        sync()
+        el = time.perf_counter() - t0
+        k_ms, k_launches = timer.timing_read()
+        timer.timing(False)
+        blocks.append((el, k_ms, k_launches))
+        if repeats is None:      # same decision on every rank: from the first block's max-over-ranks time
+            el0 = max_over_ranks([el])[0]
+            repeats = max(1, min(25, int(math.ceil(0.25 / max(el0, 1e-9)))))
+        if len(blocks) >= repeats:
+            break
+    els = max_over_ranks([b[0] for b in blocks])
+    mi = _median_index(els)
+    el, (_, k_ms, k_launches) = els[mi], blocks[mi]
     if not per_launch_events:
-        k_ms, k_launches = el / a.steps * 1e3, a.steps
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        k_ms, k_launches = el / steps * 1e3, steps
     F1, C1, _ = solver.diagnostics()
     if getattr(solver, "transport", None) is not None:
         solver.transport.check()       # peer-copy transport: a wait that gave up means wrong ghosts -- fail loudly
 
     total_cells = gn[0] * gn[1] * gn[2]
-    value = total_cells * a.steps / el
+    value = total_cells * steps / el
     # dominant kernel: all step launches of this rank (1 per step on one GPU; interior + 2 boundary launches per
     # step in slab mode, summed)
-    kernel_s_per_step = k_ms * 1e-3 * k_launches / max(a.steps, 1)
+    kernel_s_per_step = k_ms * 1e-3 * k_launches / max(steps, 1)
     achieved = bytes_per_cell * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+    block_ms = [e / steps * 1e3 for e in els]
     out = {
         "metric": "cell-updates/sec on PFHub %s (%s)" % (
             "BM1 Cahn-Hilliard" if model == "bm1" else "BM6 Cahn-Hilliard + Poisson",
             ("explicit FD, fused HIP stencil" + (" + rocFFT Poisson" if model == "bm6" else "")) if scheme == "fd"
             else "semi-implicit spectral; rocFFT + HIP k-space kernels, fused LDS-FFT kernels for 2-D power-of-two grids"),
-        "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": a.workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
+        "config": {"workload": workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
                    "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
                    "parallelism": "slab%d%s%s%s" % (world, "-forced" if a.slab else "", "-REHEARSAL-one-device-gloo" if rehearsal else "",
                                                   ("-ipc-fused" if a.fused_slab else "-ipc")
                                                   if (dist is not None and a.transport == "ipc") else "")},
+        # timed-region bookkeeping: what ran before the clock started, and every timed block (the reported one is the median)
+        "preheat_ms": preheat_ms, "preheat_steps": preheat_steps, "repeats": len(blocks),
+        "block_ms_per_step": block_ms,
+        "steady": (max(block_ms) - min(block_ms)) <= 0.03 * block_ms[mi],
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(a.workload, a.variant) if world == 1 else None,
+                     "traffic": measured_traffic(workload, a.variant) if world == 1 else None,
                      "traffic_source": "profiles/r*/summary_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
-                                       "bytes per launch)" % a.workload,
-                     "kernel_ms_per_step": kernel_s_per_step * 1e3, "launches_per_step": k_launches / max(a.steps, 1),
+                                       "bytes per launch)" % workload,
+                     "kernel_ms_per_step": kernel_s_per_step * 1e3, "launches_per_step": k_launches / max(steps, 1),
                      "bytes_per_cell_update": bytes_per_cell},
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
-    if rank == 0 and world == 1 and dim == 3 and scheme == "fd":
+    if copy_ceiling and rank == 0 and world == 1 and dim == 3 and scheme == "fd":
         # the same 8 B read + 8 B write per cell as a plain device copy (pfk_stream_copy): what the memory system
-        # delivers for this traffic pattern, measured in the same process (SURVEY 8d "confirm with a device memcpy")
+        # delivers for this traffic pattern, measured in the same process and the same (pre-heated, busy) state:
+        # launched straight behind a few more steps, no idle gap (SURVEY 8d "confirm with a device memcpy")
         import ctypes as C
         gap = local_cells + 8192            # dst starts 64 KB (mod 512 KB) after src ends: pfhip.h, pf_ext_buffer_offset
         blk = torch.ones(gap + local_cells, dtype=torch.float64, device="cuda")
         src, dst = blk[:local_cells], blk[gap:]
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        run(20)
+        sync()
         for it in range(23):
             if it == 3:
                 e0.record(st)
@@ -381,35 +465,54 @@ def main():
                                           "kernel": "pfk_stream_copy (one 16-byte element per thread), %d doubles, 20 launches"
                                                     % local_cells}
         out["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
-    if model == "bm6":
+    if model == "bm6" or not cpu:
         pass          # no CPU leg for the BM6 box (the BM6 oracle is a test checker, minutes per step at this size)
-    elif rank == 0 and world == 1 and not a.no_cpu_baseline and scheme == "spectral":
+    elif rank == 0 and world == 1 and scheme == "spectral":
         out["cpu_baseline"] = cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8)
-    elif rank == 0 and world == 1 and not a.no_cpu_baseline:
+    elif rank == 0 and world == 1:
         if dim == 3:
             out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 64, dt, 400)
         else:
             out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 1, dt, 4000)
-    if rank == 0 and world == 1 and a.workload == "bm1_fd_512c":
-        # BASELINE.json's metric also names 512^2: short side measurements (wall clock incl. launches), same run
-        also = {}
-        for name, sch, nst, dts in (("bm1_spectral_512s", "spectral", 300, 1e-2), ("bm1_fd_512s", "fd", 4001, 1e-3)):
-            with PhaseFieldSolver(dim=2, n=512, h=h, scheme=sch, device=local_rank) as s2:
-                s2.set_ic_bm1(0.5, 0.05)
-                s2.step(dts, 21)
+    if not slab:
+        solver.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_measurements(a, ctx):
+    """Same run, same process, rank 0 of an N = 1 default run: the other configurations BASELINE.json's metric and
+    north_star name -- the two 512^2 workloads (wall clock incl. launches), the 1024^3 stencil (north_star's roofline
+    target; own pre-heat, timed blocks, per-launch events) and config 1 = the reference's own algorithm on the GPU with
+    its CPU restatement (oracle/fem_be.py) timed beside it and whether FEniCS itself is on the host."""
+    from pfhubbenchmarks_amd.solver import PhaseFieldSolver
+    also = {}
+    for name, sch, nst, dts in (("bm1_spectral_512s", "spectral", 300, 1e-2), ("bm1_fd_512s", "fd", 4001, 1e-3)):
+        with PhaseFieldSolver(dim=2, n=512, h=1.0, scheme=sch, device=ctx["local_rank"]) as s2:
+            s2.set_ic_bm1(0.5, 0.05)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.1:      # pre-heat, as for the main workload
+                s2.step(dts, 101)
                 s2.sync()
+            reps = []
+            for _ in range(5):
                 t0 = time.perf_counter()
                 s2.step(dts, nst)
                 s2.sync()
-                e2 = time.perf_counter() - t0
-            also[name] = {"value": 512 * 512 * nst / e2, "unit": "cell-updates/s", "us_per_step": e2 / nst * 1e6,
-                          "steps": nst}
-        out["also"] = also
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                reps.append(time.perf_counter() - t0)
+            e2 = sorted(reps)[2]
+        also[name] = {"value": 512 * 512 * nst / e2, "unit": "cell-updates/s", "us_per_step": e2 / nst * 1e6,
+                      "steps": nst, "repeats": 5}
+    big = bench_grid(a, "bm1_fd_1024c", ctx, max(10, min(a.steps, 50)), min(a.warmup, 10), cpu=False)
+    also["bm1_fd_1024c"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "preheat_ms", "repeats",
+                                                "block_ms_per_step", "steady", "roofline", "check")}
+    also["bm1_fd_1024c"]["config"] = {"workload": "bm1_fd_1024c", "grid": big["config"]["grid"],
+                                      "note": "BASELINE.json config 4 on ONE GPU (16 GiB of state); north_star roofline target"}
+    if not a.no_cpu_baseline:
+        fb = bench_fem_be(a, 1, steps=8, warmup=2, ncpu_max=3)
+        also["bm1_fem_be"] = {k: fb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "check",
+                                                 "fenics_on_host", "cpu_baseline") if k in fb}
+    return also
 
 
 if __name__ == "__main__":

@@ -229,6 +229,10 @@ int pf_diagnostics_local(pf_handle* h, double out[3]);
  * HIP events on the handle's stream; enable with pf_timing_enable(h, 1). */
 int pf_timing_enable(pf_handle* h, int on);
 int pf_timing_read(pf_handle* h, double* avg_ms, int64_t* launches);
+/* the individual launches since pf_timing_enable(h, 1) (at most 65536 are kept): device time of each (dur_ms) and
+ * its start relative to the enable call (start_ms, may be NULL).  *n = samples available; min(*n, cap) are written.
+ * Does not reset anything.  tools/ramp_probe.py and bench.py's steady-state check read the launch timeline here. */
+int pf_timing_samples(pf_handle* h, double* dur_ms, double* start_ms, int64_t cap, int64_t* n);
 
 /* ---- kernel-level entry points (stateless; caller-owned device pointers) ------------------------------ */
 typedef struct pfk_ch_params {
@@ -273,6 +277,12 @@ int pfk_wait_flag(const int64_t* flag, int64_t seq, int32_t* timeout, void* stre
 /* Measures the cost of one grid-wide barrier (agent-scope release + atomic count-in + acquire) of a cooperative launch
  * with nblocks x nthreads: the price a persistent multi-phase kernel pays instead of a kernel boundary. */
 int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier);
+
+/* Shader clock actually held, measured inside a kernel: delta s_memtime / delta s_memrealtime x 100 MHz over ~spin_us
+ * microseconds, by `nblocks` workgroups.  out_dev: 2 * nblocks DEVICE doubles {MHz, start of the probe in ms of the
+ * free-running 100 MHz counter}.  busy = 0: one sleeping lane per workgroup; busy = 1: all SIMDs run an fp64 fma chain
+ * (no memory traffic) -- an "active but not HBM-bound" load for tools/ramp_probe.py.  Asynchronous on `stream`. */
+int pfk_clock_probe(double* out_dev, int nblocks, int spin_us, int busy, void* stream);
 
 #ifdef __cplusplus
 }

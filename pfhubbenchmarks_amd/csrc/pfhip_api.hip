@@ -125,6 +125,8 @@ struct pf_handle {
   size_t ev_used = 0;
   double t_ms = 0.0;
   int64_t t_launches = 0;
+  hipEvent_t ev_t0 = nullptr;        // recorded by pf_timing_enable(h, 1): origin of the per-launch start offsets
+  std::vector<float> s_dur, s_start; // per-launch samples since then (pf_timing_samples), capped at kMaxSamples
   std::string err;
 };
 
@@ -196,6 +198,7 @@ int ensure_mu_scratch(pf_handle* h, int64_t elems) {
   return PF_OK;
 }
 
+constexpr size_t kMaxSamples = 1 << 16;
 int timing_flush(pf_handle* h) {
   if (h->ev_used == 0) return PF_OK;
   PF_HIP(h, hipEventSynchronize(h->ev[h->ev_used - 1].second));
@@ -204,6 +207,12 @@ int timing_flush(pf_handle* h) {
     PF_HIP(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
     h->t_ms += ms;
     h->t_launches += 1;
+    if (h->ev_t0 && h->s_dur.size() < kMaxSamples) {
+      float st = 0.f;
+      PF_HIP(h, hipEventElapsedTime(&st, h->ev_t0, h->ev[i].first));
+      h->s_dur.push_back(ms);
+      h->s_start.push_back(st);
+    }
   }
   h->ev_used = 0;
   return PF_OK;
@@ -553,6 +562,9 @@ int pf_destroy(pf_handle* h) {
   for (auto& e : h->ev) {
     (void)hipEventDestroy(e.first);
     (void)hipEventDestroy(e.second);
+  }
+  if (h->ev_t0) {
+    (void)hipEventDestroy(h->ev_t0);
   }
   if (h->block) (void)hipFree(h->block);
   if (h->mu_scratch) (void)hipFree(h->mu_scratch);
@@ -991,8 +1003,26 @@ int pf_timing_enable(pf_handle* h, int on) {
   if (!on) {
     int rc = timing_flush(h);
     if (rc) return rc;
+  } else if (!h->timing) {
+    if (!h->ev_t0) PF_HIP(h, hipEventCreate(&h->ev_t0));
+    PF_HIP(h, hipEventRecord(h->ev_t0, h->stream));
+    h->s_dur.clear();
+    h->s_start.clear();
   }
   h->timing = on != 0;
+  return PF_OK;
+}
+
+int pf_timing_samples(pf_handle* h, double* dur_ms, double* start_ms, int64_t cap, int64_t* n) {
+  if (!h || !n || cap < 0 || (cap > 0 && !dur_ms)) return PF_ERR_INVALID;
+  int rc = timing_flush(h);
+  if (rc) return rc;
+  const int64_t have = (int64_t)h->s_dur.size();
+  *n = have;
+  for (int64_t i = 0; i < have && i < cap; ++i) {
+    dur_ms[i] = h->s_dur[i];
+    if (start_ms) start_ms[i] = h->s_start[i];
+  }
   return PF_OK;
 }
 
@@ -1089,6 +1119,14 @@ int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_
   if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_grid_barrier_probe: ") + hipGetErrorString(e));
   if (!ok) return fail(nullptr, PF_ERR_STATE, "pfk_grid_barrier_probe: the bounded spin tripped (workgroups not co-resident?)");
   *us_per_barrier = ms * 1e3;
+  return PF_OK;
+}
+
+int pfk_clock_probe(double* out_dev, int nblocks, int spin_us, int busy, void* stream) {
+  if (!out_dev || nblocks < 1 || nblocks > 4096 || spin_us < 1 || spin_us > 1000000)
+    return fail(nullptr, PF_ERR_INVALID, "pfk_clock_probe: bad arguments");
+  hipError_t e = launch_clock_probe(out_dev, nblocks, spin_us, busy, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_clock_probe: ") + hipGetErrorString(e));
   return PF_OK;
 }
 

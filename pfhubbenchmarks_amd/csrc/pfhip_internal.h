@@ -56,6 +56,7 @@ hipError_t launch_push_planes(const double* src, double* dst, int64_t n, long lo
 void set_push_wgs(int n);
 hipError_t launch_wait_flag(const long long* flag, long long seq, int* timeout, hipStream_t stream);
 hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* ms_per_barrier, int* ok);
+hipError_t launch_clock_probe(double* out, int nblocks, int spin_us, int busy, hipStream_t stream);
 hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t stream);
 hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, int ends, hipStream_t stream);
 

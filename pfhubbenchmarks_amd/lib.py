@@ -93,6 +93,8 @@ SYMBOLS = {
     "pf_diagnostics_local": (C.c_int, [_H, _D]),
     "pf_timing_enable": (C.c_int, [_H, C.c_int]),
     "pf_timing_read": (C.c_int, [_H, _D, C.POINTER(C.c_int64)]),
+    "pf_timing_samples": (C.c_int, [_H, _D, _D, C.c_int64, C.POINTER(C.c_int64)]),
+    "pfk_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pfk_ch_fd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.POINTER(PfkChParams), C.c_int, C.c_void_p]),
     "pfk_set_tuning": (C.c_int, [C.c_int, C.c_int]),

@@ -150,6 +150,16 @@ class PhaseFieldSolver:
         self._ck(self._lib.pf_timing_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def timing_samples(self):
+        """(durations_ms, starts_ms) of every step launch since timing(True) -- pf_timing_samples"""
+        n = C.c_int64()
+        self._ck(self._lib.pf_timing_samples(self._h, None, None, 0, C.byref(n)))
+        dur, st = np.empty(n.value), np.empty(n.value)
+        _D = C.POINTER(C.c_double)
+        self._ck(self._lib.pf_timing_samples(self._h, dur.ctypes.data_as(_D), st.ctypes.data_as(_D), n.value,
+                                             C.byref(n)))
+        return dur, st
+
 
 def slab_partition(n_planes, nranks, rank):
     """(first, count) of the planes a rank owns -- pf_slab_partition (pure host code in libpfhip)."""

@@ -841,7 +841,8 @@ def test_bench_multi_rank_launch_contract_rehearsal():
     env = dict(os.environ, PFHIP_BENCH_REHEARSAL="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "6", "--warmup", "3"], env=env, cwd=root, capture_output=True,
+                        "--gpus", "2", "--steps", "6", "--warmup", "3", "--preheat-s", "0.05", "--repeats", "2"],
+                       env=env, cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -852,6 +853,7 @@ def test_bench_multi_rank_launch_contract_rehearsal():
     assert abs(d["value"] - 512 ** 3 * 2 * 6 / (d["ms_per_step"] * 1e-3 * 6)) <= 1e-6 * d["value"]
     assert d["check"]["C_rel_drift"] < 1e-12 and d["check"]["F_after"] < d["check"]["F_before"]
     assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None
+    assert d["repeats"] == 2 and len(d["block_ms_per_step"]) == 2 and d["preheat_steps"] >= 5
 
 
 def test_bench_contract_json_line():
@@ -880,6 +882,17 @@ def test_bench_contract_json_line():
     assert cb["kind"] == "port" and cb["unit"] == "cell-updates/s" and cb["cores"] >= 1 and cb["value"] > 0
     assert abs(d["value"] - 512 ** 3 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     assert d["check"]["C_rel_drift"] < 1e-12
+    # timed-region bookkeeping: declared pre-heat, repeated K-step blocks, the reported block is the median one
+    assert d["preheat_ms"] >= 400.0 and d["preheat_steps"] > 100 and d["repeats"] == len(d["block_ms_per_step"]) == 25
+    assert sorted(d["block_ms_per_step"])[12] == d["ms_per_step"]
+    # north_star's target configuration and the reference's own algorithm ride in the same line
+    big = d["also"]["bm1_fd_1024c"]
+    assert big["config"]["grid"] == [1024, 1024, 1024] and 0.2 < big["roofline"]["frac"] < 1.0
+    assert abs(big["value"] - 1024 ** 3 / (big["ms_per_step"] * 1e-3)) < 1e-6 * big["value"]
+    assert big["check"]["C_rel_drift"] < 1e-12 and big["check"]["F_after"] < big["check"]["F_before"]
+    fb = d["also"]["bm1_fem_be"]
+    assert fb["unit"] == "node-updates/s" and fb["cpu_baseline"]["kind"] == "port" and fb["fenics_on_host"] in (True, False)
+    assert abs(fb["check"]["F"] - 190.1699) < 1e-3      # row t = 11.1 of the reference's bench1_out.csv
 
 
 def test_b13d_driver_3d_extrusion_invariants(lib, tmp_path):
