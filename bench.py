@@ -101,7 +101,7 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
     times = report_times("bench1")
     steps = min(steps, len(times) - warmup)
     nodes = 20201
-    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", max_newton=100) as s:
         s.set_ic_bm1()
         tprev, its = 0.0, 0
         for i in range(warmup):
@@ -131,7 +131,7 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
            "fenics_on_host": all(importlib.util.find_spec(m) is not None for m in ("ufl", "ffc", "petsc4py"))}
     if not a.no_cpu_baseline:
         from oracle import fem_be
-        o = fem_be.FemBE("bm1")
+        o = fem_be.FemBE("bm1", newton_max=100)
         tp = 0.0
         for i in range(warmup):
             o.step(times[i] - tp)

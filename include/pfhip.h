@@ -96,7 +96,11 @@ typedef struct pf_config {
                            all-to-all buffers, pf_a2a_buffer_doubles() doubles each */
   double* ext_phi;      /* BM6 slab mode: optional caller-owned ghosted phi buffer (same size as an ext_c buffer) */
   int32_t flags;        /* PF_FLAG_* */
-  int32_t reserved1;
+  int32_t max_newton;   /* PF_SCHEME_FEM_BE: Newton iteration cap per solve; 0 = 10, the reference's
+                           nlparams['maximum_iterations'] (dolfin/bench1.py:88).  A solve that needs more reports
+                           info.ok = 0 with the state untouched and the caller halves dt (bench1.py:164-177).
+                           Following the COMMITTED run's time grid with exact linear solves needs up to 24 (rows
+                           21, 37 of results/bench1_out.csv): the fixture driver passes 100. */
 } pf_config;
 
 /* pf_config.flags */

@@ -309,7 +309,7 @@ struct FemBE {
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double atol = 1e-6;
-  int max_newton = 100;
+  int max_newton = 10;  // the reference's nlparams['maximum_iterations'] (bench1.py:88); pf_config.max_newton overrides
   int last_iters = 0;
   bool have_prev = false;
   std::string err;
@@ -684,6 +684,10 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
   }
   FB_HIP(hipStreamSynchronize(fb->stream));
   return 0;
+}
+
+void fembe_set_max_newton(FemBE* fb, int n) {
+  if (n > 0) fb->max_newton = n;
 }
 
 int fembe_rollback(FemBE* fb) {

@@ -521,6 +521,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     int frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
                            cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err);
     if (frc != 0) return bail(PF_ERR_HIP);
+    fembe_set_max_newton(h->fb, cfg->max_newton);
   } else if (cfg->model == PF_MODEL_BM6 && slab_fft) {
     if (cfg->ext_phi) {
       h->phi = cfg->ext_phi;

@@ -129,6 +129,7 @@ int fembe_set_c(FemBE* fb, const double* host);
 int fembe_get(FemBE* fb, int field, double* host);
 int fembe_step(FemBE* fb, double dt, int* converged, int* iters);
 int fembe_rollback(FemBE* fb);
+void fembe_set_max_newton(FemBE* fb, int n);  // n <= 0: keep the default (10, bench1.py:88)
 int fembe_diagnostics(FemBE* fb, double out[3]);
 const char* fembe_error(const FemBE* fb);
 

@@ -27,7 +27,7 @@ class PfConfig(C.Structure):
         ("rho_s", C.c_double), ("c_alpha", C.c_double), ("c_beta", C.c_double), ("kappa", C.c_double),
         ("M", C.c_double), ("k", C.c_double), ("eps_r", C.c_double),
         ("stream", C.c_void_p), ("ext_c", C.c_void_p * 2), ("ext_a2a", C.c_void_p * 2), ("ext_phi", C.c_void_p),
-        ("flags", C.c_int32), ("reserved1", C.c_int32),
+        ("flags", C.c_int32), ("max_newton", C.c_int32),
     ]
 
 

@@ -48,7 +48,7 @@ class PhaseFieldSolver:
         for k, v in params.items():
             if not hasattr(cfg, k):
                 raise TypeError("unknown model parameter %r" % k)
-            setattr(cfg, k, float(v))
+            setattr(cfg, k, int(v) if k == "max_newton" else float(v))
         if stream is not None:
             cfg.stream = C.c_void_p(int(stream))
         self.cfg = cfg

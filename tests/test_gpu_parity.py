@@ -505,8 +505,8 @@ def test_fem_be_parity_mode_bm1_against_reference_fixtures(lib, golden_dir):
     from oracle import fem_be
     csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
     fields = np.load(os.path.join(golden_dir, "bm1_fields.npz"))
-    o = fem_be.FemBE("bm1")
-    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:
+    o = fem_be.FemBE("bm1", newton_max=100)
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", max_newton=100) as s:
         s.set_ic_bm1(0.5, 0.05)
         assert s.get_c().shape == (20201,)
         assert np.abs(s.get_c() - o.c).max() < 1e-14
@@ -539,8 +539,8 @@ def test_fem_be_parity_mode_bm6(lib, golden_dir):
     import os
     from oracle import fem_be
     csv = np.loadtxt(os.path.join(golden_dir, "bench6_out.csv"), delimiter=",", skiprows=1)
-    o = fem_be.FemBE("bm6")
-    with PhaseFieldSolver(dim=2, n=101, h=1.0, bc="mirror", scheme="fem_be", model="bm6") as s:
+    o = fem_be.FemBE("bm6", newton_max=100)
+    with PhaseFieldSolver(dim=2, n=101, h=1.0, bc="mirror", scheme="fem_be", model="bm6", max_newton=100) as s:
         s.set_ic_bm6(0.5, 0.04)
         tprev = 0.0
         for i in range(4):
@@ -556,6 +556,87 @@ def test_fem_be_parity_mode_bm6(lib, golden_dir):
             assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(C - Co) <= 1e-12 * abs(Co)
             assert np.abs(s.get_c() - o.c).max() <= 1e-9
             assert np.abs(s.get_phi() - o.phi).max() <= 1e-9
+
+
+def test_fem_be_full_reference_trajectory_bm1(lib, golden_dir):
+    """The WHOLE committed run of the reference (results/bench1_out.csv, 73 accepted steps, dt 0.1 ... 102.4) through the
+    GPU BE-parity mode: every row's F within 1e-8 and C within 1e-9 of the reference's CSV, the six VTU c-fields within
+    5e-9, and the plain-Newton iteration counts of the pinned CPU oracle (oracle/logs/fem_be_bm1_full.log) -- the large
+    steps (rows 21, 37: dt = 12.8 / 51.2, 24 iterations; row 62: 16) are where the block cyclic reduction has to hold."""
+    import os
+    csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
+    fields = np.load(os.path.join(golden_dir, "bm1_fields.npz"))
+    assert csv.shape == (73, 3)
+    its, worst_f, worst_c = [], 0.0, 0.0
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", max_newton=100) as s:
+        s.set_ic_bm1(0.5, 0.05)
+        tprev = 0.0
+        for i in range(73):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok, (i, s.last_iters)
+            its.append(s.last_iters)
+            tprev = csv[i, 0]
+            F, C, _ = s.diagnostics()
+            worst_f = max(worst_f, abs(F - csv[i, 1]) / csv[i, 1])
+            worst_c = max(worst_c, abs(C - csv[i, 2]) / csv[i, 2])
+            assert abs(F - csv[i, 1]) <= 1e-8 * csv[i, 1], (i, F, csv[i, 1])
+            assert abs(C - csv[i, 2]) <= 1e-9 * csv[i, 2], (i, C, csv[i, 2])
+            if i < 6:
+                assert np.abs(s.get_c() - fields["c"][i]).max() < 5e-9
+    assert abs(tprev - 1031.9) < 1e-9
+    assert (its[21], its[37], its[62]) == (24, 24, 16), its
+    assert max(v for i, v in enumerate(its) if i not in (21, 37, 62)) <= 9, its
+    print("BM1 full trajectory: worst rel F %.3g, worst rel C %.3g, Newton its %s" % (worst_f, worst_c, its))
+
+
+def test_fem_be_full_reference_trajectory_bm6(lib, golden_dir):
+    """All 14 rows of results/bench6_out.csv (dt 0.01 ... 0.32) through the monolithic (c, mu, phi) BE-parity mode: F within
+    1e-6 (the reference's own two committed BM6 runs differ by 1e-7), C within 1e-9, the six VTU c / phi fields."""
+    import os
+    csv = np.loadtxt(os.path.join(golden_dir, "bench6_out.csv"), delimiter=",", skiprows=1)
+    fields = np.load(os.path.join(golden_dir, "bm6_fields.npz"))
+    assert csv.shape == (14, 3)
+    with PhaseFieldSolver(dim=2, n=101, h=1.0, bc="mirror", scheme="fem_be", model="bm6", max_newton=100) as s:
+        s.set_ic_bm6(0.5, 0.04)
+        tprev = 0.0
+        for i in range(14):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok and s.last_iters <= 10, (i, s.last_iters)
+            tprev = csv[i, 0]
+            F, C, _ = s.diagnostics()
+            assert abs(F - csv[i, 1]) <= 1e-6 * csv[i, 1], (i, F, csv[i, 1])
+            assert abs(C - csv[i, 2]) <= 1e-9 * csv[i, 2]
+            if i < 6:
+                assert abs(fields["times"][i] - csv[i, 0]) < 1e-9
+                # the field frames come from another run of the reference than its CSV (they differ by ~1e-7 in F)
+                assert np.abs(s.get_c() - fields["c"][i]).max() < 5e-6
+                assert np.abs(s.get_phi() - fields["phi"][i]).max() < 5e-6
+
+
+def test_fem_be_newton_cap_is_the_references_and_failure_restores_state(lib, golden_dir):
+    """Row a9 (solver contract): with the default cap -- the reference's maximum_iterations = 10 (bench1.py:88) -- a
+    solve that needs more reports ok = 0 after exactly 10 iterations with the state untouched, and the caller's
+    halve-dt retry (bench1.py:164-177) then succeeds.  Rows 0-20 of the committed grid need <= 7 iterations; row 21
+    (dt = 12.8) needs 24 with exact linear solves."""
+    import os
+    csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:       # max_newton = 0 -> 10
+        s.set_ic_bm1(0.5, 0.05)
+        tprev = 0.0
+        for i in range(21):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok and s.last_iters <= 7
+            tprev = csv[i, 0]
+        before_c, before_mu, t_before = s.get_c(), s.get_mu(), s.t
+        dt = csv[21, 0] - tprev
+        assert abs(dt - 12.8) < 1e-9
+        ok, _, _ = s.step(dt, 1, check=True)
+        assert not ok and s.last_iters == 10
+        np.testing.assert_array_equal(s.get_c(), before_c)
+        np.testing.assert_array_equal(s.get_mu(), before_mu)
+        assert s.t == t_before
+        ok, _, _ = s.step(0.5 * dt, 1, check=True)       # bench1.py:171: dt.assign(max(0.5 * dt, dt_min)); retry
+        assert ok and s.last_iters <= 10 and abs(s.t - (t_before + 6.4)) < 1e-9
 
 
 def _lockstep(engs, op, dt=0.0):

@@ -30,11 +30,11 @@ def test_mesh_numbering_matches_reference_vtu(golden_dir):
 
 def test_known_answers_at_t0():
     # P1 / Strang-Fix functional of the interpolated BM1 initial condition (SURVEY.md 8c known-answer scalars)
-    s = fem_be.FemBE("bm1")
+    s = fem_be.FemBE("bm1", newton_max=100)
     F, C = s.diagnostics()
     assert abs(F - 297.6736899201) < 2e-9
     assert abs(C - 20504.4690550850) < 2e-9
-    s6 = fem_be.FemBE("bm6")
+    s6 = fem_be.FemBE("bm6", newton_max=100)
     assert abs(s6.diagnostics()[1] - 5096.8562678) < 1e-6
 
 
@@ -55,7 +55,7 @@ def test_bm1_trajectory_and_fields(golden_dir):
     assert csv.shape == (73, 3)
     fields = np.load(os.path.join(golden_dir, "bm1_fields.npz"))
     nrows = 73 if FULL else 6
-    s = fem_be.FemBE("bm1")
+    s = fem_be.FemBE("bm1", newton_max=100)
     frames = {}
 
     def cb(solver, its):
@@ -77,7 +77,7 @@ def test_bm6_trajectory_and_fields(golden_dir):
     assert csv.shape == (14, 3)
     fields = np.load(os.path.join(golden_dir, "bm6_fields.npz"))
     nrows = 14 if FULL else 3
-    s = fem_be.FemBE("bm6")
+    s = fem_be.FemBE("bm6", newton_max=100)
     frames = {}
 
     def cb(solver, its):
