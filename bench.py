@@ -358,21 +358,17 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
     # ---- declared pre-heat by wall time (untimed): every rank runs the SAME number of steps (the slab path exchanges
     # ghost planes every step), decided from a probe block timed with the max over ranks
     t_pre = time.perf_counter()
-    preheat_steps = 0
-    if a.preheat_s > 0:
-        probe = 5
+    preheat_steps, nblk = 0, 5
+    while a.preheat_s > 0:
         t0 = time.perf_counter()
-        run(probe)
+        run(nblk)
         sync()
-        per = max_over_ranks([(time.perf_counter() - t0) / probe])[0]
-        preheat_steps = probe
-        rest = max(0, min(int(math.ceil(a.preheat_s / max(per, 1e-7))) - probe, 200000))
-        while rest > 0:
-            k = min(rest, 200)
-            run(k)
-            sync()
-            preheat_steps += k
-            rest -= k
+        t1 = time.perf_counter()
+        preheat_steps += nblk
+        spent, per = max_over_ranks([t1 - t_pre, (t1 - t0) / nblk])     # identical on every rank -> identical decisions
+        if spent >= a.preheat_s:
+            break
+        nblk = max(1, min(200, int(math.ceil((a.preheat_s - spent) / max(per, 1e-7)))))
     preheat_ms = (time.perf_counter() - t_pre) * 1e3
     run(warmup)
     sync()

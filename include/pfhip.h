@@ -278,6 +278,19 @@ int pfk_push_planes(const double* src, double* dst, int64_t n, int64_t* flag, in
                     void* stream);
 int pfk_wait_flag(const int64_t* flag, int64_t seq, int32_t* timeout, void* stream);
 
+/* Flag words of the peer-copy transport.  A flag is polled by a RUNNING kernel on its home GPU while a PEER GPU writes it
+ * (pfk_push_planes), so it must not live in ordinary (coarse-grained) device memory, whose lines the home GPU's L2 may
+ * keep across the peer's write: pfk_flags_alloc returns FINE-GRAINED device memory (hipExtMallocWithFlags,
+ * hipDeviceMallocFinegrained), zero-filled; `timeout_host` (may be NULL) receives one int32 in mapped, pinned HOST memory
+ * for the wait kernels' give-up mark, readable by the host at any time without a device sync.
+ * pfk_ipc_export / pfk_ipc_import move such an allocation (or any hipMalloc'ed base pointer) between the processes of a
+ * node: 64-byte handle = hipIpcMemHandle_t.  pfk_ipc_close unmaps an imported pointer. */
+int pfk_flags_alloc(int n_words, int64_t** flags_dev, int32_t** timeout_host);
+int pfk_flags_free(int64_t* flags_dev, int32_t* timeout_host);
+int pfk_ipc_export(const void* dev_base, unsigned char handle[64]);
+int pfk_ipc_import(const unsigned char handle[64], void** dev_ptr);
+int pfk_ipc_close(void* dev_ptr);
+
 /* Measures the cost of one grid-wide barrier (agent-scope release + atomic count-in + acquire) of a cooperative launch
  * with nblocks x nthreads: the price a persistent multi-phase kernel pays instead of a kernel boundary. */
 int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier);

@@ -1111,6 +1111,64 @@ int pfk_wait_flag(const int64_t* flag, int64_t seq, int32_t* timeout, void* stre
   return PF_OK;
 }
 
+int pfk_flags_alloc(int n_words, int64_t** flags_dev, int32_t** timeout_host) {
+  if (n_words < 1 || n_words > 4096 || !flags_dev) return fail(nullptr, PF_ERR_INVALID, "pfk_flags_alloc: bad arguments");
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, sizeof(int64_t) * (size_t)n_words, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("hipExtMallocWithFlags(finegrained): ") + hipGetErrorString(e));
+  e = hipMemset(p, 0, sizeof(int64_t) * (size_t)n_words);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return fail(nullptr, PF_ERR_HIP, std::string("pfk_flags_alloc memset: ") + hipGetErrorString(e));
+  }
+  if (timeout_host) {
+    void* t = nullptr;
+    e = hipHostMalloc(&t, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      return fail(nullptr, PF_ERR_HIP, std::string("hipHostMalloc(mapped): ") + hipGetErrorString(e));
+    }
+    *reinterpret_cast<volatile int32_t*>(t) = 0;
+    *timeout_host = reinterpret_cast<int32_t*>(t);
+  }
+  *flags_dev = reinterpret_cast<int64_t*>(p);
+  return PF_OK;
+}
+
+int pfk_flags_free(int64_t* flags_dev, int32_t* timeout_host) {
+  if (flags_dev) (void)hipFree(flags_dev);
+  if (timeout_host) (void)hipHostFree(timeout_host);
+  return PF_OK;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "pfhip.h states a 64-byte IPC handle");
+
+int pfk_ipc_export(const void* dev_base, unsigned char handle[64]) {
+  if (!dev_base || !handle) return fail(nullptr, PF_ERR_INVALID, "pfk_ipc_export: null pointer");
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, const_cast<void*>(dev_base));
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+  memcpy(handle, &h, 64);
+  return PF_OK;
+}
+
+int pfk_ipc_import(const unsigned char handle[64], void** dev_ptr) {
+  if (!handle || !dev_ptr) return fail(nullptr, PF_ERR_INVALID, "pfk_ipc_import: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  hipError_t e = hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+  return PF_OK;
+}
+
+int pfk_ipc_close(void* dev_ptr) {
+  if (!dev_ptr) return PF_OK;
+  hipError_t e = hipIpcCloseMemHandle(dev_ptr);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("hipIpcCloseMemHandle: ") + hipGetErrorString(e));
+  return PF_OK;
+}
+
 int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier) {
   if (nblocks < 1 || nblocks > 1024 || nthreads < 64 || nthreads > 256 || iters < 1 || iters > 100000 || !us_per_barrier)
     return fail(nullptr, PF_ERR_INVALID, "pfk_grid_barrier_probe: bad arguments");

@@ -6,6 +6,10 @@
                             point / cell order and PointData layout as the reference's results/bench1/conc00000N.vtu
   read_vtu_pointdata        reader for both (and for the reference's ASCII / zlib-binary files)
   plot_stats                Python port of stats.jl:17-44 (free energy and normalised solute vs log time)
+  FieldStore                per-step field dump, the counterpart of the reference's HDF5File("results/bench1/conc.h5")
+                            (bench1.py:116-119: outfile.write(mesh, "mesh"); :190-191: outfile.write(c, "c", t)) with the
+                            same dataset names ("c/vector_<i>"), read back by postprocess.process_bench1 like
+                            dolfin/process_bench1.py:9-32 reads the HDF5 file.  Container: .npz (h5py is not in this image).
 """
 from __future__ import annotations
 
@@ -136,3 +140,66 @@ def plot_stats(csv_path, out_prefix):
             ax.set_ylim(*ylim)
         fig.savefig(out_prefix + suffix + ".png")
         plt.close(fig)
+
+
+class FieldStore:
+    """Write-once / read-many container of per-step fields.
+
+    writer:  st = FieldStore(path, "w"); st.write_mesh(kind="grid", h=..., shape=...) ; st.write(c, "c", t) per accepted
+             step (dataset "c/vector_<i>", time in "c/time_<i>" -- DOLFIN's HDF5 naming, bench1.py:190-191); st.close()
+    reader:  st = FieldStore(path, "r"); st.mesh() -> dict; st.count("c"); st.read("c", i); st.time("c", i)
+    The file is a plain numpy .npz (one zip member per dataset), written when the writer closes."""
+
+    def __init__(self, path, mode="r"):
+        if mode not in ("r", "w"):
+            raise ValueError("FieldStore mode must be 'r' or 'w'")
+        self.path, self.mode = path, mode
+        self._data, self._count = {}, {}
+        if mode == "r":
+            with np.load(path, allow_pickle=False) as z:
+                self._data = {k: z[k] for k in z.files}
+            for k in self._data:
+                m = re.match(r"(.+)/vector_(\d+)$", k)
+                if m:
+                    self._count[m.group(1)] = max(self._count.get(m.group(1), 0), int(m.group(2)) + 1)
+
+    # -- writer
+    def write_mesh(self, kind, **meta):
+        """kind = "grid" (uniform lattice: h, shape) or "crossed" (the reference's triangulation: N, L)"""
+        assert self.mode == "w"
+        self._data["mesh/kind"] = np.array(kind)
+        for k, v in meta.items():
+            self._data["mesh/" + k] = np.asarray(v)
+
+    def write(self, field, name, t):
+        assert self.mode == "w"
+        i = self._count.get(name, 0)
+        self._data["%s/vector_%d" % (name, i)] = np.array(field, dtype=np.float64, copy=True)
+        self._data["%s/time_%d" % (name, i)] = np.float64(t)
+        self._count[name] = i + 1
+
+    def close(self):
+        if self.mode == "w" and self._data is not None:
+            os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
+            with open(self.path, "wb") as fh:       # a file object: np.savez would append ".npz" to a bare name
+                np.savez(fh, **self._data)
+        self._data = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- reader
+    def mesh(self):
+        return {k[5:]: (v.item() if v.ndim == 0 else v) for k, v in self._data.items() if k.startswith("mesh/")}
+
+    def count(self, name):
+        return self._count.get(name, 0)
+
+    def read(self, name, i):
+        return self._data["%s/vector_%d" % (name, i)]
+
+    def time(self, name, i):
+        return float(self._data["%s/time_%d" % (name, i)])

@@ -95,6 +95,11 @@ SYMBOLS = {
     "pf_timing_read": (C.c_int, [_H, _D, C.POINTER(C.c_int64)]),
     "pf_timing_samples": (C.c_int, [_H, _D, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "pfk_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pfk_flags_alloc": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "pfk_flags_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pfk_ipc_export": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "pfk_ipc_import": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "pfk_ipc_close": (C.c_int, [C.c_void_p]),
     "pfk_ch_fd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.POINTER(PfkChParams), C.c_int, C.c_void_p]),
     "pfk_set_tuning": (C.c_int, [C.c_int, C.c_int]),

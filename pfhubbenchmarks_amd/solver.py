@@ -297,6 +297,16 @@ class HipSlabEngine:
         return ms.value, n.value
 
 
+class _Words:
+    """a raw device / host address with the `.data_ptr()` spelling of a tensor"""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
+
+    def data_ptr(self):
+        return self.ptr
+
+
 class IpcHaloTransport:
     """Ghost-plane exchange inside one node WITHOUT RCCL kernels: every rank maps its neighbours' buffers through CUDA
     IPC (torch.multiprocessing.reductions) and, per step, a small kernel on a side stream writes its boundary planes
@@ -307,7 +317,14 @@ class IpcHaloTransport:
     happens after its boundary launch of step k-2, the last reader of that plane; I push step k only after I consumed
     its step k-1 flag).  Why: RCCL's send/recv kernel is starved beside the HBM-saturating stencil and costs +27 us per
     step.  The torch.distributed group is used for the one-time handle exchange only.
-    Works between processes on different GPUs of a node and, for tests, between processes sharing one GPU."""
+
+    Memory kinds: the ghost planes are ordinary (coarse-grained) device memory -- their readers start after the flag
+    wait.  The FLAG words are polled by a running kernel while a peer GPU writes them, so they are fine-grained device
+    memory (pfk_flags_alloc, shared with pfk_ipc_export / pfk_ipc_import); the give-up mark of the bounded waits lives
+    in mapped host memory, so `check()` reads it without a device sync.
+
+    EXPERIMENTAL: validated between processes sharing one GPU (tests), never yet across two physical GPUs -- RCCL stays
+    the default transport of SlabSolver until such a run has bit-matched the single-GPU result."""
 
     def __init__(self, engine, group=None):
         import torch
@@ -315,30 +332,48 @@ class IpcHaloTransport:
         from torch.multiprocessing.reductions import reduce_tensor
         self.torch, self.e, self._lib = torch, engine, _lib.load()
         dev = engine.buffers[0].device
-        self.flags = torch.zeros(2, dtype=torch.int64, device=dev)    # [0]: written by the lo neighbour, [1]: by the hi
+        fl, to = C.c_void_p(), C.c_void_p()
+        _lib.check(self._lib.pfk_flags_alloc(2, C.byref(fl), C.byref(to)))
+        self._flags_ptr, self._timeout_ptr = fl.value, to.value
+        self.flags = _Words(fl.value)        # [0]: written by the lo neighbour, [1]: by the hi neighbour
+        self.timeout = _Words(to.value)      # mapped host int32: device address == host address (HIP unified addressing)
         self.tickets = torch.zeros(2, dtype=torch.int32, device=dev)
-        self.timeout = torch.zeros(1, dtype=torch.int32, device=dev)
         self.side = torch.cuda.Stream(device=dev)
         self.seq = 0
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         off1 = (engine.buffers[1].data_ptr() - engine.buffers[0].data_ptr()) // 8
         torch.cuda.synchronize(dev)
+        handle = C.create_string_buffer(64)
+        _lib.check(self._lib.pfk_ipc_export(C.c_void_p(fl.value), handle))
         objs = [None] * world
-        dist.all_gather_object(objs, (reduce_tensor(engine._block), reduce_tensor(self.flags), off1, engine.nz),
-                               group=group)
+        dist.all_gather_object(objs, (reduce_tensor(engine._block), handle.raw, off1, engine.nz), group=group)
         opened = {rank: (engine._block, self.flags, off1, engine.nz)}
+        self._imported = []
 
         def peer(r):
             if r < 0:
                 return None
             if r not in opened:
-                (fb, ab), (ff, af), o1, nz = objs[r]
-                opened[r] = (fb(*ab), ff(*af), o1, nz)
+                (fb, ab), hraw, o1, nz = objs[r]
+                pp = C.c_void_p()
+                _lib.check(self._lib.pfk_ipc_import(C.create_string_buffer(hraw, 64), C.byref(pp)))
+                self._imported.append(pp.value)
+                opened[r] = (fb(*ab), _Words(pp.value), o1, nz)
             return opened[r]
 
         self.lo, self.hi = peer(engine.rank_lo), peer(engine.rank_hi)
         self.plane = engine.buffers[0].shape[1] * engine.buffers[0].shape[2]
         dist.barrier(group=group)          # every rank has mapped its neighbours before anybody pushes
+
+    def close(self):
+        """unmap the neighbours' flag words and free this rank's own (after every rank has stopped pushing)"""
+        if getattr(self, "_flags_ptr", None):
+            self.torch.cuda.synchronize()
+            for p in self._imported:
+                self._lib.pfk_ipc_close(C.c_void_p(p))
+            self._imported = []
+            self._lib.pfk_flags_free(C.c_void_p(self._flags_ptr), C.c_void_p(self._timeout_ptr))
+            self._flags_ptr = self._timeout_ptr = None
 
     def post(self):
         """push my boundary planes of the CURRENT buffer into the neighbours' ghost planes (side stream); returns
@@ -373,9 +408,12 @@ class IpcHaloTransport:
                                                    C.c_void_p(self.timeout.data_ptr()), st))
 
     def check(self):
-        """after a device sync: raise if a wait gave up (a neighbour never published its planes)"""
-        if int(self.timeout.item()) != 0:
-            raise RuntimeError("IpcHaloTransport: timed out waiting for a neighbour's ghost planes")
+        """raise if a bounded wait gave up (a neighbour never published its planes: the step then ran on stale ghost
+        planes).  Reads the mapped host word -- no device sync; it sees every wait that has finished so far, so call it
+        after a sync for a final verdict (SlabSolver does, wherever results leave the device)."""
+        if self._timeout_ptr and C.c_int32.from_address(self._timeout_ptr).value != 0:
+            raise RuntimeError("IpcHaloTransport: timed out waiting for a neighbour's ghost planes -- the fields since "
+                               "then were computed with stale ghost planes")
 
 
 class SlabSolver:
@@ -437,6 +475,9 @@ class SlabSolver:
             for r in self._post_exchange():
                 r.wait()
         self.ghosts_fresh = True
+        if self.transport is not None:       # peer-copy transport: a wait that gave up means stale ghosts -- never silent
+            self.engine.sync()
+            self.transport.check()
 
     def step(self, dt, nsteps=1):
         e = self.engine
@@ -457,12 +498,16 @@ class SlabSolver:
                 e.step_finish()
             self.ghosts_fresh = False
             self.t += dt
+        if self.transport is not None:
+            self.transport.check()           # non-blocking (mapped host word): any wait that has already given up
 
     def diagnostics(self):
         """(total_free_energy, total_solute, f_elec) summed over ranks (the reference's implicit MPI_Allreduce)."""
         import torch
         self.exchange()
-        loc = self.engine.diag_local()
+        loc = self.engine.diag_local()       # synchronises the engine's stream
+        if self.transport is not None:
+            self.transport.check()
         dev = self.engine.buffers[0].device if self.dist.get_backend(self.group) == "nccl" else "cpu"
         t = torch.tensor(loc, dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -473,6 +518,8 @@ class SlabSolver:
         """Whole field on every rank (testing / small runs only)."""
         import torch
         loc = torch.from_numpy(self.engine.get_local())
+        if self.transport is not None:
+            self.transport.check()
         world = self.dist.get_world_size(self.group)
         if self.dist.get_backend(self.group) == "nccl":
             loc = loc.to(self.engine.buffers[0].device)

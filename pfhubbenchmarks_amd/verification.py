@@ -1,0 +1,103 @@
+"""Scheme-to-reference verification (SURVEY.md section 7.0-5 route (a); VERDICT r01 "next round" #3).
+
+The committed reference trajectory (results/bench1_out.csv) carries the backward-Euler error of its own large steps
+(dt = 1.6 at t = 7.9: 3.6e-2 in F), so the throughput schemes (explicit FD, semi-implicit spectral) cannot be compared
+with it row by row.  What CAN be compared is the limit: the reference's ALGORITHM (P1 'crossed' FEM + backward Euler,
+dolfin/pfbase.py:361-383, run here by the GPU BE-parity mode that reproduces the committed CSV to 5e-9) refined in
+h and dt, against the FD and the spectral scheme refined the same way.  All three are Richardson-extrapolated:
+
+  FEM-BE   F(h, dt) = F* + A h^2 + B dt + B2 dt^2 + C h^2 dt      5 runs: h = 2 at dt, dt/2, dt/4; h = 1 at dt, dt/2
+  FD       F(h, dt) = F* + A h^2 + B dt + C h^2 dt                4 runs: h = 1, 0.5 at the stable dt and half of it
+  spectral F(dt)    = F* + B dt + B2 dt^2   (spatially converged) 3 runs: dt, dt/2, dt/4 (+ a coarser lattice as a check)
+
+Everything runs through the product API (PhaseFieldSolver over libpfhip); nothing here touches oracle/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .solver import PhaseFieldSolver, stable_dt
+
+L_BM1 = 200.0          # dolfin/bench1.py:21
+
+
+def _march(s, times, dt):
+    """fixed-size steps to each report time (all times are multiples of dt to rounding); returns F at each"""
+    out, t = [], 0.0
+    for T in times:
+        n = int(round((T - t) / dt))
+        assert abs(n * dt - (T - t)) < 1e-9, (T, t, dt)
+        s.step(dt, n)
+        t = T
+        out.append(s.diagnostics()[0])
+    return np.array(out)
+
+
+def fem_be_energy(intervals, dt, times):
+    """the reference's algorithm at mesh size h = 200 / intervals with fixed BE steps"""
+    out, t = [], 0.0
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L_BM1 / intervals, bc="mirror", scheme="fem_be") as s:
+        s.set_ic_bm1(0.5, 0.05)
+        for T in times:
+            n = int(round((T - t) / dt))
+            assert abs(n * dt - (T - t)) < 1e-9
+            for _ in range(n):
+                ok, _, _ = s.step(dt, 1, check=True)
+                if not ok:
+                    raise RuntimeError("fem_be: Newton failed at t = %g (h = %g, dt = %g)" % (s.t, L_BM1 / intervals, dt))
+            t = T
+            out.append(s.diagnostics()[0])
+    return np.array(out)
+
+
+def grid_energy(scheme, intervals, dt, times):
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L_BM1 / intervals, bc="mirror", scheme=scheme) as s:
+        s.set_ic_bm1(0.5, 0.05)
+        return _march(s, times, dt)
+
+
+def quad_extrapolate(f1, f2, f4):
+    """limit dt -> 0 of f(dt) = f0 + b dt + b2 dt^2 from f(dt), f(dt/2), f(dt/4); also returns b2 dt^2"""
+    # f1 - f2 = b dt/2 + 3/4 b2 dt^2 ; f2 - f4 = b dt/4 + 3/16 b2 dt^2
+    b2dt2 = (8.0 / 3.0) * ((f1 - f2) - 2.0 * (f2 - f4))
+    bdt = 2.0 * ((f1 - f2) - 0.75 * b2dt2)
+    return f1 - bdt - b2dt2, b2dt2
+
+
+def fem_be_limit(times, dt=0.1, log=None):
+    """F*(t) of the reference's algorithm, (h, dt) -> (0, 0)"""
+    runs = {}
+    for N, d in ((100, dt), (100, dt / 2), (100, dt / 4), (200, dt), (200, dt / 2)):
+        runs[(N, d)] = fem_be_energy(N, d, times)
+        if log:
+            log("fem_be h = %g dt = %g: %s" % (L_BM1 / N, d, np.array2string(runs[(N, d)], precision=6)))
+    g2, b2dt2 = quad_extrapolate(runs[(100, dt)], runs[(100, dt / 2)], runs[(100, dt / 4)])      # h = 2, dt -> 0
+    # h = 1: remove the dt^2 term found at h = 2, then linear extrapolation in dt
+    a, b = runs[(200, dt)] - b2dt2, runs[(200, dt / 2)] - b2dt2 / 4.0
+    g1 = 2.0 * b - a
+    return (4.0 * g1 - g2) / 3.0, {"h2_dt0": g2, "h1_dt0": g1, "runs": runs}
+
+
+def fd_limit(times, log=None):
+    """explicit FD scheme, (h, dt) -> (0, 0): first order in dt, second order in h"""
+    lim = {}
+    for N in (200, 400):
+        h = L_BM1 / N
+        d = stable_dt(h, dim=2, safety=0.4)
+        d = 0.1 / np.ceil(0.1 / d - 1e-9)      # a dt that divides every report time (all are multiples of 0.1)
+        f1, f2 = grid_energy("fd", N, d, times), grid_energy("fd", N, d / 2, times)
+        lim[N] = 2.0 * f2 - f1
+        if log:
+            log("fd h = %g dt = %.4g / half: %s / %s" % (h, d, np.array2string(f1, precision=6),
+                                                           np.array2string(f2, precision=6)))
+    return (4.0 * lim[400] - lim[200]) / 3.0, {"h1_dt0": lim[200], "h05_dt0": lim[400]}
+
+
+def spectral_limit(times, intervals=256, dt=0.01, log=None):
+    """semi-implicit spectral scheme on the even extension (2 * intervals lattice points), dt -> 0"""
+    f = [grid_energy("spectral", intervals, d, times) for d in (dt, dt / 2, dt / 4)]
+    if log:
+        for d, v in zip((dt, dt / 2, dt / 4), f):
+            log("spectral N = %d dt = %g: %s" % (intervals, d, np.array2string(v, precision=6)))
+    lim, _ = quad_extrapolate(*f)
+    return lim, {"runs": f}

@@ -45,6 +45,8 @@ def main():
         np.savez(out + ".rank%d.npz" % rank, local=eng.get_local(), z0=eng.z0, d0=np.array(d0), d1=np.array(d1),
                  full=full)
     dist.barrier()
+    if s.transport is not None:
+        s.transport.close()
     eng.close()
     dist.destroy_process_group()
     print("IPC_SLAB_OK rank %d" % rank, flush=True)

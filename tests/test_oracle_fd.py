@@ -114,3 +114,21 @@ def test_bm6_spectral_oracle_agrees_with_the_fd_phi_eliminated_oracle():
     Fa, Ca, Ea = a.diagnostics()
     Fb, Cb, Eb = b.diagnostics()
     assert abs(Ca - Cb) < 1e-9 and abs(Fa - Fb) < 1e-4 * abs(Fb) and abs(Ea - Eb) < 1e-2 * abs(Eb)
+
+
+def test_oracle_under_asan_ubsan():
+    """SURVEY.md section 5 (sanitizers on the CPU build): oracle/sanitize_check.c drives every entry point of
+    oracle/ch_fd.c over the edge shapes on exactly-sized heap buffers, built with -fsanitize=address,undefined; it must
+    run clean and print the same checksum as the plain build of the same driver."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "sanitize"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    a = subprocess.run([os.path.join(root, "oracle", "sanitize_check_asan")], capture_output=True, text=True, env=env,
+                       timeout=300)
+    p = subprocess.run([os.path.join(root, "oracle", "sanitize_check_plain")], capture_output=True, text=True,
+                       timeout=300)
+    assert a.returncode == 0 and a.stderr.strip() == "", a.stderr[-3000:]
+    assert p.returncode == 0
+    assert a.stdout.startswith("SANITIZE_OK cases=121") and a.stdout == p.stdout, (a.stdout, p.stdout)

@@ -1,11 +1,8 @@
-"""Convergence study: the GPU schemes and the reference's algorithm approach the SAME solution of
-PFHub BM1 as (h, dt) -> 0, although the committed reference trajectory (h = 2, dt up to 102.4) is 3.7e-2 away from it.
-
-Runs on the GPU box; writes results/CONVERGENCE.md.  All runs: 200 x 200 no-flux domain, BM1 initial condition.
-  fem_be  : the reference's own discretisation (PF_SCHEME_FEM_BE) at (N, dt) = (100, 0.1), (100, 0.05), (200, 0.05), (200, 0.025)
-  fd      : explicit finite differences at h = 2, 1, 0.5 (stable dt)
-  spectral: semi-implicit Fourier (even extension) at N = 256 / 512 lattice points... (h = 400/N), dt = 0.01, 0.0025
-F is reported at t = 4.7, 7.9, 11.1 (the rows where the committed CSV deviates most)."""
+"""Convergence study: the GPU schemes and the reference's algorithm approach
+the SAME solution of PFHub BM1 as (h, dt) -> 0, although the committed reference trajectory (h = 2, dt up to 102.4) is
+3.6e-2 away from it.  Runs on the GPU box through pfhubbenchmarks_amd/verification.py (the same functions the -m gpu
+test tests/test_gpu_parity.py::test_schemes_converge_to_the_reference_algorithm asserts on) and writes
+results/CONVERGENCE.md."""
 import os
 import sys
 import time
@@ -14,72 +11,57 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from pfhubbenchmarks_amd.drivers import advance_to  # noqa: E402
-from pfhubbenchmarks_amd.solver import PhaseFieldSolver, stable_dt  # noqa: E402
+from pfhubbenchmarks_amd import verification as V  # noqa: E402
 
-TS = (4.7, 7.9, 11.1)
-
-
-def run_fem(N, dt):
-    out = []
-    with PhaseFieldSolver(dim=2, n=N + 1, h=200.0 / N, bc="mirror", scheme="fem_be") as s:
-        s.set_ic_bm1()
-        t, k = 0.0, 0
-        for T in TS:
-            n = int(round((T - t) / dt))
-            for _ in range(n):
-                ok, _, _ = s.step(dt, 1, check=True)
-                assert ok
-            t = T
-            out.append(s.diagnostics()[0])
-    return out
-
-
-def run_grid(scheme, intervals, dt):
-    out = []
-    h = 200.0 / intervals
-    with PhaseFieldSolver(dim=2, n=intervals + 1, h=h, bc="mirror", scheme=scheme) as s:
-        s.set_ic_bm1()
-        for T in TS:
-            advance_to(s, T, dt, dt / 64)
-            out.append(s.diagnostics()[0])
-    return out
+TS = (0.7, 3.1, 4.7, 7.9)
 
 
 def main():
     ref = np.loadtxt(os.path.join(ROOT, "tests", "golden", "bench1_out.csv"), delimiter=",", skiprows=1)
-    rows = [("committed `results/bench1_out.csv` of the reference (FEniCS, h = 2, dt = 1.6 there)",
-             [float(ref[np.argmin(abs(ref[:, 0] - T)), 1]) for T in TS], 0.0)]
-    jobs = [("GPU `fem_be` (reference algorithm) h = 2, dt = 0.1", lambda: run_fem(100, 0.1)),
-            ("GPU `fem_be` h = 2, dt = 0.05", lambda: run_fem(100, 0.05)),
-            ("GPU `fem_be` h = 1, dt = 0.05", lambda: run_fem(200, 0.05)),
-            ("GPU `fem_be` h = 1, dt = 0.025", lambda: run_fem(200, 0.025)),
-            ("GPU `fd` explicit h = 2, dt = 0.02", lambda: run_grid("fd", 100, 0.02)),
-            ("GPU `fd` explicit h = 1, dt = %.3g" % stable_dt(1.0, dim=2, safety=0.4),
-             lambda: run_grid("fd", 200, stable_dt(1.0, dim=2, safety=0.4))),
-            ("GPU `fd` explicit h = 0.5, dt = %.3g" % stable_dt(0.5, dim=2, safety=0.4),
-             lambda: run_grid("fd", 400, stable_dt(0.5, dim=2, safety=0.4))),
-            ("GPU `spectral` h = 1.5625 (256 lattice), dt = 0.01", lambda: run_grid("spectral", 128, 0.01)),
-            ("GPU `spectral` h = 0.78125 (512 lattice), dt = 0.01", lambda: run_grid("spectral", 256, 0.01)),
-            ("GPU `spectral` h = 0.78125 (512 lattice), dt = 0.0025", lambda: run_grid("spectral", 256, 0.0025))]
-    for name, fn in jobs:
-        t0 = time.time()
-        vals = fn()
-        rows.append((name, vals, time.time() - t0))
-        print(name, vals, "%.1f s" % rows[-1][2], flush=True)
-    best = rows[-1][1]
+    committed = np.array([float(ref[np.argmin(abs(ref[:, 0] - T)), 1]) for T in TS])
+    lines = []
+
+    def log(msg):
+        print(msg, flush=True)
+        lines.append(msg)
+    t0 = time.time()
+    fem, fem_d = V.fem_be_limit(TS, log=log)
+    t_fem = time.time() - t0
+    t0 = time.time()
+    fd, fd_d = V.fd_limit(TS, log=log)
+    t_fd = time.time() - t0
+    t0 = time.time()
+    sp, sp_d = V.spectral_limit(TS, log=log)
+    sp128, _ = V.spectral_limit(TS, intervals=128)
+    t_sp = time.time() - t0
+    rel = lambda a, b: np.abs(a - b) / np.abs(b)  # noqa: E731
     with open(os.path.join(ROOT, "results", "CONVERGENCE.md"), "w") as f:
         f.write("# Convergence of the GPU schemes and of the reference's algorithm to one solution (PFHub BM1)\n\n")
-        f.write("Produced by `python tools/convergence_study.py` on an MI355X.  Total free energy F(t); the last column is "
-                "the relative distance at t = 7.9 to the finest spectral run.\n\n")
-        f.write("| run | F(4.7) | F(7.9) | F(11.1) | rel. dist. @7.9 | wall |\n|---|---|---|---|---|---|\n")
-        for name, v, w in rows:
-            f.write("| %s | %.4f | %.4f | %.4f | %.1e | %s |\n" % (name, v[0], v[1], v[2], abs(v[1] - best[1]) / best[1],
-                                                                  "%.1f s" % w if w else "—"))
-        f.write("\nReading: the committed reference trajectory carries its own backward-Euler error (dt = 1.6 at these times); "
-                "the reference's *algorithm*, refined in h and dt, the explicit FD scheme and the spectral scheme all "
-                "approach the same values.  Row-by-row agreement with the committed CSV itself is the BE-parity mode's job "
-                "(`results/fem_be/`: <= 5e-9).\n")
+        f.write("Produced by `python tools/convergence_study.py` on an MI355X (`pfhubbenchmarks_amd/verification.py`; the\n"
+                "same numbers are asserted by `tests/test_gpu_parity.py::test_schemes_converge_to_the_reference_algorithm`).\n"
+                "Total free energy F(t) on the 200 x 200 no-flux domain, each scheme Richardson-extrapolated to (h, dt) -> 0.\n\n")
+        f.write("| quantity | " + " | ".join("F(%.1f)" % T for T in TS) + " |\n|---|" + "---|" * len(TS) + "\n")
+
+        def row(name, v, fmt="%.5f"):
+            f.write("| %s | " % name + " | ".join(fmt % x for x in v) + " |\n")
+        row("committed `results/bench1_out.csv` (FEniCS, h = 2, adaptive dt up to 1.6 here)", committed)
+        row("reference algorithm (GPU `fem_be`), h = 2, dt -> 0", fem_d["h2_dt0"])
+        row("reference algorithm, h = 1, dt -> 0", fem_d["h1_dt0"])
+        row("**reference algorithm, (h, dt) -> 0**", fem)
+        row("explicit FD, h = 1, dt -> 0", fd_d["h1_dt0"])
+        row("explicit FD, h = 0.5, dt -> 0", fd_d["h05_dt0"])
+        row("**explicit FD, (h, dt) -> 0**", fd)
+        row("spectral, 256 lattice, dt -> 0", sp128)
+        row("**spectral, 512 lattice, dt -> 0**", sp)
+        row("rel. distance FD limit vs reference-algorithm limit", rel(fd, fem), "%.1e")
+        row("rel. distance spectral limit vs reference-algorithm limit", rel(sp, fem), "%.1e")
+        row("rel. distance FD limit vs spectral limit", rel(fd, sp), "%.1e")
+        row("rel. distance committed CSV vs reference-algorithm limit", rel(committed, fem), "%.1e")
+        f.write("\nWall: fem_be runs %.0f s, FD runs %.1f s, spectral runs %.1f s.\n\nRaw runs:\n\n```\n%s\n```\n"
+                % (t_fem, t_fd, t_sp, "\n".join(lines)))
+        f.write("\nReading: the committed reference trajectory carries its own backward-Euler error; the reference's "
+                "*algorithm*, refined in h and dt, the explicit FD scheme and the spectral scheme approach the same values.  "
+                "Row-by-row agreement with the committed CSV itself is the BE-parity mode's job (`results/fem_be/`: <= 5e-9).\n")
     print(open(os.path.join(ROOT, "results", "CONVERGENCE.md")).read())
 
 
