@@ -713,7 +713,7 @@ def test_drivers_save_solution_and_process_bench1(lib, golden_dir, tmp_path):
     rows2, _ = run_bench1(intervals=100, scheme="fd", end_time=0.5, out_dir=out2, save_solution=True, verbose=False)
     mesh2, times2, cs2, stats2 = postprocess.process_bench1(os.path.join(out2, "bench1"))
     assert mesh2["kind"] == "grid" and mesh2["h"] == 2.0 and len(cs2) == rows2.shape[0] == 3
-    assert cs2[0].shape == (101, 101) and abs(cs2[2].mean() - 0.5126) < 1e-3
+    assert cs2[0].shape == (101, 101) and abs(cs2[2].mean() - 0.5126) < 3e-3
     files2 = postprocess.write_series(os.path.join(out2, "bench1"), mesh2, times2, cs2)
     np.testing.assert_array_equal(pio.read_vtu_pointdata(files2[1])["c"].reshape(101, 101), cs2[1])
 
