@@ -258,7 +258,9 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
 /* tuning hooks for benchmarks: key 0 = fused-kernel variant (table in csrc/ch_fd_kernels.hip);
  * key 1 = target number of workgroups for the z-chunk split; key 2 = minimum planes per z-chunk;
  * key 3 = largest number of 2-D time steps fused into one launch (1, 2 or 4); key 4 = 10 K + rows per wave of the 2-D
- * K-step kernel; keys 5 / 6 = workgroups per CU / kernel form of pfk_stream_copy; key 7 = workgroups per pfk_push_planes message */
+ * K-step kernel; keys 5 / 6 = workgroups per CU / kernel form of pfk_stream_copy; key 7 = workgroups per pfk_push_planes
+ * message; key 8 = diagnostics kernel form (10 x rows per wave + planes in flight; 0 = the round-1 kernel); key 9 = its
+ * target workgroup count */
 int pfk_set_tuning(int key, int value);
 
 /* Device copy dst[i] = src[i], n doubles, 16-byte accesses: the measured HBM ceiling for a 1-read + 1-write stream

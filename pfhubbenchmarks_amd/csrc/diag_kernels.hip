@@ -162,6 +162,134 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_stream_kernel(const double* _
     for (int q = 0; q < 6; ++q) partials[(int64_t)blockIdx.x * 6 + q] = v[q];
 }
 
+// ---- streaming partial kernel, second generation (round 2) ---------------------------------------------------------
+// diag_stream_kernel above reaches 3.6 TB/s at 512^3: every row is loaded twice (once by its owner, once as the "up" row
+// of the wave below, requested in the iteration that consumes it) and only one plane per wave is in flight, i.e. 32 KiB
+// of HBM requests per CU -- at ~2 us loaded latency that is the 4 TB/s it delivers.  Here
+//   * a wave owns ROWS adjacent rows of 128 cells (16-byte buffer loads, 1 KiB per wave instruction): the y+1 neighbour
+//     comes from the wave's own registers except for ONE halo row per ROWS rows (read over-fetch (ROWS+1)/ROWS from
+//     L2, not 2x), x+1 by wave shuffle, z+1 from the register ring;
+//   * planes z .. z+DEPTH are in flight in a register ring (the slot of plane z is refilled with plane z+DEPTH+1 as soon
+//     as it has been consumed), loads are branch-free through buffer descriptors (a plane past the chunk gets a
+//     zero-length descriptor, an inactive lane an out-of-range offset);
+//   * XCD-aware tile order (blocks b, b+8, .. share an L2; each XCD takes a contiguous run of tiles) so the halo row is
+//     an L2 hit; ~4 workgroups per CU, all co-resident.
+typedef unsigned int du32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t DOOB = 0x80000000u;
+__device__ __forceinline__ auto dplane_rsrc(const double* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, (int)bytes, 0x00020000);
+}
+template <class R>
+__device__ __forceinline__ double2 dbld2(R rs, uint32_t boff) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)boff, 0, 0));
+}
+template <class R>
+__device__ __forceinline__ double dbld1(R rs, uint32_t boff) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(double, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(rs, (int)boff, 0, 0));
+}
+
+struct DiagArgs {
+  const double* c;
+  const double* phi;
+  int nx, ny, nz, ghost, zwrap, zends;
+  int ntx, nty, zchunk, ntiles;
+  double rho, ca, cb;
+  double* partials;
+};
+
+template <int ROWS, int DEPTH, bool HAS_PHI>
+__global__ __launch_bounds__(DIAG_BLOCK) void diag_stream2_kernel(const DiagArgs k) {
+  __shared__ double sh[24];
+  constexpr int NS = DEPTH + 1;  // ring slots: planes z .. z+DEPTH
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double v[6] = {0.0, 0.0, 0.0, 0.0, INFINITY, -INFINITY};
+  const int per = gridDim.x >> 3;
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (t < k.ntiles) {
+    const int tx = t % k.ntx, ty = (t / k.ntx) % k.nty, ch = t / (k.ntx * k.nty);
+    const int x = tx * 128 + 2 * lane, y0 = ty * (4 * ROWS) + wave * ROWS;
+    const bool lane_on = x < k.nx;
+    const bool last = x + 2 >= k.nx || lane == 63;  // this lane's x+1 neighbour of its second cell is not in lane+1
+    const int64_t plane = (int64_t)k.nx * k.ny;
+    const uint32_t plane_bytes = (uint32_t)(plane * 8);
+    uint32_t off[ROWS + 1], offx[ROWS];
+    bool row_on[ROWS];
+#pragma unroll
+    for (int r = 0; r <= ROWS; ++r) {
+      int y = y0 + r;
+      const bool on = lane_on && (r < ROWS ? y < k.ny : y - 1 < k.ny);  // halo row: needed iff the row above it is on
+      if (y >= k.ny) y -= k.ny;                                          // y0 + ROWS <= ny + ROWS - 1 < 2 ny when on
+      off[r] = on ? (uint32_t)(((int64_t)y * k.nx + x) * 8) : DOOB;
+      if (r < ROWS) {
+        row_on[r] = on;
+        const int xn = x + 2 >= k.nx ? 0 : x + 2;
+        offx[r] = (on && last) ? (uint32_t)(((int64_t)y * k.nx + xn) * 8) : DOOB;
+      }
+    }
+    const int zs = ch * k.zchunk, ze = min(k.nz, zs + k.zchunk);
+    auto zoff = [&](int p) -> int64_t { return (int64_t)((k.zwrap ? wrapi(p, k.nz) : p) + k.ghost) * plane; };
+    double2 R[NS][ROWS + 1], PH[NS][ROWS];
+    double XR[NS][ROWS];
+    auto load_plane = [&](int slot, int p) {
+      const bool valid = p <= ze;  // plane ze is the z+1 neighbour of the chunk's last plane
+      const auto rc = dplane_rsrc(k.c + zoff(valid ? p : ze), valid ? plane_bytes : 0u);
+#pragma unroll
+      for (int r = 0; r <= ROWS; ++r) R[slot][r] = dbld2(rc, off[r]);
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) XR[slot][r] = dbld1(rc, offx[r]);
+      if constexpr (HAS_PHI) {
+        const bool pv = p < ze;
+        const auto rp = dplane_rsrc(k.phi + zoff(pv ? p : zs), pv ? plane_bytes : 0u);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) PH[slot][r] = dbld2(rp, off[r]);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < NS; ++d) load_plane(d, zs + d);
+    for (int z0 = zs; z0 < ze; z0 += NS) {
+#pragma unroll
+      for (int d = 0; d < NS; ++d) {
+        const int z = z0 + d;
+        if (z < ze) {
+          const int nslot = (d + 1) % NS;
+          const double wz = zweight(z, k.nz, k.zends), wd = (z == k.nz - 1 && (k.zends & 2)) ? 0.0 : 1.0;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const double2 cur = R[d][r], up = R[d][r + 1], nxt = R[nslot][r];
+            double xr = __shfl_down(cur.x, 1, 64);
+            if (last) xr = XR[d][r];
+            if (row_on[r]) {
+              double a = cur.x - k.ca, b = k.cb - cur.x, ab = a * b;
+              double f = k.rho * (ab * ab);
+              double dx = cur.y - cur.x, dy = up.x - cur.x, dz = nxt.x - cur.x;
+              double g = wz * (dx * dx + dy * dy) + wd * (dz * dz);
+              a = cur.y - k.ca;
+              b = k.cb - cur.y;
+              ab = a * b;
+              f += k.rho * (ab * ab);
+              dx = xr - cur.y;
+              dy = up.y - cur.y;
+              dz = nxt.y - cur.y;
+              g += wz * (dx * dx + dy * dy) + wd * (dz * dz);
+              v[0] += wz * (cur.x + cur.y);
+              v[1] += wz * f;
+              v[2] += g;
+              if constexpr (HAS_PHI) v[3] += wz * (cur.x * PH[d][r].x + cur.y * PH[d][r].y);
+              v[4] = fmin(v[4], fmin(cur.x, cur.y));
+              v[5] = fmax(v[5], fmax(cur.x, cur.y));
+            }
+          }
+          load_plane(d, z + NS);  // refill the slot just consumed: planes z+1 .. z+DEPTH stay in flight meanwhile
+        }
+      }
+    }
+  }
+  block_reduce6(v, sh);
+  if (threadIdx.x == 0)
+    for (int q = 0; q < 6; ++q) k.partials[(int64_t)blockIdx.x * 6 + q] = v[q];
+}
+
 __global__ __launch_bounds__(DIAG_BLOCK) void diag_final_kernel(const double* __restrict__ partials, int nblocks,
                                                                double* __restrict__ out6) {
   __shared__ double sh[24];
@@ -307,6 +435,10 @@ __global__ __launch_bounds__(256) void stream_copy_flat_kernel(const double2* __
   if (i < n2) dst[i] = src[i];
 }
 
+// measured (tools/diag_ab.py, profiles/r02/diag_ab_*.log; wall per pf_diagnostics call incl. launch + read-back):
+// 512^3 0.277 ms (round-1 kernel) -> 0.196 ms <4,2> at 2 workgroups per CU; 1024^3 2.215 -> 1.485 ms; BM6 (c and phi
+// streams) 0.454 -> 0.349 ms with <2,1>
+int g_diag_variant = -1 /* auto: <4,2>, with phi <2,1> */, g_diag_target_blocks = 512;
 int g_copy_wgs_per_cu = 16, g_copy_mode = 5;  // flat: 6.2 TB/s vs 5.2-5.7 for the looping forms (profiles/r01/copy_sweep.txt)
 
 }  // namespace
@@ -409,12 +541,69 @@ hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, 
 
 int diag_partials_elems() { return DIAG_MAX_BLOCKS * 6; }
 
+// pfk_set_tuning keys 8 / 9: 10 ROWS + DEPTH of diag_stream2_kernel (0 = the round-1 kernel), target workgroups
+void set_diag_tuning(int variant, int target_blocks) {
+  if (variant >= 0) g_diag_variant = variant;
+  if (target_blocks > 0) g_diag_target_blocks = target_blocks;
+}
+
 hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, int zends,
                        double rho, double ca, double cb, double* partials, double* out6, hipStream_t stream) {
   const int64_t total = (int64_t)nx * ny * nz;
   int64_t nb;
   const bool aligned = (nx % 2 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) &&
                        (phi == nullptr || (reinterpret_cast<uintptr_t>(phi) & 15) == 0);
+  const int variant = g_diag_variant < 0 ? (phi ? 21 : 42) : g_diag_variant;
+  if (aligned && variant > 0 && (int64_t)nx * ny * 8 < (int64_t)DOOB) {
+    const int rows = variant / 10;  // variant = 10 ROWS + DEPTH (validated by pfk_set_tuning)
+    DiagArgs k;
+    k.c = c;
+    k.phi = phi;
+    k.nx = nx;
+    k.ny = ny;
+    k.nz = nz;
+    k.ghost = ghost;
+    k.zwrap = zwrap;
+    k.zends = zends;
+    k.ntx = (nx + 127) / 128;
+    k.nty = (ny + 4 * rows - 1) / (4 * rows);
+    const int64_t xy = (int64_t)k.ntx * k.nty;
+    int nchunk = (int)((g_diag_target_blocks + xy - 1) / xy);
+    if (nchunk > nz) nchunk = nz;
+    if (nchunk < 1) nchunk = 1;
+    while (xy * nchunk > DIAG_MAX_BLOCKS - 8 && nchunk > 1) --nchunk;
+    k.zchunk = (nz + nchunk - 1) / nchunk;
+    nchunk = (nz + k.zchunk - 1) / k.zchunk;
+    k.ntiles = (int)(xy * nchunk);
+    k.rho = rho;
+    k.ca = ca;
+    k.cb = cb;
+    k.partials = partials;
+    nb = ((xy * nchunk + 7) / 8) * 8;  // XCD-aware order needs a multiple of 8; surplus blocks write neutral partials
+    if (nb <= DIAG_MAX_BLOCKS) {
+#define PF_DIAG_LAUNCH(RW, DP)                                                                                        \
+  do {                                                                                                                \
+    if (phi)                                                                                                          \
+      hipLaunchKernelGGL((diag_stream2_kernel<RW, DP, true>), dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, k);         \
+    else                                                                                                              \
+      hipLaunchKernelGGL((diag_stream2_kernel<RW, DP, false>), dim3((int)nb), dim3(DIAG_BLOCK), 0, stream, k);        \
+  } while (0)
+      switch (variant) {
+        case 21: PF_DIAG_LAUNCH(2, 1); break;
+        case 22: PF_DIAG_LAUNCH(2, 2); break;
+        case 23: PF_DIAG_LAUNCH(2, 3); break;
+        case 41: PF_DIAG_LAUNCH(4, 1); break;
+        case 43: PF_DIAG_LAUNCH(4, 3); break;
+        case 12: PF_DIAG_LAUNCH(1, 2); break;
+        case 13: PF_DIAG_LAUNCH(1, 3); break;
+        default: PF_DIAG_LAUNCH(4, 2); break;
+      }
+#undef PF_DIAG_LAUNCH
+      hipLaunchKernelGGL(diag_final_kernel, dim3(1), dim3(DIAG_BLOCK), 0, stream, (const double*)partials, (int)nb,
+                         out6);
+      return hipGetLastError();
+    }
+  }
   if (aligned) {
     const int ntx = (nx + 127) / 128, nty = (ny + DS_ROWS - 1) / DS_ROWS;
     const int64_t xy = (int64_t)ntx * nty;

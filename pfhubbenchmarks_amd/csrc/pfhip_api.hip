@@ -1218,6 +1218,15 @@ int pfk_set_tuning(int key, int value) {
     set_push_wgs(value);
     return PF_OK;
   }
+  if (key == 8 && (value == 0 || value == 12 || value == 13 || value == 21 || value == 22 || value == 23 || value == 41 ||
+                   value == 42 || value == 43)) {  // diagnostics kernel: 10 ROWS + DEPTH (0 = round-1 kernel)
+    set_diag_tuning(value, 0);
+    return PF_OK;
+  }
+  if (key == 9 && value > 0) {  // diagnostics kernel: target number of workgroups
+    set_diag_tuning(-1, value);
+    return PF_OK;
+  }
   if (key == 6 && value >= 0 && value <= 5) {  // pfk_stream_copy: kernel form (table in csrc/diag_kernels.hip)
     set_copy_tuning(0, value);
     return PF_OK;

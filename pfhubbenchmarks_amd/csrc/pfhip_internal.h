@@ -46,6 +46,7 @@ void set_2d_rows(int k, int rows);
 // diagnostics: raw sums {sum c, sum f_chem, sum |fwd diff|^2, sum c*phi, min c, max c} -> out6 (device, 6 doubles)
 // partials: device scratch of diag_partials_elems() doubles
 int diag_partials_elems();
+void set_diag_tuning(int variant, int target_blocks);  // < 0 / <= 0: keep
 // zends: bit 0 / bit 1 = local plane 0 / nz-1 is a no-flux wall of a z-line decomposition (trapezoid weights)
 hipError_t launch_diag(const double* c, const double* phi, int nx, int ny, int nz, int ghost, int zwrap, int zends,
                        double rho, double ca, double cb, double* partials, double* out6, hipStream_t stream);
