@@ -17,7 +17,7 @@ def main():
     out, mode = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n = (16, 12, 8)
+    n = (16, 12, 8) if world <= 4 else (16, 2 * world, 2 * world)    # slab FFT: ny and nz divisible by the ranks
     eng = OracleFFTSlabEngine(n, 1.0, world, rank, scheme="spectral" if mode == "spectral" else "fd",
                               model="bm6" if mode.startswith("bm6") else "bm1", eliminate_phi=mode == "bm6_elim")
     rng = np.random.default_rng(4)

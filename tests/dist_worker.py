@@ -19,7 +19,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bc = sys.argv[3] if len(sys.argv) > 3 else "periodic"
-    n = (16, 10, 12) if bc == "periodic" else (9, 6, 12)     # mirror: nodes of the no-flux box
+    nzg = max(12, 3 * world)                                 # >= 3 planes per rank (the mirror line needs them)
+    n = (16, 10, nzg) if bc == "periodic" else (9, 6, nzg)   # mirror: nodes of the no-flux box
     eng = OracleSlabEngine(n, 1.0, world, rank, bc=bc)
     rng = np.random.default_rng(3)
     full = 0.5 + 0.1 * rng.standard_normal((n[2], n[1], n[0]))

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_solver_matches_single_domain(world, tmp_path, orc):
     out = str(tmp_path / "res.npz")
     nsteps = 4
@@ -45,7 +45,7 @@ def test_slab_solver_matches_single_domain(world, tmp_path, orc):
     np.testing.assert_array_equal(res["field"], c)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_mirror_bc_line_of_slabs_matches_even_extension(world, tmp_path, orc):
     """PF_BC_MIRROR in slab mode ('a line with local reflection at the ends'): SlabSolver skips the wall
     neighbours (-1), the engine mirrors its own planes; result = the whole-domain oracle on the 3-D even extension."""
@@ -73,15 +73,16 @@ def test_mirror_bc_line_of_slabs_matches_even_extension(world, tmp_path, orc):
     np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
 
 
-@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim"])
-def test_fft_slab_solver_matches_single_domain(mode, tmp_path, orc):
-    """the all-to-all / halo orchestration of FFTSlabSolver (world size 2, gloo) against the single-domain oracles"""
+@pytest.mark.parametrize("mode,world", [("spectral", 2), ("bm6", 2), ("bm6_elim", 2), ("spectral", 8), ("bm6", 8)])
+def test_fft_slab_solver_matches_single_domain(mode, world, tmp_path, orc):
+    """the all-to-all / halo orchestration of FFTSlabSolver (world size 2, and 8 = the driver's node, gloo) against the
+    single-domain oracles"""
     from oracle import bm6_fd, ch_spectral
     out = str(tmp_path / "res.npz")
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_fft_worker.py"), out, mode],
                                       env=env, cwd=ROOT))
@@ -106,3 +107,34 @@ def test_fft_slab_solver_matches_single_domain(mode, tmp_path, orc):
     np.testing.assert_allclose(res["d0"][:2], [F0, C0], rtol=1e-11)
     np.testing.assert_allclose(res["d1"][:2], [F1, C1], rtol=1e-11)
     assert np.abs(res["field"] - ref).max() <= 1e-12
+
+
+def test_eight_rank_partitions_of_the_baseline_configs():
+    """pure-host geometry of the driver's 8-GPU runs (no GPU, no process group): BASELINE.json config 4 strong
+    (1024^3 -> 128 planes per rank, 16 MiB ghost messages), config 3/5 weak (512 planes per rank of a 512 x 512 x 4096
+    box), and the slab-FFT all-to-all block size -- what bench.py --gpus 8 will allocate per rank."""
+    import ctypes as C
+    from pfhubbenchmarks_amd import lib as L
+    lib = L.load()
+    for (nx, ny, nzg, world) in ((1024, 1024, 1024, 8), (512, 512, 4096, 8), (512, 512, 1024, 2), (512, 512, 2048, 4)):
+        planes = []
+        for r in range(world):
+            f, c = C.c_int(), C.c_int()
+            assert lib.pf_slab_partition(nzg, world, r, C.byref(f), C.byref(c)) == 0
+            planes.append((f.value, c.value))
+            cfg = L.default_config(3, nx, 1.0)
+            cfg.n[0], cfg.n[1], cfg.n[2] = nx, ny, nzg
+            cfg.nranks, cfg.rank = world, r
+            assert lib.pf_field_elems(C.byref(cfg)) == nx * ny * c.value
+            assert lib.pf_field_elems_with_ghosts(C.byref(cfg)) == nx * ny * (c.value + 4)
+            off1 = lib.pf_ext_buffer_offset(C.byref(cfg), 1)
+            assert off1 >= nx * ny * (c.value + 4) and (off1 * 8) % (512 * 1024) == 64 * 1024
+            cfg.scheme = L.PF_SCHEME_SPECTRAL_SI
+            per_rank = lib.pf_a2a_buffer_doubles(C.byref(cfg))
+            assert per_rank >= 2 * (nx // 2 + 1) * ny * c.value          # complex half spectrum of the local planes
+        assert planes[0][0] == 0 and all(planes[i][0] + planes[i][1] == planes[i + 1][0] for i in range(world - 1))
+        assert planes[-1][0] + planes[-1][1] == nzg and len({c for _, c in planes}) == 1
+    # 2-D problems do not shard (replicas only, DESIGN.md section 4)
+    cfg = L.default_config(2, 512, 1.0)
+    cfg.nranks, cfg.rank = 8, 0
+    assert lib.pf_field_elems_with_ghosts(C.byref(cfg)) < 0

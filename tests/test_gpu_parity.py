@@ -984,10 +984,17 @@ def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
         np.testing.assert_array_equal(p["local"], e[z0:z0 + p["local"].shape[0]])
 
 
-def test_bench_multi_rank_launch_contract_rehearsal():
-    """The driver's N > 1 command line (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2) on the
-    1-GPU box: both ranks on device 0 over gloo (PFHIP_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).
-    Checks the launch contract only: env parsing, one JSON line from rank 0, whole-job value, weak scaling grid."""
+@pytest.mark.parametrize("world,workload,grid,scaling", [
+    (2, "bm1_fd_512c", [512, 512, 1024], "weak"),          # the driver's default series (weak: 512^3 per rank)
+    (4, "bm1_fd_1024c", [1024, 1024, 1024], "strong"),     # BASELINE.json config 4: 1024^3 split into z-slabs
+    (2, "bm1_spectral_512c", [512, 512, 1024], "weak"),    # slab FFT: one all-to-all each way per transform
+    (2, "bm6_fd_256c", [256, 256, 512], "weak"),           # BM6: slab-FFT Poisson (2 all-to-alls) + ghost exchange of c, phi
+])
+def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scaling):
+    """The driver's N > 1 command line (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) on the
+    1-GPU box: all ranks on device 0 over gloo (PFHIP_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device; at most 6
+    processes may share the card, so the 8-rank case is rehearsed on CPU in tests/test_dist_gloo.py).
+    Checks the launch contract only: env parsing, one JSON line from rank 0, whole-job value, grid and scaling mode."""
     import json
     import os
     import socket
@@ -999,18 +1006,19 @@ def test_bench_multi_rank_launch_contract_rehearsal():
     port = sk.getsockname()[1]
     sk.close()
     env = dict(os.environ, PFHIP_BENCH_REHEARSAL="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "6", "--warmup", "3", "--preheat-s", "0.05", "--repeats", "2"],
-                       env=env, cwd=root, capture_output=True,
-                       text=True, timeout=600)
+                        "--gpus", str(world), "--workload", workload, "--steps", "4", "--warmup", "2",
+                        "--preheat-s", "0.05", "--repeats", "2"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 3 and d["scaling"] == "weak"
-    assert d["config"]["grid"] == [512, 512, 1024] and "REHEARSAL" in d["config"]["parallelism"]
-    assert abs(d["value"] - 512 ** 3 * 2 * 6 / (d["ms_per_step"] * 1e-3 * 6)) <= 1e-6 * d["value"]
+    assert d["n_gpus"] == world and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == scaling
+    assert d["config"]["grid"] == grid and "REHEARSAL" in d["config"]["parallelism"]
+    cells = grid[0] * grid[1] * grid[2]
+    assert abs(d["value"] - cells * 4 / (d["ms_per_step"] * 1e-3 * 4)) <= 1e-6 * d["value"]
     assert d["check"]["C_rel_drift"] < 1e-12 and d["check"]["F_after"] < d["check"]["F_before"]
     assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None
     assert d["repeats"] == 2 and len(d["block_ms_per_step"]) == 2 and d["preheat_steps"] >= 5
