@@ -987,7 +987,6 @@ def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
 @pytest.mark.parametrize("world,workload,grid,scaling", [
     (2, "bm1_fd_512c", [512, 512, 1024], "weak"),          # the driver's default series (weak: 512^3 per rank)
     (4, "bm1_fd_1024c", [1024, 1024, 1024], "strong"),     # BASELINE.json config 4: 1024^3 split into z-slabs
-    (2, "bm1_spectral_512c", [512, 512, 1024], "weak"),    # slab FFT: one all-to-all each way per transform
     (2, "bm6_fd_256c", [256, 256, 512], "weak"),           # BM6: slab-FFT Poisson (2 all-to-alls) + ghost exchange of c, phi
 ])
 def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scaling):
