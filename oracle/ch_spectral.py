@@ -42,21 +42,31 @@ def ksq(shape, h):
 class SpectralCH:
     """keeps c_k resident between steps exactly like the HIP path"""
 
-    def __init__(self, c, h=1.0, rho_s=5.0, c_alpha=0.3, c_beta=0.7, kappa=2.0, M=5.0, bm6=False, k=0.09, eps=90.0):
+    def __init__(self, c, h=1.0, rho_s=5.0, c_alpha=0.3, c_beta=0.7, kappa=2.0, M=5.0, bm6=False, k=0.09, eps=90.0,
+                 workers=None):
+        """workers: None = numpy.fft (pocketfft, one thread); an int = scipy.fft (the same pocketfft, threaded) -- what
+        makes a 512^3 check affordable (three 1 GiB transforms per step)"""
         self.c = np.array(c, dtype=np.float64)
+        if workers:
+            import scipy.fft as sfft
+            self._rfftn = lambda x: sfft.rfftn(x, workers=workers)
+            self._irfftn = lambda x, s: sfft.irfftn(x, s=s, axes=tuple(range(len(s))), workers=workers)
+        else:
+            self._rfftn = np.fft.rfftn
+            self._irfftn = lambda x, s: np.fft.irfftn(x, s=s, axes=tuple(range(len(s))))
         self.h, self.kappa, self.M = h, kappa, M
         self.bm6, self.k, self.eps = bm6, k, eps
         self.model = dict(rho_s=rho_s, c_alpha=c_alpha, c_beta=c_beta)
         self.k2 = ksq(self.c.shape, h)
-        self.chat = np.fft.rfftn(self.c)
+        self.chat = self._rfftn(self.c)
 
     def step(self, dt, nsteps=1):
         for _ in range(nsteps):
-            ghat = np.fft.rfftn(fprime(self.c, **self.model))
+            ghat = self._rfftn(fprime(self.c, **self.model))
             gam = np.where(self.k2 > 0.0, dt * self.M * (self.k * self.k / self.eps), 0.0) if self.bm6 else 0.0
             self.chat = (self.chat - (dt * self.M) * self.k2 * ghat) / (
                 (1.0 + gam) + (dt * self.M * self.kappa) * self.k2 ** 2)
-            self.c = np.fft.irfftn(self.chat, s=self.c.shape, axes=tuple(range(self.c.ndim)))
+            self.c = self._irfftn(self.chat, self.c.shape)
         return self.c
 
     def diagnostics(self, mirror=False):
@@ -66,7 +76,7 @@ class SpectralCH:
         vol = self.h ** d * (0.5 ** d if mirror else 1.0)
         m = self.model
         f = m["rho_s"] * ((c - m["c_alpha"]) * (m["c_beta"] - c)) ** 2
-        chat = np.fft.rfftn(c)
+        chat = self._rfftn(c)
         n_last = c.shape[-1]
         w = np.full(chat.shape[-1], 2.0)
         w[0] = 1.0

@@ -82,7 +82,8 @@ const char* spectral_error(const Spectral* sp);
 
 // fused LDS-FFT spectral step for 2-D power-of-two grids (spectral2d_fused.hip); same spectrum layout as rocFFT D2Z
 struct Fused2D;
-bool fused2d_supported(int dim, int nx, int ny, int nz);  // 2-D power-of-two grids, or the 512^3 cube
+bool fused2d_supported(int dim, int nx, int ny, int nz);
+int fused_spectrum_pitch(int dim, int nx, int ny, int nz);  // complex elements per k_x row of the arrays handed to fused2d_* / fused3d_poisson  // 2-D power-of-two grids, or the 512^3 cube
 int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream);
 void fused2d_destroy(Fused2D* f);
 void fused2d_invalidate(Fused2D* f);

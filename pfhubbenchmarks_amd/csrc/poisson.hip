@@ -153,7 +153,12 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
     po->have_plans = true;
     PO_FFT(hipfftSetStream(po->fwd, stream));
     PO_FFT(hipfftSetStream(po->inv, stream));
-    PO_HIP(hipMalloc(&po->ph, sizeof(double2) * po->nh));
+    {  // the hand-written 512^3 passes use a padded row pitch (fused_spectrum_pitch); the rocFFT path the natural one
+      const bool fast = npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz);
+      const int64_t nh_alloc = fast ? (int64_t)fused_spectrum_pitch(3, nx, ny, a.nz) * ny * a.nz : po->nh;
+      PO_HIP(hipMalloc(&po->ph, sizeof(double2) * nh_alloc));
+      if (nh_alloc != po->nh) PO_HIP(hipMemsetAsync(po->ph, 0, sizeof(double2) * nh_alloc, stream));
+    }
     if (npx > 0) PO_HIP(hipMalloc(&po->rhs, sizeof(double) * po->n));
     if (npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz) &&
         fused2d_create(&po->fast, nx, ny, a.nz, h, stream) != 0) {

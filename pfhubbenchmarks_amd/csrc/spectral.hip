@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void dfdc_kernel(const double* __restrict__ c,
 
 struct KsArgs {
   int nxh, ny, nz;   // half-spectrum extents (x fastest)
+  int pitch;         // complex elements per k_x row in memory (nxh, or 264 on the hand-written 512^3 path)
   int nx;            // full x extent
   double kx0, ky0, kz0;  // 2 pi / (n h) per axis
   double dtM, dtMkappa, inv_n;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void kspace_grad_energy_kernel(const double2* 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (int64_t)gridDim.x * 256) {
     const int mx = (int)(i % a.nxh);
     const double w = (mx == 0 || 2 * mx == a.nx) ? 1.0 : 2.0;
-    const double2 ch = chat[i];
+    const double2 ch = chat[(i / a.nxh) * a.pitch + mx];   // i runs over the logical half spectrum
     const double k2 = ksq(a, i), m2 = ch.x * ch.x + ch.y * ch.y;
     acc += w * k2 * m2;
     if (k2 > 0.0) acc2 += w * m2 / k2;
@@ -196,6 +197,10 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
   sp->n = (int64_t)nx * ny * sp->nz;
   const int nxh = nx / 2 + 1;
   sp->nh = (int64_t)nxh * ny * sp->nz;
+  const char* e3 = getenv("PFHIP_SPECTRAL_2D");
+  const bool want_fast = fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e3 && std::string(e3) == "rocfft");
+  sp->ks.pitch = want_fast ? fused_spectrum_pitch(dim, nx, ny, sp->nz) : nxh;
+  const int64_t nh_alloc = (int64_t)sp->ks.pitch * ny * sp->nz;
   sp->ks.nxh = nxh;
   sp->ks.ny = ny;
   sp->ks.nz = sp->nz;
@@ -219,13 +224,17 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     sp->have_plans = true;
     SP_FFT(hipfftSetStream(sp->fwd, stream));
     SP_FFT(hipfftSetStream(sp->inv, stream));
-    SP_HIP(hipMalloc(&sp->chat, sizeof(double2) * sp->nh));
-    SP_HIP(hipMalloc(&sp->ghat, sizeof(double2) * sp->nh));
-    SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * sp->nh));
+    SP_HIP(hipMalloc(&sp->chat, sizeof(double2) * nh_alloc));
+    SP_HIP(hipMalloc(&sp->ghat, sizeof(double2) * nh_alloc));
+    SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * nh_alloc));
+    if (nh_alloc != sp->nh) {  // padded rows: the pad columns are never written by the passes; keep them defined
+      SP_HIP(hipMemsetAsync(sp->chat, 0, sizeof(double2) * nh_alloc, stream));
+      SP_HIP(hipMemsetAsync(sp->ghat, 0, sizeof(double2) * nh_alloc, stream));
+      SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
+    }
     SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
     SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 4096));
-    const char* e = getenv("PFHIP_SPECTRAL_2D");  // "rocfft" forces the library path (A/B comparison)
-    if (fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e && std::string(e) == "rocfft")) {
+    if (want_fast) {  // PFHIP_SPECTRAL_2D / _3D = rocfft force the library path (A/B comparison)
       if (fused2d_create(&sp->fast, nx, ny, sp->nz, h, stream) != 0) {
         sp->err = "fused2d_create failed";
         return -3;

@@ -31,6 +31,8 @@ constexpr int CT = 256;  // threads per column
 
 struct F2Args {
   int nx, ny, nxh, lgx, lgy;
+  int pitch;  // complex elements per k_x row of the half spectrum in memory: nxh (rocFFT's D2Z layout) in 2-D; rounded up
+              // to a multiple of 8 (one 128-byte line per 8 columns) on the 512^3 path -- see fused_spectrum_pitch()
   double ca, cb, two_rho;
   double dtM, dtMkappa, kx0, ky0, inv_n;
   int nz = 1;        // 3-D path (512^3) only
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double
   double2 z[MAXP];
   if (from_spectrum) {
     for (int k = lane; k <= N / 2; k += RT) {
-      const double2 p = H[(int64_t)y0 * a.nxh + k], q = H[(int64_t)y1 * a.nxh + k];
+      const double2 p = H[(int64_t)y0 * a.pitch + k], q = H[(int64_t)y1 * a.pitch + k];
       X[px(brev(k, lg))] = make_double2(p.x - q.y, p.y + q.x);  // p + i q
       if (k > 0 && k < N / 2) X[px(brev(N - k, lg))] = make_double2(p.x + q.y, q.x - p.y);  // conj(p) + i conj(q)
     }
@@ -197,8 +199,8 @@ __global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double
   fft_inplace<-1, RT>(X, TW, N, lg, lane);
   for (int k = lane; k <= N / 2; k += RT) {
     const double2 w = X[px(k)], m = X[px((N - k) & (N - 1))];
-    G[(int64_t)y0 * a.nxh + k] = make_double2(0.5 * (w.x + m.x), 0.5 * (w.y - m.y));
-    G[(int64_t)y1 * a.nxh + k] = make_double2(0.5 * (w.y + m.y), -0.5 * (w.x - m.x));
+    G[(int64_t)y0 * a.pitch + k] = make_double2(0.5 * (w.x + m.x), 0.5 * (w.y - m.y));
+    G[(int64_t)y1 * a.pitch + k] = make_double2(0.5 * (w.y + m.y), -0.5 * (w.x - m.x));
   }
 }
 
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
   for (int k = tid; k < N / 2; k += CT * CW) TW[k] = twy_g[k];
   for (int idx = tid; idx < N * CW; idx += CT * CW) {
     const int y = idx / CW, ci = idx % CW, kx = kxb + ci;
-    X[ci * NP + px(brev(y, lg))] = kx < a.nxh ? G[(int64_t)y * a.nxh + kx] : make_double2(0.0, 0.0);
+    X[ci * NP + px(brev(y, lg))] = kx < a.nxh ? G[(int64_t)y * a.pitch + kx] : make_double2(0.0, 0.0);
   }
   __syncthreads();
   fft_inplace<-1, CT>(X + wave * NP, TW, N, lg, lane);
@@ -233,18 +235,18 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
       o[i] = gh;
       if (kx < a.nxh) {
         if (init_only) {
-          chat[(int64_t)ky * a.nxh + kx] = gh;
+          chat[(int64_t)ky * a.pitch + kx] = gh;
         } else {
           const int my = 2 * ky > N ? ky - N : ky;
           const double kxv = a.kx0 * kx, kyv = a.ky0 * my;
           const double k2 = (kxv * kxv + kyv * kyv) + 0.0;  // same grouping as spectral.hip's ksq with kz = 0
           const double num = a.dtM * k2;
           const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
-          const double2 ch = chat[(int64_t)ky * a.nxh + kx];
+          const double2 ch = chat[(int64_t)ky * a.pitch + kx];
           double2 r;
           r.x = fma(-num, gh.x, ch.x) * den;
           r.y = fma(-num, gh.y, ch.y) * den;
-          chat[(int64_t)ky * a.nxh + kx] = r;
+          chat[(int64_t)ky * a.pitch + kx] = r;
           o[i] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
         }
       }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
   fft_inplace<+1, CT>(X + wave * NP, TW, N, lg, lane);
   for (int idx = tid; idx < N * CW; idx += CT * CW) {
     const int y = idx / CW, ci = idx % CW, kx = kxb + ci;
-    if (kx < a.nxh) H[(int64_t)y * a.nxh + kx] = X[ci * NP + px(y)];
+    if (kx < a.nxh) H[(int64_t)y * a.pitch + kx] = X[ci * NP + px(y)];
   }
 }
 
@@ -364,6 +366,51 @@ __device__ __forceinline__ void fft512_wave(double2 (&v)[8], double2* L, int m, 
   radix8<SIGN>(v);
 }
 
+// Same transform with the twiddles fetched from the (L1/L2-resident, 9 KB) tables right before each use instead of held
+// in 56 VGPRs for the whole kernel: the column passes then fit 128 VGPRs with the resident spectrum in flight, i.e. two
+// 8-wave workgroups per CU instead of one (f3_col512_kernel).  rowA = this lane's input index m, rowB = lane & 7.
+template <int SIGN>
+__device__ __forceinline__ void fft512_wave_tw(double2 (&v)[8], double2* L, int m, const double2* __restrict__ twA_g,
+                                               const double2* __restrict__ twB_g, int lane) {
+  const int hi = lane >> 3, lo = lane & 7;
+  {
+    double2 tw[7];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) tw[q - 1] = twA_g[m * 8 + q];
+    radix8<SIGN>(v);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      double2 w = tw[q - 1];
+      if (SIGN > 0) w.y = -w.y;
+      v[q] = cmul2(w, v[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) L[q * 72 + m] = v[q];
+  wave_lds_sync();
+#pragma unroll
+  for (int l1 = 0; l1 < 8; ++l1) v[l1] = L[hi * 72 + lo + 8 * l1];
+  {
+    double2 tw[7];
+#pragma unroll
+    for (int sx = 1; sx < 8; ++sx) tw[sx - 1] = twB_g[lo * 8 + sx];
+    radix8<SIGN>(v);
+#pragma unroll
+    for (int sx = 1; sx < 8; ++sx) {
+      double2 w = tw[sx - 1];
+      if (SIGN > 0) w.y = -w.y;
+      v[sx] = cmul2(w, v[sx]);
+    }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int sidx = 0; sidx < 8; ++sidx) L[hi * 72 + 9 * lo + sidx] = v[sidx];
+  wave_lds_sync();
+#pragma unroll
+  for (int l0 = 0; l0 < 8; ++l0) v[l0] = L[hi * 72 + 9 * l0 + lo];
+  radix8<SIGN>(v);
+}
+
 __device__ __forceinline__ void load_tw(double2 (&tw)[7], const double2* __restrict__ table, int row) {
 #pragma unroll
   for (int q = 1; q < 8; ++q) tw[q - 1] = table[row * 8 + q];
@@ -371,6 +418,9 @@ __device__ __forceinline__ void load_tw(double2 (&tw)[7], const double2* __restr
 
 // Row kernel, nx == 512: one wave per pair of rows; same contract as f2_row_kernel.
 constexpr int RW = 1;  // row pairs (waves) per workgroup
+// LAZY: twiddles fetched right before each use (fft512_wave_tw) instead of held in 84 VGPRs -- the 512^3 pass streams
+// from HBM and wants occupancy; the latency-bound 2-D step keeps them resident (loaded beside the data at kernel entry).
+template <bool LAZY>
 __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, const double2* __restrict__ H,
                                                             const double* __restrict__ c_in,
                                                             double* __restrict__ c_out, double2* __restrict__ G,
@@ -385,22 +435,27 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
   const int y0 = 2 * pair, y1 = y0 + 1;  // ny is even and (ny / 2) % RW == 0 (checked by the launcher)
   const int T = (lane >> 3) + 8 * (lane & 7);
   double2 twN[7], twB[7], v[8];
-  load_tw(twN, twA_g, lane);
-  load_tw(twB, twB_g, lane & 7);
+  if (!LAZY) {
+    load_tw(twN, twA_g, lane);
+    load_tw(twB, twB_g, lane & 7);
+  }
   int m = lane;
   if (from_spectrum) {
     double2 twT[7];
-    load_tw(twT, twA_g, T);
+    if (!LAZY) load_tw(twT, twA_g, T);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = lane + 64 * j;
       const bool upper = k > N / 2;
       const int kk = upper ? N - k : k;
-      const double2 p = H[(int64_t)y0 * a.nxh + kk], q = H[(int64_t)y1 * a.nxh + kk];
+      const double2 p = H[(int64_t)y0 * a.pitch + kk], q = H[(int64_t)y1 * a.pitch + kk];
       // X[k] = p + i q for k <= N/2, conj(p) + i conj(q) beyond (Hermitian rows)
       v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
     }
-    fft512_wave<+1>(v, L, lane, twN, twB, lane);
+    if (LAZY)
+      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+    else
+      fft512_wave<+1>(v, L, lane, twN, twB, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
@@ -408,8 +463,10 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
     }
     if (from_spectrum == 2) return;  // inverse only (Poisson solve): no forward transform of the result
     m = T;
+    if (!LAZY) {
 #pragma unroll
-    for (int q = 0; q < 7; ++q) twN[q] = twT[q];
+      for (int q = 0; q < 7; ++q) twN[q] = twT[q];
+    }
     __syncthreads();
   } else {
 #pragma unroll
@@ -420,7 +477,10 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
   }
-  fft512_wave<-1>(v, L, m, twN, twB, lane);
+  if (LAZY)
+    fft512_wave_tw<-1>(v, L, m, twA_g, twB_g, lane);
+  else
+    fft512_wave<-1>(v, L, m, twN, twB, lane);
   // Hermitian separation of the two real rows: needs X[k] and X[N - k] -> one more exchange (skewed: k + k / 8)
   __syncthreads();
 #pragma unroll
@@ -435,8 +495,8 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
     if (k <= N / 2) {
       const int km = (N - k) & (N - 1);
       const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-      G[(int64_t)y0 * a.nxh + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
-      G[(int64_t)y1 * a.nxh + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+      G[(int64_t)y0 * a.pitch + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+      G[(int64_t)y1 * a.pitch + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
     }
   }
 }
@@ -469,16 +529,16 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
   load_tw(twT, twA_g, T);
   load_tw(twB, twB_g, lane & 7);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = G[(int64_t)(lane + 64 * j) * a.nxh + kxc];
+  for (int j = 0; j < 8; ++j) v[j] = G[(int64_t)(lane + 64 * j) * a.pitch + kxc];
   if (!init_only) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) ch[t] = chat[(int64_t)(T + 64 * t) * a.nxh + kxc];
+    for (int t = 0; t < 8; ++t) ch[t] = chat[(int64_t)(T + 64 * t) * a.pitch + kxc];
   }
   fft512_wave<-1>(v, L, lane, twN, twB, lane);
   if (init_only) {
     if (on) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) chat[(int64_t)(T + 64 * t) * a.nxh + kx] = v[t];
+      for (int t = 0; t < 8; ++t) chat[(int64_t)(T + 64 * t) * a.pitch + kx] = v[t];
     }
     return;
   }
@@ -494,14 +554,14 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
     double2 r;
     r.x = fma(-num, v[t].x, ch[t].x) * den;
     r.y = fma(-num, v[t].y, ch[t].y) * den;
-    if (on) chat[(int64_t)ky * a.nxh + kx] = r;
+    if (on) chat[(int64_t)ky * a.pitch + kx] = r;
     v[t] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
   }
   __syncthreads();
   fft512_wave<+1>(v, L, T, twT, twB, lane);
   if (on) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) H[(int64_t)(T + 64 * t) * a.nxh + kx] = v[t];
+    for (int t = 0; t < 8; ++t) H[(int64_t)(T + 64 * t) * a.pitch + kx] = v[t];
   }
 }
 
@@ -515,8 +575,8 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
 //   X: f2_row512_kernel over all ny*nz rows: inverse x-FFT -> c stored -> f'(c) -> forward x-FFT -> G
 //   Y: forward y-FFT of G in place                                                              (MODE 0)
 // MODE 3 = forward z-FFT stored as the resident spectrum (initialisation).
-template <int MODE, int CW3>
-__global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
+template <int MODE, int CW3, bool EARLY = false>  // EARLY (MODE 2): request the resident spectrum before the forward FFT
+__global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
                                                              double2* __restrict__ chat, double2* __restrict__ H,
                                                              int64_t col_stride, int64_t batch_stride, int nblk,
                                                              int nitems, const double2* __restrict__ twA_g,
@@ -529,9 +589,7 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
   auto nat = [](int n) { return n + (n >> 3); };
   const int ci = tid % CW3;
   double2* Lc = Lall + ci * W8C + 4 * ci;
-  double2 twN[7], twB[7], v[8], ch[PER];
-  load_tw(twN, twA_g, lane);
-  load_tw(twB, twB_g, lane & 7);
+  double2 v[8], ch[PER];
   // One work item (batch b, block of CW3 k_x columns) per workgroup.  (A persistent, software-pipelined form -- next
   // item's loads in flight during the transforms -- was measured and is slower: 3.85 vs 3.25 ms per step; its extra 32
   // VGPRs cost a wave per SIMD, and short-lived workgroups already overlap through the dispatcher.)
@@ -554,17 +612,25 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) Lc[nat((tid + NT * i) / CW3)] = v[i];
+    if (MODE == 2 && EARLY) {  // the resident spectrum is requested now and consumed after the forward transform (its
+                               // HBM latency hides behind the FFT) -- 128 VGPRs with ~14 dwords of scratch
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int r = (tid + NT * i) / CW3;
+        ch[i] = on ? chat[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
     if (MODE == 1)
-      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
     else
-      fft512_wave<-1>(v, L, lane, twN, twB, lane);
+      fft512_wave_tw<-1>(v, L, lane, twA_g, twB_g, lane);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
-    if (MODE == 2) {  // the resident spectrum is fetched only now: holding it across the transform costs a wave per SIMD
+    if (MODE == 2 && !EARLY) {  // fetched only now: 108 VGPRs, no scratch, but the load latency is exposed
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
@@ -588,7 +654,7 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
-      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
@@ -627,7 +693,7 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
-      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
@@ -641,7 +707,8 @@ __global__ __launch_bounds__(64 * CW3, (MODE == 2 || MODE == 4) ? 3 : 4) void f3
   }
 }
 
-int g_cw3 = 8;  // k_x columns per workgroup of the 3-D column passes (PFHIP_FFT3D_CW = 4 | 8); 8: 2.95 ms, 4: 3.15 ms
+int g_zearly = 0;  // z pass: request the resident spectrum before the forward FFT (PFHIP_FFT3D_ZEARLY = 0 | 1)
+int g_cw3 = 0;  // k_x columns per workgroup of the 3-D column passes: 0 = per pass (z: 4, y: 8), PFHIP_FFT3D_CW = 4 | 8 forces one
 int g_cw512 = 1;  // columns per workgroup of the 2-D column kernel (PFHIP_FFT512_CW = 1 | 2 | 4): 13.05 / 14.3 / 17.5 us
 
 int ilog2(int n) {
@@ -673,6 +740,21 @@ bool fused2d_supported(int dim, int nx, int ny, int nz) {
   return dim == 2 && lx >= 7 && lx <= 10 && ly >= 7 && ly <= 10;
 }
 
+// Row pitch (complex elements) of every half-spectrum array this file touches.  2-D: nx/2 + 1, rocFFT's D2Z layout (the
+// 2 MiB problem is L2-resident).  512^3: 264 instead of 257.  With 257 a column workgroup's 8 adjacent columns (128 bytes
+// per row) start 16 bytes further into a 128-byte line on every row, so 7 of 8 rows straddle two lines: rocprofv3
+// measured FETCH_SIZE x2 = 2.02 GB for the 1.08 GB a y pass needs (1.875x = (7*2 + 1)/8 exactly) and 4.09 GB for the z
+// pass's 2.16 GB, with the passes already at 5.4-5.9 TB/s of HBM traffic (profiles/r02/spectral_512c_before_pitch.md).
+// A pitch that is a multiple of 8 makes every (row, column-block) exactly one line.
+int fused_spectrum_pitch(int dim, int nx, int ny, int nz) {
+  const int nxh = nx / 2 + 1;
+  if (dim == 3 && fused2d_supported(dim, nx, ny, nz)) {
+    const char* e = getenv("PFHIP_FFT3D_PITCH");  // "natural": keep nx/2 + 1 (A/B comparison)
+    if (!(e && std::string(e) == "natural")) return (nxh + 7) / 8 * 8;
+  }
+  return nxh;
+}
+
 int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream) {
   Fused2D* f = new Fused2D();
   *out = f;
@@ -684,6 +766,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   a.nx = nx;
   a.ny = ny;
   a.nxh = nx / 2 + 1;
+  a.pitch = fused_spectrum_pitch(nz > 1 ? 3 : 2, nx, ny, nz);
   a.lgx = ilog2(nx);
   a.lgy = ilog2(ny);
   a.kx0 = TWO_PI_F / (nx * h);
@@ -705,6 +788,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
   f->col512 = (allow8 || f->cube512) && ny == 512;
   if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : 8;
+  if (const char* ze = getenv("PFHIP_FFT3D_ZEARLY")) g_zearly = std::atoi(ze) != 0;
 
   if (const char* cw = getenv("PFHIP_FFT512_CW")) {
     const int c = std::atoi(cw);
@@ -753,7 +837,7 @@ namespace {
 void launch_row(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
                 int from_spectrum, int use_fprime) {
   if (f->row512)
-    hipLaunchKernelGGL(f2_row512_kernel, dim3(a.ny / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
+    hipLaunchKernelGGL(f2_row512_kernel<false>, dim3(a.ny / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
   else
     hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_row, f->stream, a, H, c_in, c_out, G,
@@ -779,23 +863,30 @@ namespace {
 // 3-D passes (512^3).  Rows: f2_row512_kernel over ny*nz/2 row pairs (its row index is the flattened (z, y) index).
 void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
                  int from_spectrum, int use_fprime) {
-  hipLaunchKernelGGL(f2_row512_kernel, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
+  hipLaunchKernelGGL(f2_row512_kernel<true>, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
                      (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
 }
 template <int MODE, int CW3>
 void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
   const int nblk = (a.nxh + CW3 - 1) / CW3;
-  const int64_t row = a.nxh, plane = (int64_t)a.nxh * a.ny;
+  const int64_t row = a.pitch, plane = (int64_t)a.pitch * a.ny;
   // axis 1: columns along y (stride one x-row), one batch per z-plane; axis 2: columns along z, one batch per y-row
   const int64_t col_stride = axis == 1 ? row : plane, batch_stride = axis == 1 ? plane : row;
   const int nbatch = axis == 1 ? a.nz : a.ny;
   const int nitems = nblk * nbatch;
-  hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                     col_stride, batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b);
+  if (MODE == 2 && g_zearly)
+    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, true>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
+                       col_stride, batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b);
+  else
+    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, false>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
+                       col_stride, batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b);
 }
 template <int MODE>
 void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
-  if (g_cw3 == 4)
+  // measured after the aligned pitch (rocprofv3, 512^3): z pass 999 us with 4 columns per workgroup (4 workgroups of 4
+  // waves per CU) vs 1073 us with 8; y passes 441-452 us with 8 vs 466-471 us with 4
+  const int cw = g_cw3 ? g_cw3 : ((MODE == 2 || MODE == 4 || MODE == 3) ? 4 : 8);
+  if (cw == 4)
     launch_col3_t<MODE, 4>(f, a, A, chat, H, axis);
   else
     launch_col3_t<MODE, 8>(f, a, A, chat, H, axis);

@@ -373,6 +373,31 @@ def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape):
         PhaseFieldSolver(dim=2, n=65, h=1.0, bc="mirror", scheme="spectral", model="bm6")
 
 
+def test_spectral_512cubed_one_step_against_the_cpu_oracle(lib):
+    """512^3 (the size the hand-written passes exist for) against the CPU oracle itself, not against another path of the
+    same library: one semi-implicit step of oracle/ch_spectral.py (pocketfft through scipy.fft, threaded: three 1 GiB
+    transforms) from the BM1 initial condition plus noise.  Field to 1e-11 (pocketfft and the radix-8 LDS FFTs round
+    differently), F and C to 1e-11 / 1e-13."""
+    import os
+    from oracle import ch_fd, ch_spectral
+    rng = np.random.default_rng(79)
+    c0 = np.repeat(ch_fd.ic(512, 512, 1), 512, 0) + 0.01 * rng.standard_normal((512, 512, 512), dtype=np.float32)
+    o = ch_spectral.SpectralCH(c0, h=1.0, workers=min(16, os.cpu_count() or 1))
+    with PhaseFieldSolver(dim=3, n=512, h=1.0, scheme="spectral") as s:
+        s.set_c(c0)
+        F0, C0, _ = s.diagnostics()
+        Fo, Co = o.diagnostics()
+        assert abs(F0 - Fo) <= 1e-11 * abs(Fo) and abs(C0 - Co) <= 1e-13 * abs(Co)
+        s.step(1e-2, 1)
+        o.step(1e-2, 1)
+        got = s.get_c()
+        err = np.abs(got - o.c).max()
+        assert err <= 1e-11, err
+        F1, C1, _ = s.diagnostics()
+        Fo, Co = o.diagnostics()
+        assert abs(F1 - Fo) <= 1e-11 * abs(Fo) and abs(C1 - Co) <= 1e-13 * abs(Co)
+
+
 def test_spectral_512cubed_lds_fft_passes_equal_the_rocfft_path(lib):
     """512^3 semi-implicit spectral step: the hand-written passes (x rows by f2_row512_kernel, y and z columns by
     f3_col512_kernel, 4 launches per step) against the rocFFT path of the same library (PFHIP_SPECTRAL_3D=rocfft, itself
