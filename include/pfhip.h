@@ -63,8 +63,19 @@ enum {
                                 (bench1.py:21-110) -- 2-D, PF_BC_MIRROR, n[0] == n[1] = corner nodes per side;
                                 fields are in the reference's node order: (n*n corners, then (n-1)*(n-1) centres) */
 };
-enum { PF_MODEL_BM1 = 1, PF_MODEL_BM6 = 6 };
-enum { PF_FIELD_C = 0, PF_FIELD_MU = 1, PF_FIELD_PHI = 2 };
+enum {
+  PF_MODEL_BM1 = 1,
+  PF_MODEL_BM6 = 6,
+  PF_MODEL_BM2 = 2, /* Ostwald ripening: Cahn-Hilliard + 4 Allen-Cahn fields (dolfin/bench2.py); PF_SCHEME_FEM_BE only */
+  PF_MODEL_BM3 = 3  /* dendritic growth: heat diffusion + Allen-Cahn (dolfin/bench3.py);          PF_SCHEME_FEM_BE only */
+};
+enum {
+  PF_FIELD_C = 0,
+  PF_FIELD_MU = 1,
+  PF_FIELD_PHI = 2,  /* BM6: electrostatic potential; BM3: the order parameter phi */
+  PF_FIELD_ETA1 = 3, /* BM2: eta1 .. eta4 = PF_FIELD_ETA1 .. PF_FIELD_ETA1 + 3 */
+  PF_FIELD_U = 7     /* BM3: dimensionless temperature U */
+};
 enum { PF_KERNEL_AUTO = 0, PF_KERNEL_FUSED = 1, PF_KERNEL_TWOPASS = 2 }; /* FD step implementation */
 
 /* Model + discretisation.  Defaults of the reference: dolfin/bench1.py:32-36, dolfin/bench6.py:38-39. */
@@ -101,6 +112,9 @@ typedef struct pf_config {
                            info.ok = 0 with the state untouched and the caller halves dt (bench1.py:164-177).
                            Following the COMMITTED run's time grid with exact linear solves needs up to 24 (rows
                            21, 37 of results/bench1_out.csv): the fixture driver passes 100. */
+  double model_params[8]; /* PF_MODEL_BM2: {kappa_eta, w, alpha, L} (with c_alpha, c_beta, rho_s = rho, kappa = kappa_c, M
+                             above; dolfin/bench2.py:33-41).  PF_MODEL_BM3: {W0, tau0, D, Delta} (bench3.py:31-37).
+                             pf_config_model_defaults fills the reference's values. */
 } pf_config;
 
 /* pf_config.flags */
@@ -164,6 +178,9 @@ const char* pf_last_error(const pf_handle* h);
 int pf_device_count(void);
 /* fill *cfg with the reference's BM1 constants for an n^dim periodic grid (pure host, no HIP call) */
 int pf_config_default(pf_config* cfg, int dim, int n, double h);
+/* switch an initialised config to `model` with the reference's constants for it (bench1.py:32-36, bench2.py:33-41,
+ * bench3.py:31-37, bench6.py:38-39); pure host */
+int pf_config_model_defaults(pf_config* cfg, int model);
 
 /* ---- pure-host helpers (no HIP call; usable without a GPU) ------------------------------------------- */
 /* planes [*first, *first + *count) of `n_planes` owned by `rank` of `nranks` (remainder to the low ranks) */
@@ -190,6 +207,10 @@ int pf_destroy(pf_handle* h);
 /* ---- state ------------------------------------------------------------------------------------------ */
 int pf_set_ic_bm1(pf_handle* h, double c0, double eps);  /* pfbase.py:187-189; z-extruded in 3-D (b13d.py:55) */
 int pf_set_ic_bm6(pf_handle* h, double c0, double c1);   /* pfbase.py:332-334 */
+/* InitialConditionsBench2 (pfbase.py:268-296; bench2.py:58-62: c0 0.5, eps 0.05, eps_eta 0.1, psi 1.5): c, mu = 0, eta1..4 */
+int pf_set_ic_bm2(pf_handle* h, double c0, double eps, double eps_eta, double psi);
+/* InitialConditionsBench3 (pfbase.py:298-320; bench3.py:52-57: r 8, w 1, vin 1, vout -1): U = Delta, phi = radial seed */
+int pf_set_ic_bm3(pf_handle* h, double r, double w, double vin, double vout);
 int pf_set_field(pf_handle* h, int field, const double* host, size_t n); /* caller-owned host buffer, copied */
 int pf_get_field(pf_handle* h, int field, double* host, size_t n);
 

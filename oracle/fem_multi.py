@@ -1,0 +1,323 @@
+"""ORACLE (test infrastructure, not product code) -- CPU restatement of the reference's FEM / backward-Euler algorithm
+for PFHub BM2 (Ostwald ripening: Cahn-Hilliard + 4 Allen-Cahn order parameters) and BM3 (dendritic growth: heat
+diffusion + Allen-Cahn), on the same 'crossed' P1 machinery as oracle/fem_be.py (BM1 / BM6).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+What it restates (paths relative to the reference tree):
+  BM2  dolfin/bench2.py:21-23   mesh RectangleMesh(0,0 -> 200,200, 100, 100, 'crossed')
+       dolfin/bench2.py:33-41   c_alpha 0.3, c_beta 0.7, rho sqrt 2, kappa_c = kappa_eta = 3, M 5, w 1, alpha 5, L 5
+       dolfin/bench2.py:44-52   mixed space P1^6: (c, mu, eta1..eta4)
+       dolfin/bench2.py:58-66   initial condition InitialConditionsBench2(c0 0.5, eps 0.05, eps_eta 0.1, psi 1.5):
+                                dolfin/pfbase.py:268-296 (note the psi term uses the 0-based index i, the others i + 1)
+       dolfin/bench2.py:76-103  f_chem = f_alpha (1 - h) + f_beta h + w g, double_well g, hinterp h; df/dc, df/deta_i
+       dolfin/bench2.py:105-111 F = cahn_hilliard_weak_form + 4 x allen_cahn_weak_form (pfbase.py:361-383, 396-409)
+       dolfin/bench2.py:184-192 total_free_energy = int f_chem + kappa_c/2 |grad c|^2 + sum kappa_eta/2 |grad eta_i|^2
+  BM3  dolfin/bench3.py:21-23   mesh RectangleMesh(0,0 -> 960,960, 350, 350, 'crossed')
+       dolfin/bench3.py:31-37   W0 1, tau0 1, D 10, Delta -0.3 (anisotropy switched off: a = 1, bench3.py:76-77)
+       dolfin/bench3.py:52-60   initial condition InitialConditionsBench3(Delta, r 8, w 1, vin 1, vout -1): pfbase.py:298-320
+       dolfin/bench3.py:66-71   lam = D tau0 / (0.6267 W0^2); f_chem
+       dolfin/bench3.py:82      dfdp = (phi - lam U (1 - phi^2)) (1 - phi^2)
+       dolfin/bench3.py:89-97   Fu = diffusion_weak_form(U) - 0.5 allen_cahn_RHS_IBP(phi, test_U) ; Fp = allen_cahn_weak_form(phi)
+       dolfin/bench3.py:160-168 total_free_energy = int f_chem + W^2/2 |grad phi|^2; solid_fraction = int (phi+1)/2 / (Lx Ly)
+  both quadrature_degree = 3 (bench2.py:16, bench3.py:16) -> the 6-point Strang-Fix rule for every nonlinear term;
+       SNES absolute_tolerance 1e-6 on ||R||_2 (bench2.py:130, bench3.py:115); plain full Newton steps here.
+
+Generic form (one residual block per field e, unknown fields f):
+    R_e = sum_f [ T_ef M (u_f - u0_f)/dt + A_ef M u_f + Kc_ef K u_f ] + int S_e(u_h) lambda_i
+with M / K the P1 mass / stiffness matrices; the model supplies the constant tables T, A, Kc, the pointwise source S
+and its derivative dS_e/du_f (both evaluated at the quadrature points).  The HIP BE-parity mode
+(pfhubbenchmarks_amd/csrc/fem_be.hip, generic kernels) uses the same decomposition.
+
+Pinning: the reference's committed results/bench2_out.csv (120 rows) and results/bench3_out.csv (46 rows), copied as
+data to tests/golden/; tests/test_oracle_multi.py checks the first rows in the CPU suite, oracle/logs/ holds longer runs.
+Time grid = column 1 of the CSV (the reference's controller depends on its inexact SNES/GMRES iteration counts).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from .fem_be import _SF_W, CrossedMesh, ic_bm1
+
+
+# ---- models ---------------------------------------------------------------------------------------------------------
+class BM2:
+    """fields: 0 c, 1 mu, 2..5 eta1..eta4"""
+    name, nf, L_dom, N = "bm2", 6, 200.0, 100
+    fields = ("c", "mu", "eta1", "eta2", "eta3", "eta4")
+
+    def __init__(self, c_alpha=0.3, c_beta=0.7, rho=np.sqrt(2.0), kappa_c=3.0, kappa_eta=3.0, M=5.0, w=1.0, alpha=5.0,
+                 L=5.0):
+        self.ca, self.cb, self.rho2 = c_alpha, c_beta, rho * rho
+        self.kc, self.ke, self.M, self.w, self.alpha, self.L = kappa_c, kappa_eta, M, w, alpha, L
+        nf = self.nf
+        self.T = np.zeros((nf, nf))
+        self.A = np.zeros((nf, nf))
+        self.Kc = np.zeros((nf, nf))
+        self.T[0, 0] = 1.0                       # c_t
+        self.Kc[0, 1] = M                        # + M K mu
+        self.A[1, 1] = 1.0                       # mu
+        self.Kc[1, 0] = -kappa_c                 # - kappa_c K c        (- int f_c lambda comes from S)
+        for i in range(4):
+            self.T[2 + i, 2 + i] = 1.0           # eta_t
+            self.Kc[2 + i, 2 + i] = L * kappa_eta
+        self.grad_coef = np.array([kappa_c, 0.0, kappa_eta, kappa_eta, kappa_eta, kappa_eta])
+
+    @staticmethod
+    def _h(u):
+        return u ** 3 * (6.0 * u * u - 15.0 * u + 10.0)
+
+    @staticmethod
+    def _hp(u):
+        return 30.0 * u * u * (1.0 - u) ** 2
+
+    @staticmethod
+    def _hpp(u):
+        return 60.0 * u * (1.0 - u) * (1.0 - 2.0 * u)
+
+    def ic(self, x, y, c0=0.5, eps=0.05, eps_eta=0.1, psi=1.5):
+        u = np.zeros((self.nf, x.size))
+        u[0] = ic_bm1(x, y, c0, eps)
+        for i in range(4):
+            ii = i + 1.0
+            u[2 + i] = eps_eta * (
+                np.cos((0.01 * ii) * x - 4.0) * np.cos((0.007 + 0.01 * ii) * y)
+                + np.cos((0.11 + 0.01 * ii) * x) * np.cos((0.11 + 0.01 * ii) * y)
+                + psi * (np.cos((0.046 + 0.001 * i) * x - (0.0405 + 0.001 * i) * y)
+                         * np.cos((0.031 + 0.001 * i) * x - (0.004 + 0.001 * i) * y)) ** 2) ** 2
+        return u
+
+    def source(self, v):
+        """v: (nf, ...) field values at quadrature points -> S (nf, ...)"""
+        c, e = v[0], v[2:6]
+        S = np.zeros_like(v)
+        h = self._h(e).sum(0)
+        fa, fb = self.rho2 * (c - self.ca) ** 2, self.rho2 * (c - self.cb) ** 2
+        S[1] = -(2.0 * self.rho2 * (c - self.ca) * (1.0 - h) + 2.0 * self.rho2 * (c - self.cb) * h)
+        e2 = (e * e).sum(0)
+        for i in range(4):
+            ei = e[i]
+            well = 2.0 * ei * (1.0 - ei) ** 2 - 2.0 * ei * ei * (1.0 - ei) + 2.0 * self.alpha * ei * (e2 - ei * ei)
+            S[2 + i] = self.L * ((fb - fa) * self._hp(ei) + self.w * well)
+        return S
+
+    def dsource(self, v):
+        """-> {(e, f): dS_e/du_f at the quadrature points}"""
+        c, e = v[0], v[2:6]
+        fa, fb = self.rho2 * (c - self.ca) ** 2, self.rho2 * (c - self.cb) ** 2
+        e2 = (e * e).sum(0)
+        d = {(1, 0): np.full_like(c, -2.0 * self.rho2)}
+        cross = 2.0 * self.rho2 * (self.ca - self.cb)
+        for i in range(4):
+            ei = e[i]
+            hp = self._hp(ei)
+            d[(1, 2 + i)] = -cross * hp
+            d[(2 + i, 0)] = self.L * cross * hp
+            well2 = 2.0 * (1.0 - ei) ** 2 - 8.0 * ei * (1.0 - ei) + 2.0 * ei * ei + 2.0 * self.alpha * (e2 - ei * ei)
+            d[(2 + i, 2 + i)] = self.L * ((fb - fa) * self._hpp(ei) + self.w * well2)
+            for j in range(4):
+                if j != i:
+                    d[(2 + i, 2 + j)] = self.L * self.w * 4.0 * self.alpha * ei * e[j]
+        return d
+
+    def energy_density(self, v):
+        c, e = v[0], v[2:6]
+        h = self._h(e).sum(0)
+        fa, fb = self.rho2 * (c - self.ca) ** 2, self.rho2 * (c - self.cb) ** 2
+        g = (e * e * (1.0 - e) ** 2).sum(0)
+        for i in range(4):
+            for j in range(i + 1, 4):
+                g = g + self.alpha * e[i] ** 2 * e[j] ** 2
+        return fa * (1.0 - h) + fb * h + self.w * g
+
+    def second_diag(self, mesh, u):
+        """column 3 of the CSV: total_solute = int c (bench2.py:181-182)"""
+        return float(np.sum(mesh.area * u[0][mesh.tri].mean(axis=1)))
+
+
+class BM3:
+    """fields: 0 U, 1 phi"""
+    name, nf, L_dom, N = "bm3", 2, 960.0, 350
+    fields = ("U", "phi")
+
+    def __init__(self, W0=1.0, tau0=1.0, D=10.0, Delta=-0.3):
+        self.W2, self.itau, self.D, self.Delta = W0 * W0, 1.0 / tau0, D, Delta
+        self.lam = D * tau0 / (0.6267 * W0 * W0)
+        self.T = np.eye(2)
+        self.A = np.zeros((2, 2))
+        self.Kc = np.array([[D, 0.5 * self.itau * self.W2], [0.0, self.itau * self.W2]])
+        self.grad_coef = np.array([0.0, self.W2])
+
+    def ic(self, x, y, r0=8.0, w=1.0, vin=1.0, vout=-1.0):
+        u = np.zeros((2, x.size))
+        u[0] = self.Delta
+        r = np.sqrt(x * x + y * y)
+        ramp = vout + 0.5 * (vin - vout) * (1.0 + np.cos(np.pi * (r - r0 + 0.5 * w) / w))
+        u[1] = np.where(r < r0 - 0.5 * w, vin, np.where(r > r0 + 0.5 * w, vout, ramp))
+        return u
+
+    def _dfdp(self, U, p):
+        P = 1.0 - p * p
+        return (p - self.lam * U * P) * P
+
+    def source(self, v):
+        d = self._dfdp(v[0], v[1])
+        return np.stack([-0.5 * self.itau * d, -self.itau * d])
+
+    def dsource(self, v):
+        U, p = v[0], v[1]
+        P = 1.0 - p * p
+        dU = -self.lam * P * P
+        dp = (1.0 + 2.0 * self.lam * U * p) * P - 2.0 * p * (p - self.lam * U * P)
+        return {(0, 0): -0.5 * self.itau * dU, (0, 1): -0.5 * self.itau * dp,
+                (1, 0): -self.itau * dU, (1, 1): -self.itau * dp}
+
+    def energy_density(self, v):
+        U, p = v[0], v[1]
+        return -0.5 * p * p + 0.25 * p ** 4 + self.lam * U * p * (1.0 - 2.0 / 3.0 * p * p + 0.2 * p ** 4)
+
+    def second_diag(self, mesh, u):
+        """column 3 of the CSV: solid_fraction (bench3.py:166-167)"""
+        return float(np.sum(mesh.area * (0.5 * (u[1][mesh.tri].mean(axis=1) + 1.0)))) / (mesh.L * mesh.L)
+
+
+MODELS = {"bm2": BM2, "bm3": BM3}
+
+
+class MultiFieldBE:
+    """Backward-Euler Newton solver for a generic multi-field model on the crossed P1 mesh."""
+
+    def __init__(self, model="bm2", N=None, newton_atol=1e-6, newton_max=10, line_search=None, **model_kw):
+        """line_search: "basic" (full Newton steps: bench3.py:124) or "cp" (PETSc's critical-point search with its default
+        single secant iteration: bench2.py:140); None = the model's choice in the reference script"""
+        self.m = MODELS[model](**model_kw) if isinstance(model, str) else model
+        self.line_search = line_search or ("cp" if self.m.name == "bm2" else "basic")
+        self.mesh = CrossedMesh(self.m.L_dom, N or self.m.N)
+        self.atol, self.newton_max = newton_atol, newton_max
+        self.u = self.m.ic(self.mesh.x, self.mesh.y)
+        self.t = 0.0
+        self.last_newton_iters = 0
+        self._W = self.mesh.area[:, None] * _SF_W[None, :]         # quadrature weights (ntri, 6)
+
+    # quadrature-point values of all fields: (nf, ntri, 6)
+    def _quad(self, u):
+        return np.einsum("fti,qi->ftq", u[:, self.mesh.tri], self.mesh._lam)
+
+    def residual(self, u, u0, dt):
+        mesh, m = self.mesh, self.m
+        Mu = np.stack([mesh.Mass @ u[f] for f in range(m.nf)])
+        Md = np.stack([mesh.Mass @ (u[f] - u0[f]) for f in range(m.nf)])
+        Ku = np.stack([mesh.K @ u[f] for f in range(m.nf)])
+        S = m.source(self._quad(u))                                 # (nf, ntri, 6)
+        R = (m.T / dt) @ Md + m.A @ Mu + m.Kc @ Ku
+        for e in range(m.nf):
+            if np.any(S[e]):
+                ge = (self._W * S[e]) @ mesh._lam                   # (ntri, 3)
+                R[e] += mesh._S @ ge.ravel()
+        return R.ravel()
+
+    def jacobian(self, u, dt):
+        mesh, m = self.mesh, self.m
+        d = m.dsource(self._quad(u))
+        blocks = [[None] * m.nf for _ in range(m.nf)]
+        for e in range(m.nf):
+            for f in range(m.nf):
+                B = None
+                coefM = m.T[e, f] / dt + m.A[e, f]
+                if coefM != 0.0:
+                    B = coefM * mesh.Mass
+                if m.Kc[e, f] != 0.0:
+                    B = m.Kc[e, f] * mesh.K if B is None else B + m.Kc[e, f] * mesh.K
+                if (e, f) in d:
+                    Ge = (self._W * d[(e, f)]) @ mesh._lamlam        # (ntri, 9)
+                    G = sp.csr_matrix((mesh._P @ Ge.ravel(), mesh._pat.indices, mesh._pat.indptr), shape=mesh._pat.shape)
+                    B = G if B is None else B + G
+                blocks[e][f] = B
+        return sp.bmat(blocks, format="csc")
+
+    def step(self, dt):
+        """One backward-Euler step with plain (undamped) Newton; returns (iterations, converged)."""
+        m = self.m
+        u0 = self.u.copy()
+        u = self.u.copy()
+        converged, its = False, 0
+        for its in range(self.newton_max + 1):
+            R = self.residual(u, u0, dt)
+            if np.linalg.norm(R) < self.atol:
+                converged = True
+                break
+            if its == self.newton_max:
+                break
+            d = spla.splu(self.jacobian(u, dt)).solve(-R)
+            lam = 1.0
+            if self.line_search == "cp":
+                # SNESLINESEARCHCP, max_its = 1: phi(l) = R(u + l d) . d; one secant step from l = 0 and l = 1 unless
+                # phi(1) is already negligible (rtol 1e-8 of phi(0))
+                phi0 = float(R @ d)
+                phi1 = float(self.residual(u + d.reshape(m.nf, -1), u0, dt) @ d)
+                if abs(phi1) > 1e-8 * abs(phi0) and phi0 != phi1:
+                    lam = phi0 / (phi0 - phi1)
+                    if not np.isfinite(lam):
+                        lam = 1.0
+            u = u + lam * d.reshape(m.nf, -1)
+        self.last_newton_iters = its
+        if converged:
+            self.u = u
+            self.t += dt
+        return its, converged
+
+    def diagnostics(self):
+        """(total_free_energy, second column of the reference CSV)"""
+        mesh, m = self.mesh, self.m
+        F = float(np.sum(self._W * m.energy_density(self._quad(self.u))))
+        for f in range(m.nf):
+            if m.grad_coef[f] != 0.0:
+                ue = self.u[f][mesh.tri]
+                gx, gy = np.sum(mesh.gx * ue, axis=1), np.sum(mesh.gy * ue, axis=1)
+                F += 0.5 * m.grad_coef[f] * float(np.sum(mesh.area * (gx * gx + gy * gy)))
+        return F, m.second_diag(mesh, self.u)
+
+    def run_on_time_grid(self, times, callback=None):
+        rows, tprev = [], 0.0
+        for tn in times:
+            its, ok = self.step(tn - tprev)
+            if not ok:
+                raise RuntimeError("Newton failed at t=%g dt=%g after %d iterations" % (tn, tn - tprev, its))
+            self.t = tprev = tn
+            F, C = self.diagnostics()
+            rows.append([tn, F, C])
+            if callback is not None:
+                callback(self, its)
+        return np.array(rows)
+
+
+def _main():
+    import argparse
+    import os
+    import time
+    ap = argparse.ArgumentParser(description="run the multi-field FEM-BE oracle on a fixture time grid")
+    ap.add_argument("--model", default="bm2", choices=["bm2", "bm3"])
+    ap.add_argument("--rows", type=int, default=4)
+    ap.add_argument("--golden", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    a = ap.parse_args()
+    csv = np.loadtxt(os.path.join(a.golden, "bench%s_out.csv" % a.model[2]), delimiter=",", skiprows=1)
+    t0 = time.time()
+    s = MultiFieldBE(a.model, newton_max=100)
+    F0, C0 = s.diagnostics()
+    print("t=0: F=%.10f second=%.10f  [setup %.1fs]" % (F0, C0, time.time() - t0), flush=True)
+
+    def cb(solver, its):
+        i = cb.i
+        F, C = solver.diagnostics()
+        print("row %3d t=%10.4f its=%2d F=%.10f relerr=%.2e second=%.10f relerr=%.2e  [%.1fs]" % (
+            i, solver.t, its, F, abs(F - csv[i, 1]) / abs(csv[i, 1]), C, abs(C - csv[i, 2]) / abs(csv[i, 2]),
+            time.time() - t0), flush=True)
+        cb.i += 1
+    cb.i = 0
+    s.run_on_time_grid(csv[:a.rows, 0], cb)
+
+
+if __name__ == "__main__":
+    _main()

@@ -291,6 +291,374 @@ __global__ __launch_bounds__(256) void fem_ic_kernel(const FemParams p, double c
   if (p.nf == 3) phi[n] = is_dirichlet(p, n) ? phi_bc(p, n) : 0.0;
 }
 
+
+// =====================================================================================================================
+// Generic multi-field models (BM2: dolfin/bench2.py, BM3: dolfin/bench3.py) -- SURVEY 8f next-4.
+// One residual block per field e over the unknown fields f, same decomposition as oracle/fem_multi.py:
+//   R_e = sum_f [ T_ef M (u_f - u0_f)/dt + A_ef M u_f + Kc_ef K u_f ] + int S_e(u_h) lambda_i      (6-point rule)
+// T, A, Kc are constant tables; S and dS_e/du_f are pointwise functions of the field values at a quadrature point.
+constexpr int MAXF = 6;
+struct GenModel {
+  int id = 0;  // 2: BM2 (c, mu, eta1..4), 3: BM3 (U, phi)
+  int nf = 0;
+  double T[MAXF][MAXF], A[MAXF][MAXF], Kc[MAXF][MAXF];
+  unsigned char nl[MAXF][MAXF];  // 1: dS_e/du_f is not identically zero
+  double gradc[MAXF];            // energy: sum_f gradc_f / 2 |grad u_f|^2
+  // BM2: q = {c_alpha, c_beta, rho^2, w, alpha, L};  BM3: q = {lam, 1/tau, Lx * Ly}
+  double q[8];
+  double icp[6];                 // initial-condition parameters (set by fembe_set_ic_gen)
+};
+struct FieldPtrs {
+  double* u[MAXF];
+};
+
+__device__ __forceinline__ double bm2_h(double u) { return (u * u * u) * ((6.0 * u * u - 15.0 * u) + 10.0); }
+__device__ __forceinline__ double bm2_hp(double u) { return 30.0 * (u * u) * ((1.0 - u) * (1.0 - u)); }
+__device__ __forceinline__ double bm2_hpp(double u) { return 60.0 * u * ((1.0 - u) * (1.0 - 2.0 * u)); }
+
+// S_e at one quadrature point (bench2.py:76-103 differentiated by hand; bench3.py:82)
+template <int NF>
+__device__ __forceinline__ void gen_source(const GenModel& m, const double (&v)[NF], double (&S)[NF]) {
+#pragma unroll
+  for (int e = 0; e < NF; ++e) S[e] = 0.0;
+  if constexpr (NF == 6) {
+    const double ca = m.q[0], cb = m.q[1], r2 = m.q[2], w = m.q[3], al = m.q[4], L = m.q[5];
+    const double c = v[0];
+    double h = 0.0, e2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h += bm2_h(v[2 + i]);
+      e2 += v[2 + i] * v[2 + i];
+    }
+    const double fa = r2 * ((c - ca) * (c - ca)), fb = r2 * ((c - cb) * (c - cb));
+    S[1] = -(2.0 * r2 * (c - ca) * (1.0 - h) + 2.0 * r2 * (c - cb) * h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double ei = v[2 + i];
+      const double well = (2.0 * ei * ((1.0 - ei) * (1.0 - ei)) - 2.0 * (ei * ei) * (1.0 - ei)) + 2.0 * al * ei * (e2 - ei * ei);
+      S[2 + i] = L * ((fb - fa) * bm2_hp(ei) + w * well);
+    }
+  } else {
+    const double lam = m.q[0], it = m.q[1];
+    const double U = v[0], p = v[1], P = 1.0 - p * p;
+    const double d = (p - lam * U * P) * P;
+    S[0] = -0.5 * it * d;
+    S[1] = -it * d;
+  }
+}
+
+// row e of dS/du at one quadrature point
+template <int NF>
+__device__ __forceinline__ void gen_dsource_row(const GenModel& m, int e, const double (&v)[NF], double (&d)[NF]) {
+#pragma unroll
+  for (int f = 0; f < NF; ++f) d[f] = 0.0;
+  if constexpr (NF == 6) {
+    const double ca = m.q[0], cb = m.q[1], r2 = m.q[2], w = m.q[3], al = m.q[4], L = m.q[5];
+    const double c = v[0];
+    const double cross = 2.0 * r2 * (ca - cb);
+    if (e == 1) {
+      d[0] = -2.0 * r2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[2 + i] = -cross * bm2_hp(v[2 + i]);
+    } else if (e >= 2) {
+      const int i = e - 2;
+      double e2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e2 += v[2 + j] * v[2 + j];
+      const double ei = v[2 + i];
+      const double fa = r2 * ((c - ca) * (c - ca)), fb = r2 * ((c - cb) * (c - cb));
+      d[0] = L * cross * bm2_hp(ei);
+      const double well2 = ((2.0 * ((1.0 - ei) * (1.0 - ei)) - 8.0 * ei * (1.0 - ei)) + 2.0 * (ei * ei)) + 2.0 * al * (e2 - ei * ei);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[2 + j] = j == i ? L * ((fb - fa) * bm2_hpp(ei) + w * well2) : L * w * 4.0 * al * ei * v[2 + j];
+    }
+  } else {
+    const double lam = m.q[0], it = m.q[1];
+    const double U = v[0], p = v[1], P = 1.0 - p * p;
+    const double dU = -lam * (P * P);
+    const double dp = (1.0 + 2.0 * lam * U * p) * P - 2.0 * p * (p - lam * U * P);
+    const double sc = e == 0 ? -0.5 * it : -it;
+    d[0] = sc * dU;
+    d[1] = sc * dp;
+  }
+}
+
+template <int NF>
+__device__ __forceinline__ double gen_energy_density(const GenModel& m, const double (&v)[NF]) {
+  if constexpr (NF == 6) {
+    const double ca = m.q[0], cb = m.q[1], r2 = m.q[2], w = m.q[3], al = m.q[4];
+    const double c = v[0];
+    double h = 0.0, g = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double ei = v[2 + i];
+      h += bm2_h(ei);
+      g += (ei * ei) * ((1.0 - ei) * (1.0 - ei));
+#pragma unroll
+      for (int j = i + 1; j < 4; ++j) g += al * (ei * ei) * (v[2 + j] * v[2 + j]);
+    }
+    const double fa = r2 * ((c - ca) * (c - ca)), fb = r2 * ((c - cb) * (c - cb));
+    return (fa * (1.0 - h) + fb * h) + w * g;
+  } else {
+    const double lam = m.q[0];
+    const double U = v[0], p = v[1], p2 = p * p;
+    return (-0.5 * p2 + 0.25 * (p2 * p2)) + lam * U * p * ((1.0 - (2.0 / 3.0) * p2) + 0.2 * (p2 * p2));
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void gen_residual_kernel(const FemParams p, const GenModel m,
+                                                           const int* __restrict__ ell_col,
+                                                           const double* __restrict__ ell_K,
+                                                           const double* __restrict__ ell_M,
+                                                           const int* __restrict__ nt_ptr, const int* __restrict__ nt_tri,
+                                                           const int* __restrict__ nt_loc, const int* __restrict__ tri,
+                                                           const FieldPtrs u, const FieldPtrs u0, double inv_dt,
+                                                           double* __restrict__ rhs) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.nn) return;
+  double mk[NF], md[NF], kk[NF], acc[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) mk[f] = md[f] = kk[f] = acc[f] = 0.0;
+  for (int e = 0; e < ELLW; ++e) {
+    const int col = ell_col[n * ELLW + e];
+    if (col < 0) continue;
+    const double Kv = ell_K[n * ELLW + e], Mv = ell_M[n * ELLW + e];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const double uf = u.u[f][col];
+      mk[f] += Mv * uf;
+      md[f] += Mv * (uf - u0.u[f][col]);
+      kk[f] += Kv * uf;
+    }
+  }
+  for (int t = nt_ptr[n]; t < nt_ptr[n + 1]; ++t) {
+    const int* tn = tri + 3 * nt_tri[t];
+    const int loc = nt_loc[t];
+    double ue[NF][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      ue[f][0] = u.u[f][tn[0]];
+      ue[f][1] = u.u[f][tn[1]];
+      ue[f][2] = u.u[f][tn[2]];
+    }
+    double a[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) a[f] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double v[NF], S[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) v[f] = (LAM[q][0] * ue[f][0] + LAM[q][1] * ue[f][1]) + LAM[q][2] * ue[f][2];
+      gen_source<NF>(m, v, S);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) a[f] += S[f] * LAM[q][loc];
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] += a[f] * (p.area / 6.0);
+  }
+  int grp, loc;
+  node_block(p, n, grp, loc);
+  double* r = rhs + (int64_t)grp * p.nb + loc * NF;
+#pragma unroll
+  for (int e = 0; e < NF; ++e) {
+    double R = acc[e];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) R += (m.T[e][f] * inv_dt) * md[f] + m.A[e][f] * mk[f] + m.Kc[e][f] * kk[f];
+    r[e] = -R;
+  }
+}
+
+// one thread per (triangle, equation e): the 3 x 3 element blocks of row e against every field f
+template <int NF>
+__global__ __launch_bounds__(256) void gen_jacobian_kernel(const FemParams p, const GenModel m,
+                                                           const int* __restrict__ tri, const double* __restrict__ Ke,
+                                                           const FieldPtrs u, double inv_dt, double* D, double* Lo,
+                                                           double* Up) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.ntri * NF) return;
+  const int t = idx / NF, e = idx % NF;
+  const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+  double ue[NF][3];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    ue[f][0] = u.u[f][n[0]];
+    ue[f][1] = u.u[f][n[1]];
+    ue[f][2] = u.u[f][n[2]];
+  }
+  double G[NF][6];  // symmetric 3 x 3 per field: (00, 01, 02, 11, 12, 22)
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) G[f][k] = 0.0;
+  bool any_nl = false;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) any_nl |= m.nl[e][f] != 0;
+  if (any_nl) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double v[NF], d[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) v[f] = (LAM[q][0] * ue[f][0] + LAM[q][1] * ue[f][1]) + LAM[q][2] * ue[f][2];
+      gen_dsource_row<NF>(m, e, v, d);
+      const double l0 = LAM[q][0], l1 = LAM[q][1], l2 = LAM[q][2];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const double w = d[f] * (p.area / 6.0);
+        G[f][0] += w * (l0 * l0);
+        G[f][1] += w * (l0 * l1);
+        G[f][2] += w * (l0 * l2);
+        G[f][3] += w * (l1 * l1);
+        G[f][4] += w * (l1 * l2);
+        G[f][5] += w * (l2 * l2);
+      }
+    }
+  }
+  int g[3], l[3];
+  for (int i = 0; i < 3; ++i) node_block(p, n[i], g[i], l[i]);
+  const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int f = 0; f < NF; ++f) {
+    const double cm = m.T[e][f] * inv_dt + m.A[e][f], ck = m.Kc[e][f];
+    if (cm == 0.0 && ck == 0.0 && !m.nl[e][f]) continue;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const double Mij = p.area / 12.0 * (i == j ? 2.0 : 1.0);
+        const double val = (cm * Mij + ck * Ke[9 * t + 3 * i + j]) + G[f][sym[i][j]];
+        jadd(p, D, Lo, Up, g[i], l[i], e, g[j], l[j], f, val);
+      }
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void gen_update_kernel(const FemParams p, const double* __restrict__ sol, FieldPtrs u,
+                                                         double scale) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.nn) return;
+  int g, l;
+  node_block(p, n, g, l);
+  const double* s = sol + (int64_t)g * p.nb + l * NF;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) u.u[f][n] += scale * s[f];
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, const double* __restrict__ b, int n,
+                                                  double* __restrict__ out) {
+  __shared__ double sh[4];  // single block, fixed order -> deterministic
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// diagnostics: out = {total free energy, int u_second (BM2: c; BM3: (phi + 1) / 2), 0} as per-block partials
+template <int NF>
+__global__ __launch_bounds__(256) void gen_diag_kernel(const FemParams p, const GenModel m, const int* __restrict__ tri,
+                                                       const double* __restrict__ Ke, const FieldPtrs u,
+                                                       double* __restrict__ partials) {
+  __shared__ double sh[3][4];
+  double sC = 0.0, sF = 0.0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < p.ntri; t += gridDim.x * 256) {
+    const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    double ue[NF][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      ue[f][0] = u.u[f][n[0]];
+      ue[f][1] = u.u[f][n[1]];
+      ue[f][2] = u.u[f][n[2]];
+    }
+    if (NF == 6)
+      sC += p.area * (((ue[0][0] + ue[0][1]) + ue[0][2]) / 3.0);
+    else
+      sC += p.area * (0.5 * ((((ue[1][0] + ue[1][1]) + ue[1][2]) / 3.0) + 1.0));
+    double fq = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      double v[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) v[f] = (LAM[q][0] * ue[f][0] + LAM[q][1] * ue[f][1]) + LAM[q][2] * ue[f][2];
+      fq += gen_energy_density<NF>(m, v);
+    }
+    double gsum = 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      if (m.gradc[f] == 0.0) continue;
+      double grad = 0.0;  // A |grad u_f|^2 = u_e^T K_e u_e
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) grad += ue[f][i] * Ke[9 * t + 3 * i + j] * ue[f][j];
+      gsum += 0.5 * m.gradc[f] * grad;
+    }
+    sF += p.area * fq / 6.0 + gsum;
+  }
+  double v3[3] = {sC, sF, 0.0};
+  for (int k = 0; k < 3; ++k) {
+    double a = v3[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    partials[blockIdx.x * 3 + k] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+  }
+}
+
+// initial conditions at the mesh nodes: BM2 pfbase.py:268-296 (icp = {c0, eps, eps_eta, psi}), BM3 pfbase.py:298-320
+// (icp = {Delta, r, w, vin, vout})
+__global__ __launch_bounds__(256) void gen_ic_kernel(const FemParams p, const GenModel m, FieldPtrs u) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.nn) return;
+  const int n1 = p.N + 1;
+  double X, Y;
+  if (n < n1 * n1) {
+    X = (n % n1) * p.h;
+    Y = (n / n1) * p.h;
+  } else {
+    const int k = n - n1 * n1;
+    X = (k % p.N + 0.5) * p.h;
+    Y = (k / p.N + 0.5) * p.h;
+  }
+  if (m.id == 2) {
+    const double c0 = m.icp[0], eps = m.icp[1], ee = m.icp[2], psi = m.icp[3];
+    const double t2 = cos(0.13 * X) * cos(0.087 * Y);
+    u.u[0][n] = c0 + eps * (cos(0.105 * X) * cos(0.11 * Y) + t2 * t2 + cos(0.025 * X - 0.15 * Y) * cos(0.07 * X - 0.02 * Y));
+    u.u[1][n] = 0.0;
+    for (int i = 0; i < 4; ++i) {
+      const double ii = i + 1.0, i0 = (double)i;
+      const double a = cos((0.01 * ii) * X - 4.0) * cos((0.007 + 0.01 * ii) * Y);
+      const double b = cos((0.11 + 0.01 * ii) * X) * cos((0.11 + 0.01 * ii) * Y);
+      const double cc = cos((0.046 + 0.001 * i0) * X - (0.0405 + 0.001 * i0) * Y) * cos((0.031 + 0.001 * i0) * X - (0.004 + 0.001 * i0) * Y);
+      const double sum = (a + b) + psi * (cc * cc);
+      u.u[2 + i][n] = ee * (sum * sum);
+    }
+  } else {
+    const double Delta = m.icp[0], r0 = m.icp[1], w = m.icp[2], vin = m.icp[3], vout = m.icp[4];
+    const double r = sqrt(X * X + Y * Y);
+    u.u[0][n] = Delta;
+    double ph;
+    if (r < r0 - 0.5 * w)
+      ph = vin;
+    else if (r > r0 + 0.5 * w)
+      ph = vout;
+    else
+      ph = vout + 0.5 * (vin - vout) * (1.0 + cos(3.14159265358979323846 * (r - r0 + 0.5 * w) / w));
+    u.u[1][n] = ph;
+  }
+}
+
+// padding unknowns of the last group (it has no centre row): identity rows
+__global__ __launch_bounds__(256) void gen_identity_kernel(const FemParams p, double* D) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int64_t bs = (int64_t)p.nb * p.nb;
+  if (idx < p.N * p.nf) {
+    const int uu = (p.N + 1) * p.nf + idx;
+    D[(int64_t)(p.ng - 1) * bs + uu + (int64_t)uu * p.nb] = 1.0;
+  }
+}
+
 }  // namespace
 
 struct FemBE {
@@ -308,6 +676,10 @@ struct FemBE {
   int solver = 0;                          // 0: block cyclic reduction (batched), 1: block Thomas (sequential)
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
+  double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
+  int line_search = 0;                             // 0: full Newton steps ('basic'), 1: SNESLINESEARCHCP (one secant step)
+  GenModel gm;                                     // model id 2 / 3: generic multi-field path (u, u0 hold the fields)
+  FieldPtrs u{}, u0{};
   double atol = 1e-6;
   int max_newton = 10;  // the reference's nlparams['maximum_iterations'] (bench1.py:88); pf_config.max_newton overrides
   int last_iters = 0;
@@ -484,7 +856,117 @@ void fembe_destroy(FemBE* fb) {
                   (void*)fb->rhs, (void*)fb->piv, (void*)fb->info, (void*)fb->scal, (void*)fb->partials})
     if (q) (void)hipFree(q);
   if (fb->scal_host) (void)hipHostFree(fb->scal_host);
+  if (fb->rhs0) (void)hipFree(fb->rhs0);
+  if (fb->rhs1) (void)hipFree(fb->rhs1);
+  for (int f = 3; f < MAXF; ++f) {  // fields 0..2 alias c / mu / phi
+    if (fb->u.u[f]) (void)hipFree(fb->u.u[f]);
+    if (fb->u0.u[f]) (void)hipFree(fb->u0.u[f]);
+  }
   delete fb;
+}
+
+// Generic multi-field models.  model 2 = BM2 (dolfin/bench2.py): mp = {c_alpha, c_beta, rho, kappa_c, M, kappa_eta, w,
+// alpha, L}; model 3 = BM3 (dolfin/bench3.py): mp = {W0, tau0, D, Delta}.
+int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, const double* mp, hipStream_t stream,
+                       std::string* err) {
+  const int nf = model == 2 ? 6 : 2;
+  int rc = fembe_create(out, nodes_per_side, h, nf, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, stream, err);
+  if (rc) return rc;
+  FemBE* fb = *out;
+  GenModel& m = fb->gm;
+  m.id = model;
+  m.nf = nf;
+  for (int e = 0; e < MAXF; ++e) {
+    m.gradc[e] = 0.0;
+    for (int f = 0; f < MAXF; ++f) {
+      m.T[e][f] = m.A[e][f] = m.Kc[e][f] = 0.0;
+      m.nl[e][f] = 0;
+    }
+  }
+  for (double& q : m.q) q = 0.0;
+  for (double& q : m.icp) q = 0.0;
+  if (model == 2) {
+    const double ca = mp[0], cb = mp[1], rho = mp[2], kc = mp[3], Mob = mp[4], ke = mp[5], w = mp[6], al = mp[7], L = mp[8];
+    m.q[0] = ca;
+    m.q[1] = cb;
+    m.q[2] = rho * rho;
+    m.q[3] = w;
+    m.q[4] = al;
+    m.q[5] = L;
+    m.T[0][0] = 1.0;     // c_t                              pfbase.py:369-372
+    m.Kc[0][1] = Mob;    // + M K mu
+    m.A[1][1] = 1.0;     // mu                               pfbase.py:375-378
+    m.Kc[1][0] = -kc;    // - kappa_c K c   (- int f_c lambda: S)
+    m.nl[1][0] = 1;
+    m.gradc[0] = kc;
+    for (int i = 0; i < 4; ++i) {
+      m.T[2 + i][2 + i] = 1.0;       // eta_t                pfbase.py:396-409
+      m.Kc[2 + i][2 + i] = L * ke;   // + L kappa_eta K eta  (+ L int f_eta lambda: S)
+      m.gradc[2 + i] = ke;
+      m.nl[1][2 + i] = 1;
+      m.nl[2 + i][0] = 1;
+      for (int j = 0; j < 4; ++j) m.nl[2 + i][2 + j] = 1;
+    }
+  } else {
+    const double W0 = mp[0], tau0 = mp[1], D = mp[2];
+    const double W2 = W0 * W0, it = 1.0 / tau0;
+    m.q[0] = D * tau0 / (0.6267 * W2);  // lam                bench3.py:66
+    m.q[1] = it;
+    m.q[2] = fb->p.L * fb->p.L;          // Lx * Ly (solid fraction)
+    m.T[0][0] = m.T[1][1] = 1.0;
+    m.Kc[0][0] = D;                      // diffusion_weak_form(U)                 bench3.py:94
+    m.Kc[0][1] = 0.5 * it * W2;          // - 0.5 allen_cahn_RHS_IBP(phi, test_U)  bench3.py:91,95
+    m.Kc[1][1] = it * W2;                // allen_cahn_weak_form(phi)              bench3.py:97
+    m.nl[0][0] = m.nl[0][1] = m.nl[1][0] = m.nl[1][1] = 1;
+    m.gradc[1] = W2;
+    m.icp[0] = mp[3];                    // Delta
+  }
+  fb->u.u[0] = fb->c;
+  fb->u.u[1] = fb->mu;
+  fb->u.u[2] = fb->phi;
+  fb->u0.u[0] = fb->c0;
+  fb->u0.u[1] = fb->mu0;
+  fb->u0.u[2] = fb->phi0;
+  const size_t nbytes = sizeof(double) * fb->p.nn;
+  for (int f = 3; f < nf; ++f) {
+    FB_HIP(hipMalloc(&fb->u.u[f], nbytes));
+    FB_HIP(hipMalloc(&fb->u0.u[f], nbytes));
+    FB_HIP(hipMemset(fb->u.u[f], 0, nbytes));
+    FB_HIP(hipMemset(fb->u0.u[f], 0, nbytes));
+  }
+  for (int f = nf; f < MAXF; ++f) fb->u.u[f] = fb->u0.u[f] = nullptr;
+  FB_HIP(hipMalloc(&fb->rhs0, sizeof(double) * (size_t)fb->p.nb * fb->p.ng));
+  FB_HIP(hipMalloc(&fb->rhs1, sizeof(double) * (size_t)fb->p.nb * fb->p.ng));
+  // the reference's SNES line search: 'cp' for BM2 (bench2.py:140), 'basic' for BM3 (bench3.py:124)
+  fb->line_search = model == 2 ? 1 : 0;
+  if (const char* e = getenv("PFHIP_FEM_LINESEARCH")) fb->line_search = std::string(e) == "cp" ? 1 : 0;
+  return 0;
+}
+
+int fembe_model(const FemBE* fb) { return fb->gm.id; }
+int fembe_nfields(const FemBE* fb) { return fb->p.nf; }
+
+// icp: BM2 {c0, eps, eps_eta, psi} (bench2.py:58-62), BM3 {r, w, vin, vout} (bench3.py:52-57; Delta comes from the model)
+int fembe_set_ic_gen(FemBE* fb, const double* icp) {
+  GenModel& m = fb->gm;
+  if (!m.id) return -1;
+  if (m.id == 2) {
+    for (int i = 0; i < 4; ++i) m.icp[i] = icp[i];
+  } else {
+    for (int i = 0; i < 4; ++i) m.icp[1 + i] = icp[i];
+  }
+  hipLaunchKernelGGL(gen_ic_kernel, dim3((fb->p.nn + 255) / 256), dim3(256), 0, fb->stream, fb->p, m, fb->u);
+  FB_HIP(hipGetLastError());
+  fb->have_prev = false;
+  return 0;
+}
+
+int fembe_set_field(FemBE* fb, int f, const double* host) {
+  if (!fb->gm.id || f < 0 || f >= fb->p.nf) return -1;
+  FB_HIP(hipMemcpyAsync(fb->u.u[f], host, sizeof(double) * fb->p.nn, hipMemcpyHostToDevice, fb->stream));
+  FB_HIP(hipStreamSynchronize(fb->stream));
+  fb->have_prev = false;
+  return 0;
 }
 
 int fembe_set_ic(FemBE* fb, double c0, double amp, double w0) {
@@ -513,15 +995,29 @@ int fembe_set_c(FemBE* fb, const double* host) {
 }
 
 int fembe_get(FemBE* fb, int field, double* host) {
-  const double* src = field == 0 ? fb->c : (field == 1 ? fb->mu : fb->phi);
+  const double* src = fb->gm.id ? fb->u.u[field] : (field == 0 ? fb->c : (field == 1 ? fb->mu : fb->phi));
   FB_HIP(hipMemcpyAsync(host, src, sizeof(double) * fb->p.nn, hipMemcpyDeviceToHost, fb->stream));
   FB_HIP(hipStreamSynchronize(fb->stream));
   return 0;
 }
 
-static int residual_norm(FemBE* fb, double inv_dt, double* nrm) {
+static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nullptr) {
   const FemParams& p = fb->p;
+  double* const rhs_saved = fb->rhs;
+  if (out) fb->rhs = out;  // the kernels below write -R into fb->rhs
+  struct Restore {
+    FemBE* f;
+    double* r;
+    ~Restore() { f->rhs = r; }
+  } restore{fb, rhs_saved};
   FB_HIP(hipMemsetAsync(fb->rhs, 0, sizeof(double) * (size_t)p.nb * p.ng, fb->stream));
+  if (fb->gm.id == 2)
+    hipLaunchKernelGGL(gen_residual_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
+                       fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
+  else if (fb->gm.id == 3)
+    hipLaunchKernelGGL(gen_residual_kernel<2>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
+                       fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
+  else
   hipLaunchKernelGGL(fem_residual_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->ell_col, fb->ell_K,
                      fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
                      fb->rhs);
@@ -645,6 +1141,8 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
   FB_HIP(hipMemcpyAsync(fb->c0, fb->c, nbytes, hipMemcpyDeviceToDevice, fb->stream));
   FB_HIP(hipMemcpyAsync(fb->mu0, fb->mu, nbytes, hipMemcpyDeviceToDevice, fb->stream));
   FB_HIP(hipMemcpyAsync(fb->phi0, fb->phi, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  for (int f = 3; f < p.nf; ++f)
+    FB_HIP(hipMemcpyAsync(fb->u0.u[f], fb->u.u[f], nbytes, hipMemcpyDeviceToDevice, fb->stream));
   const double inv_dt = 1.0 / dt;
   const size_t bsz = sizeof(double) * (size_t)p.nb * p.nb * p.ng;
   *converged = 0;
@@ -662,13 +1160,56 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     FB_HIP(hipMemsetAsync(fb->D, 0, bsz, fb->stream));
     FB_HIP(hipMemsetAsync(fb->Lo, 0, bsz, fb->stream));
     FB_HIP(hipMemsetAsync(fb->Up, 0, bsz, fb->stream));
+    if (fb->gm.id == 2) {
+      hipLaunchKernelGGL(gen_jacobian_kernel<6>, dim3((p.ntri * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
+                         fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
+      hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
+    } else if (fb->gm.id == 3) {
+      hipLaunchKernelGGL(gen_jacobian_kernel<2>, dim3((p.ntri * 2 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
+                         fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
+      hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
+    } else {
     hipLaunchKernelGGL(fem_jacobian_kernel, dim3((p.ntri + 255) / 256), dim3(256), 0, fb->stream, p, fb->tri, fb->Ke,
                        fb->c, inv_dt, fb->D, fb->Lo, fb->Up);
     const int nid = p.N * p.nf + (p.nf == 3 ? 2 * (p.N + 1) : 0);
     hipLaunchKernelGGL(fem_identity_kernel, dim3((nid + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
+    }
     FB_HIP(hipGetLastError());
+    const bool cp = fb->gm.id && fb->line_search == 1;
+    if (cp)  // keep -R(u): the solve overwrites rhs with the Newton direction d
+      FB_HIP(hipMemcpyAsync(fb->rhs0, fb->rhs, sizeof(double) * (size_t)p.nb * p.ng, hipMemcpyDeviceToDevice, fb->stream));
     rc = fb->solver == 1 ? block_solve(fb) : block_solve_bcr(fb);
     if (rc) return rc;
+    auto gen_update = [&](double scale) {
+      if (fb->gm.id == 2)
+        hipLaunchKernelGGL(gen_update_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
+                           (const double*)fb->rhs, fb->u, scale);
+      else
+        hipLaunchKernelGGL(gen_update_kernel<2>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
+                           (const double*)fb->rhs, fb->u, scale);
+    };
+    if (fb->gm.id) {
+      gen_update(1.0);
+      if (cp) {
+        // SNESLINESEARCHCP with its default single secant iteration (bench2.py:140): phi(l) = R(u + l d) . d,
+        // l = phi(0) / (phi(0) - phi(1)) unless phi(1) is already below rtol = 1e-8 of phi(0)
+        const int ntot = p.nb * p.ng;
+        double n1 = 0.0;
+        rc = residual_norm(fb, inv_dt, &n1, fb->rhs1);  // -R(u + d)
+        if (rc) return rc;
+        hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs0, (const double*)fb->rhs,
+                           ntot, fb->scal);
+        hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs1, (const double*)fb->rhs,
+                           ntot, fb->scal + 1);
+        FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));
+        FB_HIP(hipStreamSynchronize(fb->stream));
+        const double phi0 = -fb->scal_host[0], phi1 = -fb->scal_host[1];
+        if (std::fabs(phi1) > 1e-8 * std::fabs(phi0) && phi0 != phi1) {
+          const double lam = phi0 / (phi0 - phi1);
+          if (lam == lam && std::fabs(lam) < 1e6) gen_update(lam - 1.0);
+        }
+      }
+    } else
     hipLaunchKernelGGL(fem_update_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
                        (const double*)fb->rhs, fb->c, fb->mu, fb->phi);
   }
@@ -680,6 +1221,8 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     FB_HIP(hipMemcpyAsync(fb->c, fb->c0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
     FB_HIP(hipMemcpyAsync(fb->mu, fb->mu0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
     FB_HIP(hipMemcpyAsync(fb->phi, fb->phi0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+    for (int f = 3; f < p.nf; ++f)
+      FB_HIP(hipMemcpyAsync(fb->u.u[f], fb->u0.u[f], nbytes, hipMemcpyDeviceToDevice, fb->stream));
     fb->have_prev = false;
   }
   FB_HIP(hipStreamSynchronize(fb->stream));
@@ -696,6 +1239,8 @@ int fembe_rollback(FemBE* fb) {
   FB_HIP(hipMemcpyAsync(fb->c, fb->c0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
   FB_HIP(hipMemcpyAsync(fb->mu, fb->mu0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
   FB_HIP(hipMemcpyAsync(fb->phi, fb->phi0, nbytes, hipMemcpyDeviceToDevice, fb->stream));
+  for (int f = 3; f < fb->p.nf; ++f)
+    FB_HIP(hipMemcpyAsync(fb->u.u[f], fb->u0.u[f], nbytes, hipMemcpyDeviceToDevice, fb->stream));
   fb->have_prev = false;
   return 0;
 }
@@ -704,6 +1249,22 @@ int fembe_rollback(FemBE* fb) {
 int fembe_diagnostics(FemBE* fb, double out[3]) {
   const FemParams& p = fb->p;
   const int nblk = 160;
+  if (fb->gm.id) {
+    if (fb->gm.id == 2)
+      hipLaunchKernelGGL(gen_diag_kernel<6>, dim3(nblk), dim3(256), 0, fb->stream, p, fb->gm, fb->tri, fb->Ke, fb->u,
+                         fb->partials);
+    else
+      hipLaunchKernelGGL(gen_diag_kernel<2>, dim3(nblk), dim3(256), 0, fb->stream, p, fb->gm, fb->tri, fb->Ke, fb->u,
+                         fb->partials);
+    hipLaunchKernelGGL(fem_diag_final_kernel, dim3(1), dim3(64), 0, fb->stream, (const double*)fb->partials, nblk,
+                       fb->scal);
+    FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 3 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));
+    FB_HIP(hipStreamSynchronize(fb->stream));
+    out[0] = fb->scal_host[1];                                                      // total free energy
+    out[1] = fb->gm.id == 3 ? fb->scal_host[0] / fb->gm.q[2] : fb->scal_host[0];    // solid fraction / total solute
+    out[2] = 0.0;
+    return 0;
+  }
   hipLaunchKernelGGL(fem_diag_kernel, dim3(nblk), dim3(256), 0, fb->stream, p, fb->tri, fb->Ke, fb->c, fb->phi,
                      fb->partials);
   hipLaunchKernelGGL(fem_diag_final_kernel, dim3(1), dim3(64), 0, fb->stream, (const double*)fb->partials, nblk, fb->scal);

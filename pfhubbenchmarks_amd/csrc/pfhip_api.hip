@@ -412,6 +412,34 @@ int pf_config_default(pf_config* cfg, int dim, int n, double h) {
   return PF_OK;
 }
 
+int pf_config_model_defaults(pf_config* cfg, int model) {
+  if (!cfg || cfg->struct_bytes != (int32_t)sizeof(pf_config)) return PF_ERR_INVALID;
+  for (double& v : cfg->model_params) v = 0.0;
+  cfg->c_alpha = 0.3;
+  cfg->c_beta = 0.7;
+  cfg->M = 5.0;
+  if (model == PF_MODEL_BM1 || model == PF_MODEL_BM6) {
+    cfg->rho_s = 5.0;
+    cfg->kappa = 2.0;
+  } else if (model == PF_MODEL_BM2) {  // bench2.py:33-41
+    cfg->rho_s = 1.4142135623730951;   // rho = sqrt 2
+    cfg->kappa = 3.0;                  // kappa_c
+    cfg->model_params[0] = 3.0;        // kappa_eta
+    cfg->model_params[1] = 1.0;        // w
+    cfg->model_params[2] = 5.0;        // alpha
+    cfg->model_params[3] = 5.0;        // L
+  } else if (model == PF_MODEL_BM3) {  // bench3.py:31-37
+    cfg->model_params[0] = 1.0;        // W0
+    cfg->model_params[1] = 1.0;        // tau0
+    cfg->model_params[2] = 10.0;       // D
+    cfg->model_params[3] = -0.3;       // Delta
+  } else {
+    return PF_ERR_INVALID;
+  }
+  cfg->model = model;
+  return PF_OK;
+}
+
 int pf_slab_partition(int n_planes, int nranks, int rank, int* first, int* count) {
   if (n_planes < 1 || nranks < 1 || rank < 0 || rank >= nranks || !first || !count) return PF_ERR_INVALID;
   const int base = n_planes / nranks, rem = n_planes % nranks;
@@ -448,7 +476,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   std::string err;
   int rc = resolve(cfg, &g, &err);
   if (rc != PF_OK) return fail(nullptr, rc, err);
-  if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6) return fail(nullptr, PF_ERR_INVALID, "bad model");
+  const bool multi = cfg->model == PF_MODEL_BM2 || cfg->model == PF_MODEL_BM3;
+  if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6 && !multi) return fail(nullptr, PF_ERR_INVALID, "bad model");
+  if (multi && cfg->scheme != PF_SCHEME_FEM_BE)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3 run in the BE-parity mode (PF_SCHEME_FEM_BE) only");
   if (cfg->scheme != PF_SCHEME_FD_EXPLICIT && cfg->scheme != PF_SCHEME_SPECTRAL_SI && cfg->scheme != PF_SCHEME_FEM_BE)
     return fail(nullptr, PF_ERR_INVALID, "bad scheme");
   if (cfg->scheme == PF_SCHEME_FEM_BE &&
@@ -518,8 +549,17 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 8));
   PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 8, hipHostMallocDefault));
   if (cfg->scheme == PF_SCHEME_FEM_BE) {
-    int frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
-                           cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err);
+    int frc;
+    if (cfg->model == PF_MODEL_BM2) {
+      const double mp[9] = {cfg->c_alpha, cfg->c_beta, cfg->rho_s, cfg->kappa, cfg->M, cfg->model_params[0],
+                            cfg->model_params[1], cfg->model_params[2], cfg->model_params[3]};
+      frc = fembe_create_model(&h->fb, 2, cfg->n[0], cfg->h, mp, h->stream, &h->err);
+    } else if (cfg->model == PF_MODEL_BM3) {
+      frc = fembe_create_model(&h->fb, 3, cfg->n[0], cfg->h, cfg->model_params, h->stream, &h->err);
+    } else {
+      frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
+                         cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err);
+    }
     if (frc != 0) return bail(PF_ERR_HIP);
     fembe_set_max_newton(h->fb, cfg->max_newton);
   } else if (cfg->model == PF_MODEL_BM6 && slab_fft) {
@@ -586,6 +626,7 @@ static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   if (!h) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
   if (h->fb) {
+    if (fembe_model(h->fb) != 0) return fail(h, PF_ERR_STATE, "use pf_set_ic_bm2 / pf_set_ic_bm3 for this model");
     if (fembe_set_ic(h->fb, c0, amp, w0) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
     return PF_OK;
   }
@@ -596,11 +637,48 @@ static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   return PF_OK;
 }
 
+// field id of the C ABI -> index into the generic models' field array (-1: not a field of this model)
+static int gen_field_index(const pf_handle* h, int field) {
+  if (h->cfg.model == PF_MODEL_BM2) {
+    if (field == PF_FIELD_C) return 0;
+    if (field == PF_FIELD_MU) return 1;
+    if (field >= PF_FIELD_ETA1 && field < PF_FIELD_ETA1 + 4) return 2 + (field - PF_FIELD_ETA1);
+  } else if (h->cfg.model == PF_MODEL_BM3) {
+    if (field == PF_FIELD_U) return 0;
+    if (field == PF_FIELD_PHI) return 1;
+  }
+  return -1;
+}
+
+int pf_set_ic_bm2(pf_handle* h, double c0, double eps, double eps_eta, double psi) {
+  if (!h) return PF_ERR_INVALID;
+  if (!h->fb || h->cfg.model != PF_MODEL_BM2) return fail(h, PF_ERR_STATE, "pf_set_ic_bm2: handle is not a BM2 model");
+  const double icp[4] = {c0, eps, eps_eta, psi};
+  if (fembe_set_ic_gen(h->fb, icp) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+  return PF_OK;
+}
+
+int pf_set_ic_bm3(pf_handle* h, double r, double w, double vin, double vout) {
+  if (!h) return PF_ERR_INVALID;
+  if (!h->fb || h->cfg.model != PF_MODEL_BM3) return fail(h, PF_ERR_STATE, "pf_set_ic_bm3: handle is not a BM3 model");
+  if (!(w > 0.0)) return fail(h, PF_ERR_INVALID, "pf_set_ic_bm3: need w > 0");
+  const double icp[4] = {r, w, vin, vout};
+  if (fembe_set_ic_gen(h->fb, icp) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+  return PF_OK;
+}
+
 int pf_set_ic_bm1(pf_handle* h, double c0, double eps) { return set_ic(h, c0, eps, 0.105); }
 int pf_set_ic_bm6(pf_handle* h, double c0, double c1) { return set_ic(h, c0, c1, 0.2); }
 
 int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
+  if (h->fb && fembe_model(h->fb) != 0) {  // BM2 / BM3: any field of the model
+    const int f = gen_field_index(h, field);
+    if (f < 0) return fail(h, PF_ERR_INVALID, "pf_set_field: not a field of this model");
+    if ((int64_t)n != fembe_nodes(h->fb)) return fail(h, PF_ERR_INVALID, "pf_set_field: wrong element count");
+    if (fembe_set_field(h->fb, f, host) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   if (field != PF_FIELD_C) return fail(h, PF_ERR_UNSUPPORTED, "only PF_FIELD_C can be set");
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
   if (h->fb) {
@@ -637,6 +715,13 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
 
 int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
+  if (h->fb && fembe_model(h->fb) != 0) {
+    const int f = gen_field_index(h, field);
+    if (f < 0) return fail(h, PF_ERR_INVALID, "pf_get_field: not a field of this model");
+    if ((int64_t)n != fembe_nodes(h->fb)) return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count");
+    if (fembe_get(h->fb, f, host) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
+    return PF_OK;
+  }
   if (h->fb) {
     if (field < PF_FIELD_C || field > PF_FIELD_PHI || (field == PF_FIELD_PHI && h->cfg.model != PF_MODEL_BM6))
       return fail(h, PF_ERR_INVALID, "pf_get_field: bad field");

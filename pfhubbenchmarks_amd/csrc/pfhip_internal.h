@@ -124,6 +124,12 @@ struct FemBE;
 int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, double ca, double cb, double kappa,
                  double Mob, double k, double eps, hipStream_t stream, std::string* err);
 void fembe_destroy(FemBE* fb);
+int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, const double* mp, hipStream_t stream,
+                       std::string* err);  // model 2 = BM2, 3 = BM3 (generic multi-field path)
+int fembe_model(const FemBE* fb);           // 0: BM1 / BM6 kernels, 2 / 3: generic
+int fembe_nfields(const FemBE* fb);
+int fembe_set_ic_gen(FemBE* fb, const double* icp);
+int fembe_set_field(FemBE* fb, int f, const double* host);
 int fembe_nodes(const FemBE* fb);
 int fembe_last_iters(const FemBE* fb);
 int fembe_set_ic(FemBE* fb, double c0, double amp, double w0);

@@ -31,9 +31,9 @@ def report_times(bench):
     return np.loadtxt(os.path.join(_DATA, "%s_times.txt" % bench))
 
 
-def write_csv(path, rows):
+def write_csv(path, rows, header=CSV_HEADER):
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    np.savetxt(path, np.array(rows), fmt="%1.10f", header=CSV_HEADER, delimiter=",", comments="")
+    np.savetxt(path, np.array(rows), fmt="%1.10f", header=header, delimiter=",", comments="")
 
 
 def advance_to(solver, t_target, dt_sub, dt_min):
@@ -115,20 +115,28 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
     and retries (bench1.py:164-177); the iteration counts of a direct-LU Newton differ from the reference's inexact
     SNES/GMRES counts, so that time grid is this solver's own."""
     bm6 = bench == "bench6"
-    L, N = (100.0, 100) if bm6 else (200.0, 100)              # bench6.py:22-23 / bench1.py:21-22
-    end_time = (3.0 if bm6 else 1e3) if end_time is None else end_time
-    dt0, dt_min = (1e-2, 1e-4) if bm6 else (1e-1, 1e-2)       # bench6.py:180-181 / bench1.py:140-141
+    # per benchmark: domain, intervals (bench<N>.py:21-23), model, end_time, first dt and dt_min of the script's controller
+    # (bench1.py:138-141, bench2.py:208-211, bench3.py:192-195, bench6.py:178-181), third CSV column, output fields
+    L, N, model, end_default, dt0, dt_min, col3, out_fields = {
+        "bench1": (200.0, 100, "bm1", 1e3, 1e-1, 1e-2, "total_solute", ("c",)),
+        "bench6": (100.0, 100, "bm6", 3.0, 1e-2, 1e-4, "total_solute", ("c", "phi")),
+        "bench2": (200.0, 100, "bm2", 100.0, 1e-2, 1e-4, "total_solute", ("c", "eta1", "eta2", "eta3", "eta4")),
+        "bench3": (960.0, 350, "bm3", 100.0, 1e-2, 1e-4, "solid_fraction", ("U", "phi")),
+    }[bench]
+    header = "time,total_free_energy," + col3
+    multi = model in ("bm2", "bm3")
+    end_time = end_default if end_time is None else end_time
     rows = []
     store = None
-    if save_solution and not bm6:      # bench1.py:116-119 (bench6.py writes PVD files only, :152-153)
+    if save_solution and bench == "bench1":      # bench1.py:116-119 (bench6.py writes PVD files only, :152-153)
         store = pio.FieldStore(os.path.join(out_dir, "bench1", "conc.npz"), "w")
         store.write_mesh("crossed", N=N, L=L)
     t1 = time.time()
     # Newton cap: the reference's 10 (bench1.py:88) under its own controller; the committed time grid with exact linear
     # solves needs up to 24 plain Newton iterations (rows 21, 37), so the fixture controller lifts the cap
-    with PhaseFieldSolver(dim=2, n=N + 1, h=L / N, bc="mirror", scheme="fem_be", model="bm6" if bm6 else "bm1",
+    with PhaseFieldSolver(dim=2, n=N + 1, h=L / N, bc="mirror", scheme="fem_be", model=model,
                           device=device, max_newton=100 if controller == "fixture" else 10) as s:
-        (s.set_ic_bm6 if bm6 else s.set_ic_bm1)()
+        {"bm1": s.set_ic_bm1, "bm6": s.set_ic_bm6, "bm2": s.set_ic_bm2, "bm3": s.set_ic_bm3}[model]()
         if controller == "fixture":
             times = report_times(bench)
             times = times[[i for i, t in enumerate(times) if i == 0 or times[i - 1] < end_time + 1e-12]]
@@ -142,7 +150,12 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
                 tprev = float(tn)
                 F, C, _ = s.diagnostics()
                 rows.append([tprev, F, C])
-                if save_solution:   # same mesh, node order and PointData layout as the reference's conc00000N.vtu
+                if save_solution and multi:   # bench2.py:267-272 / bench3.py:233-236: one PVD series per field
+                    for fname in out_fields:
+                        stem = "conc" if fname == "c" else fname
+                        pio.write_vtu_crossed(os.path.join(out_dir, bench, "%s%06d.vtu" % (stem, it)),
+                                              s.get_field(fname), N, L)
+                elif save_solution:   # same mesh, node order and PointData layout as the reference's conc00000N.vtu
                     c = s.get_c()
                     pio.write_vtu_crossed(os.path.join(out_dir, bench, "conc%06d.vtu" % it), c, N, L)
                     if store is not None:
@@ -174,14 +187,19 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
     print("Time spent is %s" % spent)
     if store is not None:
         store.close()
-    if save_solution and controller == "fixture":
+    if save_solution and controller == "fixture" and multi:
+        for fname in out_fields:
+            stem = "conc" if fname == "c" else fname
+            pio.write_pvd(os.path.join(out_dir, bench, stem + ".pvd"), [r[0] for r in rows],
+                          ["%s%06d.vtu" % (stem, i) for i in range(len(rows))])
+    elif save_solution and controller == "fixture":
         pio.write_pvd(os.path.join(out_dir, bench, "conc.pvd"), [r[0] for r in rows],
                       ["conc%06d.vtu" % i for i in range(len(rows))])
         if bm6:
             pio.write_pvd(os.path.join(out_dir, bench, "phi.pvd"), [r[0] for r in rows],
                           ["phi%06d.vtu" % i for i in range(len(rows))])
-    write_csv(os.path.join(out_dir, "%s_out.csv" % bench), rows)
-    if not bm6:
+    write_csv(os.path.join(out_dir, "%s_out.csv" % bench), rows, header)
+    if bench == "bench1":
         write_csv(os.path.join(out_dir, "bench1", "stats.csv"), rows)
     return np.array(rows), spent
 
@@ -266,6 +284,29 @@ def run_b13d(intervals=50, L=100.0, dt=None, end_time=50.0, out_dir="results", d
     print("Time spent is %s" % spent)
     write_csv(os.path.join(out_dir, "b13d_out.csv"), rows)
     return np.array(rows), spent
+
+
+def _main_multi(bench, desc, argv=None):
+    ap = argparse.ArgumentParser(description=desc)
+    ap.add_argument("--controller", default="fixture", choices=["fixture", "reference"],
+                    help="fixture: the committed run's time grid; reference: the script's own dt rule")
+    ap.add_argument("--end-time", type=float, default=None)
+    ap.add_argument("--max-rows", type=int, default=None)
+    ap.add_argument("--out-dir", default="results")
+    ap.add_argument("--save-solution", action="store_true")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args(argv)
+    run_fem_be(bench, a.controller, a.end_time, a.out_dir, 0, not a.quiet, a.max_rows, a.save_solution)
+
+
+def main_bench2(argv=None):
+    _main_multi("bench2", "PFHub BM2 (Ostwald ripening) on MI355X: the reference's P1 backward-Euler discretisation "
+                          "(counterpart of dolfin/bench2.py)", argv)
+
+
+def main_bench3(argv=None):
+    _main_multi("bench3", "PFHub BM3 (dendritic growth) on MI355X: the reference's P1 backward-Euler discretisation "
+                          "(counterpart of dolfin/bench3.py)", argv)
 
 
 def main_b13d(argv=None):

@@ -12,8 +12,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpfhip.so")
 PF_OK, PF_ERR_INVALID, PF_ERR_UNSUPPORTED, PF_ERR_HIP, PF_ERR_STATE, PF_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 PF_BC_PERIODIC, PF_BC_MIRROR = 0, 1
 PF_SCHEME_FD_EXPLICIT, PF_SCHEME_SPECTRAL_SI, PF_SCHEME_FEM_BE = 0, 1, 2
-PF_MODEL_BM1, PF_MODEL_BM6 = 1, 6
-PF_FIELD_C, PF_FIELD_MU, PF_FIELD_PHI = 0, 1, 2
+PF_MODEL_BM1, PF_MODEL_BM6, PF_MODEL_BM2, PF_MODEL_BM3 = 1, 6, 2, 3
+PF_FIELD_C, PF_FIELD_MU, PF_FIELD_PHI, PF_FIELD_ETA1, PF_FIELD_U = 0, 1, 2, 3, 7
 PF_KERNEL_AUTO, PF_KERNEL_FUSED, PF_KERNEL_TWOPASS = 0, 1, 2
 PF_FLAG_BM6_ELIMINATE_PHI = 1
 
@@ -27,7 +27,7 @@ class PfConfig(C.Structure):
         ("rho_s", C.c_double), ("c_alpha", C.c_double), ("c_beta", C.c_double), ("kappa", C.c_double),
         ("M", C.c_double), ("k", C.c_double), ("eps_r", C.c_double),
         ("stream", C.c_void_p), ("ext_c", C.c_void_p * 2), ("ext_a2a", C.c_void_p * 2), ("ext_phi", C.c_void_p),
-        ("flags", C.c_int32), ("max_newton", C.c_int32),
+        ("flags", C.c_int32), ("max_newton", C.c_int32), ("model_params", C.c_double * 8),
     ]
 
 
@@ -68,6 +68,9 @@ SYMBOLS = {
     "pf_last_error": (C.c_char_p, [_H]),
     "pf_device_count": (C.c_int, []),
     "pf_config_default": (C.c_int, [C.POINTER(PfConfig), C.c_int, C.c_int, C.c_double]),
+    "pf_config_model_defaults": (C.c_int, [C.POINTER(PfConfig), C.c_int]),
+    "pf_set_ic_bm2": (C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "pf_set_ic_bm3": (C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double]),
     "pf_slab_partition": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_field_elems_with_ghosts": (C.c_int64, [C.POINTER(PfConfig)]),
     "pf_field_elems": (C.c_int64, [C.POINTER(PfConfig)]),

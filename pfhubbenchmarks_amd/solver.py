@@ -39,13 +39,20 @@ class PhaseFieldSolver:
         cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
         cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI,
                       "fem_be": _lib.PF_SCHEME_FEM_BE}[scheme]
-        cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6}[model]
+        cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6, "bm2": _lib.PF_MODEL_BM2,
+                     "bm3": _lib.PF_MODEL_BM3}[model]
+        if model in ("bm2", "bm3"):      # the reference's constants for the model (bench2.py:33-41, bench3.py:31-37)
+            _lib.check(self._lib.pf_config_model_defaults(C.byref(cfg), cfg.model))
         cfg.kernel = {"auto": _lib.PF_KERNEL_AUTO, "fused": _lib.PF_KERNEL_FUSED,
                       "twopass": _lib.PF_KERNEL_TWOPASS}[kernel]
         cfg.device = int(device)
         if eliminate_phi:
             cfg.flags |= _lib.PF_FLAG_BM6_ELIMINATE_PHI
         for k, v in params.items():
+            if k == "model_params":
+                for i, x in enumerate(v):
+                    cfg.model_params[i] = float(x)
+                continue
             if not hasattr(cfg, k):
                 raise TypeError("unknown model parameter %r" % k)
             setattr(cfg, k, int(v) if k == "max_newton" else float(v))
@@ -60,6 +67,7 @@ class PhaseFieldSolver:
         if scheme == "fem_be":      # fields are nodal vectors in the reference's node order (corners, then centres)
             self.shape = (self.nelem,)
         self.scheme = scheme
+        self.model = model
         self.last_iters = 0
         self.t = 0.0
 
@@ -92,6 +100,32 @@ class PhaseFieldSolver:
     def set_ic_bm6(self, c0=0.5, c1=0.04):
         self._ck(self._lib.pf_set_ic_bm6(self._h, c0, c1))
         self.t = 0.0
+
+    def set_ic_bm2(self, c0=0.5, eps=0.05, eps_eta=0.1, psi=1.5):
+        """InitialConditionsBench2 (dolfin/bench2.py:58-62, pfbase.py:268-296)"""
+        self._ck(self._lib.pf_set_ic_bm2(self._h, c0, eps, eps_eta, psi))
+        self.t = 0.0
+
+    def set_ic_bm3(self, r=8.0, w=1.0, vin=1.0, vout=-1.0):
+        """InitialConditionsBench3 (dolfin/bench3.py:52-57, pfbase.py:298-320)"""
+        self._ck(self._lib.pf_set_ic_bm3(self._h, r, w, vin, vout))
+        self.t = 0.0
+
+    FIELD_IDS = {"c": _lib.PF_FIELD_C, "mu": _lib.PF_FIELD_MU, "phi": _lib.PF_FIELD_PHI, "U": _lib.PF_FIELD_U,
+                 "eta1": _lib.PF_FIELD_ETA1, "eta2": _lib.PF_FIELD_ETA1 + 1, "eta3": _lib.PF_FIELD_ETA1 + 2,
+                 "eta4": _lib.PF_FIELD_ETA1 + 3}
+
+    def get_field(self, name):
+        """any field of the model by name: c, mu, phi, U, eta1..eta4 (pf_get_field)"""
+        out = np.empty(self.shape, dtype=np.float64)
+        self._ck(self._lib.pf_get_field(self._h, self.FIELD_IDS[name], out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def set_field(self, name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if a.size != self.nelem:
+            raise ValueError("set_field: expected %d values, got %s" % (self.nelem, a.shape))
+        self._ck(self._lib.pf_set_field(self._h, self.FIELD_IDS[name], a.ctypes.data_as(C.c_void_p), a.size))
 
     def set_c(self, arr):
         a = np.ascontiguousarray(arr, dtype=np.float64)

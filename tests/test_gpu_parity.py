@@ -743,6 +743,68 @@ def test_drivers_save_solution_and_process_bench1(lib, golden_dir, tmp_path):
     np.testing.assert_array_equal(pio.read_vtu_pointdata(files2[1])["c"].reshape(101, 101), cs2[1])
 
 
+def test_fem_be_bm2_against_reference_rows_and_oracle(lib, golden_dir):
+    """PFHub BM2 (dolfin/bench2.py: Cahn-Hilliard + 4 Allen-Cahn fields, P1^6 on the crossed mesh,
+    backward Euler, Newton) through the generic multi-field kernels of the BE-parity mode.  (a) t = 0: fields equal the
+    oracle's interpolated initial condition, F and C equal the oracle's; (b) the first rows of the reference's committed
+    results/bench2_out.csv: F within 1e-8, C within 1e-9 (the CPU oracle oracle/fem_multi.py reproduces these rows to
+    1e-11: oracle/logs/fem_multi_bm2_cp.log); (c) rollback / failed-solve semantics."""
+    import os
+    from oracle import fem_multi
+    csv = np.loadtxt(os.path.join(golden_dir, "bench2_out.csv"), delimiter=",", skiprows=1)
+    o = fem_multi.MultiFieldBE("bm2", newton_max=100)
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", model="bm2", max_newton=100) as s:
+        s.set_ic_bm2()
+        for f, name in enumerate(o.m.fields):
+            assert np.abs(s.get_field(name) - o.u[f]).max() < 1e-14, name
+        F, C, _ = s.diagnostics()
+        Fo, Co = o.diagnostics()
+        assert abs(F - Fo) <= 1e-12 * abs(Fo) and abs(C - Co) <= 1e-13 * abs(Co)
+        assert abs(C - 20504.4690550850) < 1e-8
+        tprev = 0.0
+        for i in range(10):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok and s.last_iters <= 8, (i, s.last_iters)
+            tprev = csv[i, 0]
+            F, C, _ = s.diagnostics()
+            assert abs(F - csv[i, 1]) <= 1e-8 * csv[i, 1], (i, F, csv[i, 1])
+            assert abs(C - csv[i, 2]) <= 1e-9 * csv[i, 2], (i, C, csv[i, 2])
+        before = {n: s.get_field(n) for n in ("c", "mu", "eta3")}
+        ok, _, _ = s.step(csv[10, 0] - tprev, 1, check=True)
+        assert ok
+        s.rollback()
+        for n, v in before.items():
+            np.testing.assert_array_equal(s.get_field(n), v)
+        # one oracle step from the GPU state: the two Newton solves land on the same root
+        o.u = np.stack([s.get_field(n) for n in o.m.fields])
+        its, ok_o = o.step(csv[10, 0] - tprev)
+        ok, _, _ = s.step(csv[10, 0] - tprev, 1, check=True)
+        assert ok and ok_o and s.last_iters == its
+        for f, name in enumerate(o.m.fields):
+            assert np.abs(s.get_field(name) - o.u[f]).max() < 1e-9, name
+
+
+def test_fem_be_bm3_against_reference_rows(lib, golden_dir):
+    """PFHub BM3 (dolfin/bench3.py: U, phi on the 350 x 350 crossed mesh, 491 402 unknowns) through the same generic
+    kernels: t = 0 known answers and the first rows of results/bench3_out.csv (F within 1e-8, solid fraction to the
+    CSV's printed precision)."""
+    import os
+    csv = np.loadtxt(os.path.join(golden_dir, "bench3_out.csv"), delimiter=",", skiprows=1)
+    with PhaseFieldSolver(dim=2, n=351, h=960.0 / 350, bc="mirror", scheme="fem_be", model="bm3", max_newton=100) as s:
+        s.set_ic_bm3()
+        U, phi = s.get_field("U"), s.get_field("phi")
+        assert U.shape == (351 * 351 + 350 * 350,) and (U == -0.3).all()
+        assert phi.max() == 1.0 and phi.min() == -1.0 and (phi > -1.0).sum() < 40       # the seed of radius 8 at the origin
+        tprev = 0.0
+        for i in range(6):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok and s.last_iters <= 8, (i, s.last_iters)
+            tprev = csv[i, 0]
+            F, S, _ = s.diagnostics()
+            assert abs(F - csv[i, 1]) <= 1e-8 * csv[i, 1], (i, F, csv[i, 1])
+            assert abs(S - csv[i, 2]) <= 6e-11, (i, S, csv[i, 2])        # the CSV prints 10 decimals of a 5e-5 number
+
+
 def _lockstep(engs, op, dt=0.0):
     """Run the distributed state machine of all slab handles on the one GPU, doing by hand (tensor copies) the
     all-to-all / halo exchanges that FFTSlabSolver does over RCCL."""
