@@ -253,14 +253,20 @@ class MultiFieldBE:
             d = spla.splu(self.jacobian(u, dt)).solve(-R)
             lam = 1.0
             if self.line_search == "cp":
-                # SNESLINESEARCHCP, max_its = 1: phi(l) = R(u + l d) . d; one secant step from l = 0 and l = 1 unless
-                # phi(1) is already negligible (rtol 1e-8 of phi(0))
-                phi0 = float(R @ d)
-                phi1 = float(self.residual(u + d.reshape(m.nf, -1), u0, dt) @ d)
-                if abs(phi1) > 1e-8 * abs(phi0) and phi0 != phi1:
-                    lam = phi0 / (phi0 - phi1)
-                    if not np.isfinite(lam):
-                        lam = 1.0
+                # SNESLINESEARCHCP with PETSc's default max_its = 1, restated from SNESLineSearchApply_CP (W = X - lambda Y,
+                # Y = J^-1 F = -d, fty = F(W) . Y): one evaluation at the full step, one secant update, two safeguards
+                fty_old = -float(R @ d)
+                fty = -float(self.residual(u + d.reshape(m.nf, -1), u0, dt) @ d)
+                if abs(fty) >= 1e-8 * abs(fty_old):
+                    s = fty - fty_old
+                    if s > 0.0:
+                        s = -s                      # "if the solve is going in the wrong direction, fix it"
+                    if s != 0.0:
+                        upd = 1.0 - fty / s
+                        if upd < 1e-12:
+                            upd = 1.0 + fty / s     # "switch directions if we stepped out of bounds"
+                        if np.isfinite(upd) and abs(upd) <= 1e8:
+                            lam = upd
             u = u + lam * d.reshape(m.nf, -1)
         self.last_newton_iters = its
         if converged:

@@ -677,6 +677,7 @@ struct FemBE {
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
+  bool verbose = false;                            // PFHIP_FEM_VERBOSE=1: residual norm (and line-search data) per iteration
   int line_search = 0;                             // 0: full Newton steps ('basic'), 1: SNESLINESEARCHCP (one secant step)
   GenModel gm;                                     // model id 2 / 3: generic multi-field path (u, u0 hold the fields)
   FieldPtrs u{}, u0{};
@@ -829,6 +830,8 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
       fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
+      const char* v = getenv("PFHIP_FEM_VERBOSE");
+      fb->verbose = v && v[0] == '1';
     }
     FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * (size_t)p.nb * p.ng));
     FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
@@ -1151,6 +1154,7 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     double nrm = 0.0;
     int rc = residual_norm(fb, inv_dt, &nrm);
     if (rc) return rc;
+    if (fb->verbose) fprintf(stderr, "[fem_be] dt %.6g newton %d ||R|| %.6e\n", dt, it, nrm);
     if (!(nrm == nrm)) break;  // NaN
     if (nrm < fb->atol) {
       *converged = 1;
@@ -1191,8 +1195,9 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     if (fb->gm.id) {
       gen_update(1.0);
       if (cp) {
-        // SNESLINESEARCHCP with its default single secant iteration (bench2.py:140): phi(l) = R(u + l d) . d,
-        // l = phi(0) / (phi(0) - phi(1)) unless phi(1) is already below rtol = 1e-8 of phi(0)
+        // SNESLINESEARCHCP (bench2.py:140) with its default single secant iteration, restated from PETSc's
+        // SNESLineSearchApply_CP including its two safeguards: one function evaluation at the full step, one secant
+        // update of lambda from fty(0), fty(1)
         const int ntot = p.nb * p.ng;
         double n1 = 0.0;
         rc = residual_norm(fb, inv_dt, &n1, fb->rhs1);  // -R(u + d)
@@ -1203,11 +1208,21 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
                            ntot, fb->scal + 1);
         FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));
         FB_HIP(hipStreamSynchronize(fb->stream));
-        const double phi0 = -fb->scal_host[0], phi1 = -fb->scal_host[1];
-        if (std::fabs(phi1) > 1e-8 * std::fabs(phi0) && phi0 != phi1) {
-          const double lam = phi0 / (phi0 - phi1);
-          if (lam == lam && std::fabs(lam) < 1e6) gen_update(lam - 1.0);
+        // PETSc's variables (W = X - lambda Y with Y = J^-1 F = -d): fty = F(W) . Y = -(R . d)
+        const double fty_old = fb->scal_host[0], fty = fb->scal_host[1];
+        double lam = 1.0;
+        if (std::fabs(fty) >= 1e-8 * std::fabs(fty_old)) {     // rtol of SNESLineSearch
+          double s = fty - fty_old;                            // (fty - fty_old) / (lambda - lambda_old), 1 - 0
+          if (s > 0.0) s = -s;                                 // "if the solve is going in the wrong direction, fix it"
+          if (s != 0.0) {
+            double upd = 1.0 - fty / s;
+            if (upd < 1e-12) upd = 1.0 + fty / s;              // "switch directions if we stepped out of bounds"
+            if (upd == upd && std::fabs(upd) <= 1e8) lam = upd;  // inf / nan / > maxstep: keep the full step
+          }
         }
+        if (fb->verbose)
+          fprintf(stderr, "[fem_be]   cp: fty0 %.4e fty1 %.4e ||R(u+d)|| %.4e lambda %.6f\n", fty_old, fty, n1, lam);
+        if (lam != 1.0) gen_update(lam - 1.0);
       }
     } else
     hipLaunchKernelGGL(fem_update_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,

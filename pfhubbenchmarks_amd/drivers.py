@@ -146,7 +146,9 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
             for it, tn in enumerate(times):
                 ok, _, _ = s.step(float(tn) - tprev, 1, check=True)
                 if not ok:
-                    raise RuntimeError("Newton failed at t = %g" % tn)
+                    write_csv(os.path.join(out_dir, "%s_out.partial.csv" % bench), rows, header)
+                    raise RuntimeError("Newton failed at t = %g (row %d, dt = %g) after %d iterations; the rows so far "
+                                       "are in %s_out.partial.csv" % (tn, it, float(tn) - tprev, s.last_iters, bench))
                 tprev = float(tn)
                 F, C, _ = s.diagnostics()
                 rows.append([tprev, F, C])
