@@ -174,6 +174,10 @@ typedef struct pf_handle pf_handle;
 int pf_version(void);
 /* message of the last failure on this handle (NULL handle: last failure of a pf_create on this thread) */
 const char* pf_last_error(const pf_handle* h);
+/* one-line description of the compute path this handle runs (scheme, kernel family) -- and a WARNING when it is not the
+ * fast one: an odd nx makes the FD scheme fall back from the fused 16 B/cell kernel to the two-pass kernels (40 B/cell,
+ * ~6x slower).  The string lives as long as the handle. */
+const char* pf_status_string(const pf_handle* h);
 /* number of HIP devices visible, or <0; touches the HIP runtime */
 int pf_device_count(void);
 /* fill *cfg with the reference's BM1 constants for an n^dim periodic grid (pure host, no HIP call) */

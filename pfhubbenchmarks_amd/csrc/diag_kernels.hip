@@ -218,13 +218,14 @@ __global__ __launch_bounds__(DIAG_BLOCK) void diag_stream2_kernel(const DiagArgs
 #pragma unroll
     for (int r = 0; r <= ROWS; ++r) {
       int y = y0 + r;
-      const bool on = lane_on && (r < ROWS ? y < k.ny : y - 1 < k.ny);  // halo row: needed iff the row above it is on
-      if (y >= k.ny) y -= k.ny;                                          // y0 + ROWS <= ny + ROWS - 1 < 2 ny when on
+      const bool own = lane_on && y < k.ny;                          // this wave accumulates row r
+      const bool on = lane_on && (r == 0 ? y < k.ny : y - 1 < k.ny);  // loaded if owned OR the y+1 row of an owned row
+      if (y >= k.ny) y -= k.ny;                                       // then y == ny: the periodic wrap to row 0
       off[r] = on ? (uint32_t)(((int64_t)y * k.nx + x) * 8) : DOOB;
       if (r < ROWS) {
-        row_on[r] = on;
+        row_on[r] = own;
         const int xn = x + 2 >= k.nx ? 0 : x + 2;
-        offx[r] = (on && last) ? (uint32_t)(((int64_t)y * k.nx + xn) * 8) : DOOB;
+        offx[r] = (own && last) ? (uint32_t)(((int64_t)y * k.nx + xn) * 8) : DOOB;
       }
     }
     const int zs = ch * k.zchunk, ze = min(k.nz, zs + k.zchunk);

@@ -128,6 +128,7 @@ struct pf_handle {
   hipEvent_t ev_t0 = nullptr;        // recorded by pf_timing_enable(h, 1): origin of the per-launch start offsets
   std::vector<float> s_dur, s_start; // per-launch samples since then (pf_timing_samples), capped at kMaxSamples
   std::string err;
+  std::string status;  // pf_status_string
 };
 
 namespace {
@@ -594,6 +595,29 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
 #undef PF_HIP_C
   *out = h;
   return PF_OK;
+}
+
+const char* pf_status_string(const pf_handle* h) {
+  if (!h) return "";
+  pf_handle* m = const_cast<pf_handle*>(h);
+  const pf_config& c = h->cfg;
+  if (h->fb) {
+    m->status = "fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction";
+  } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
+    m->status = "spectral: semi-implicit Fourier";
+  } else {
+    FdArgs a = make_args(h, 1.0, 0, h->g.nz);
+    const bool fused = c.kernel != PF_KERNEL_TWOPASS && ch_fd_fused_supported(a);
+    if (fused)
+      m->status = ch_fd2d_supported(a) ? "fd: fused 2-D multi-step kernel (LDS resident)"
+                                        : "fd: fused 2.5-D stencil kernel (16 B per cell update)";
+    else if (c.kernel == PF_KERNEL_TWOPASS)
+      m->status = "fd: two-pass kernels (requested; 40 B per cell update)";
+    else
+      m->status = "WARNING fd: nx is odd (or a buffer is not 16-byte aligned), so the fused kernel cannot run -- two-pass "
+                  "kernels, 40 B per cell update instead of 16 (about 6x slower); pad nx to an even number";
+  }
+  return m->status.c_str();
 }
 
 int pf_destroy(pf_handle* h) {

@@ -67,6 +67,7 @@ SYMBOLS = {
     "pf_version": (C.c_int, []),
     "pf_last_error": (C.c_char_p, [_H]),
     "pf_device_count": (C.c_int, []),
+    "pf_status_string": (C.c_char_p, [_H]),
     "pf_config_default": (C.c_int, [C.POINTER(PfConfig), C.c_int, C.c_int, C.c_double]),
     "pf_config_model_defaults": (C.c_int, [C.POINTER(PfConfig), C.c_int]),
     "pf_set_ic_bm2": (C.c_int, [_H, C.c_double, C.c_double, C.c_double, C.c_double]),

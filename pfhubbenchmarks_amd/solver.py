@@ -68,6 +68,10 @@ class PhaseFieldSolver:
             self.shape = (self.nelem,)
         self.scheme = scheme
         self.model = model
+        self.status = (self._lib.pf_status_string(self._h) or b"").decode()
+        if self.status.startswith("WARNING"):
+            import warnings
+            warnings.warn(self.status, RuntimeWarning, stacklevel=2)
         self.last_iters = 0
         self.t = 0.0
 

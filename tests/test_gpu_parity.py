@@ -81,6 +81,11 @@ def test_fused_multi_chunk_and_many_steps(lib, orc):
 
 
 def test_odd_nx_needs_twopass(lib, orc):
+    with pytest.warns(RuntimeWarning, match="nx is odd"):          # the 6x cliff is announced, not silent
+        with PhaseFieldSolver(dim=3, n=(7, 6, 5), h=1.0) as s_odd:
+            assert "two-pass" in s_odd.status
+    with PhaseFieldSolver(dim=3, n=(8, 6, 5), h=1.0) as s_even:
+        assert s_even.status.startswith("fd: fused 2.5-D")
     rng = np.random.default_rng(2)
     c = 0.5 + 0.1 * rng.standard_normal((3, 5, 7))
     np.testing.assert_array_equal(gpu_fd_step(lib, c, 1e-3, L.PF_KERNEL_AUTO), orc.fd_step(c, 1e-3))
