@@ -179,6 +179,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed K-step blocks (median reported); 0 = as many as needed for 0.25 s of timed work, <= 25")
     ap.add_argument("--no-also", action="store_true", help="default workload only: skip the side measurements")
+    ap.add_argument("--halo", default="wide", choices=["wide", "narrow"],
+                    help="FD slab path (N > 1 or --slab): 'wide' = PF_FLAG_WIDE_HALO, 4 ghost planes exchanged every second "
+                         "step (half the hand-offs, 8 instead of 12 redundant plane reads per step); 'narrow' = 2 ghost "
+                         "planes every step.  Bit-identical results.")
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
                              "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
@@ -292,6 +296,11 @@ def workload_table(workload, world):
     return w
 
 
+def eng_planes(nzg, world, rank):
+    from pfhubbenchmarks_amd.solver import slab_partition
+    return slab_partition(nzg, world, rank)[1]
+
+
 def _median_index(vals):
     """index of the (lower) median element: an actual block, not an average of two"""
     order = sorted(range(len(vals)), key=lambda i: vals[i])
@@ -318,7 +327,8 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
             solver = FFTSlabSolver(eng)
         else:
-            eng = HipSlabEngine(gn, h, world, rank, local_rank)
+            wide = a.halo == "wide" and a.transport == "rccl" and eng_planes(gn[2], world, rank) >= 4
+            eng = HipSlabEngine(gn, h, world, rank, local_rank, wide=wide)
             eng.set_ic_bm1(0.5, 0.05)
             solver = SlabSolver(eng, transport=a.transport, fused=a.fused_slab)
         timer = eng
@@ -419,9 +429,10 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
                    "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
-                   "parallelism": "slab%d%s%s%s" % (world, "-forced" if a.slab else "", "-REHEARSAL-one-device-gloo" if rehearsal else "",
-                                                  ("-ipc-fused" if a.fused_slab else "-ipc")
-                                                  if (dist is not None and a.transport == "ipc") else "")},
+                   "parallelism": "slab%d%s%s%s%s" % (world, "-forced" if a.slab else "", "-REHEARSAL-one-device-gloo" if rehearsal else "",
+                                                    ("-ipc-fused" if a.fused_slab else "-ipc")
+                                                    if (dist is not None and a.transport == "ipc") else "",
+                                                    "-widehalo" if (slab and getattr(timer, "wide", False)) else "")},
         # timed-region bookkeeping: what ran before the clock started, and every timed block (the reported one is the median)
         "preheat_ms": preheat_ms, "preheat_steps": preheat_steps, "repeats": len(blocks),
         "block_ms_per_step": block_ms,

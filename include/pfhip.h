@@ -119,6 +119,14 @@ typedef struct pf_config {
 
 /* pf_config.flags */
 enum {
+  PF_FLAG_WIDE_HALO = 2,        /* slab mode, FD scheme (BM1, or BM6 with phi eliminated), fused kernel: 4 ghost planes per side
+                                   exchanged every SECOND step instead of 2 every step (communication-avoiding).  Steps
+                                   alternate: A (needs fresh ghosts: pf_halo_layout.needs_exchange = 1) computes planes
+                                   [-2, nz+2) -- begin = the interior [2, nz-2), finish = two 4-plane strips; B computes
+                                   [0, nz) from them in ONE launch with no exchange (begin does it, finish only swaps).
+                                   Halves the hand-offs per step and cuts the strips' redundant reads from 12 to 8 planes
+                                   per step for 4 / nz more arithmetic.  Needs >= 4 (periodic) / 5 (mirror walls) planes per
+                                   rank.  Results are bit-identical to the 2-ghost path. */
   PF_FLAG_BM6_ELIMINATE_PHI = 1 /* BM6, periodic box, FD scheme: phi solves lap_h(phi) = -(k/eps)(c - mean c) with the SAME
                                    discrete Laplacian the Cahn-Hilliard step applies to mu, so lap_h(k phi) =
                                    -(k^2/eps)(c - mean c) exactly and the time step needs no Poisson solve:
@@ -138,14 +146,16 @@ typedef struct pf_step_info {
 typedef struct pf_halo_layout {
   double* base;            /* device pointer of the current c buffer */
   int64_t plane_elems;     /* doubles per plane of the slab axis */
-  int32_t ghost;           /* ghost planes per side (2) */
+  int32_t ghost;           /* ghost planes per side (2; 4 with PF_FLAG_WIDE_HALO) */
   int32_t n_local;         /* owned planes */
   int64_t send_lo_off, send_hi_off; /* first / last `ghost` owned planes */
   int64_t recv_lo_off, recv_hi_off; /* ghost planes below / above */
   int32_t rank_lo, rank_hi;         /* neighbour ranks: a ring (periodic bc) or a line (mirror bc: -1 = wall, the
                                        library mirrors the owned planes into those ghost layers itself) */
   int32_t cur_index;                /* which of the two c buffers (cfg.ext_c[cur_index]) is current */
-  int32_t reserved0;
+  int32_t needs_exchange;           /* 1: the next pf_step_finish reads the ghost planes of the current buffer -- exchange
+                                       them between pf_step_begin and pf_step_finish; 0 (every second step with
+                                       PF_FLAG_WIDE_HALO): no exchange for the next step */
 } pf_halo_layout;
 
 /* Distributed operations that need collectives the library does not perform itself (it never communicates).

@@ -66,6 +66,11 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
     if (g->nzg < 2 * cfg->nranks) return bad("need >= 2 planes per rank");
     pf_slab_partition(g->nzg, cfg->nranks, cfg->rank, &g->z0, &g->nz);
     g->ghost = 2;
+    if (cfg->flags & PF_FLAG_WIDE_HALO) {  // 4 ghost planes, exchanged every second step (pfhip.h)
+      const int need = g->zline ? 5 : 4;   // a wall reflects planes +1 .. +4 of the rank that owns it
+      if (g->nzg / cfg->nranks < need) return bad("PF_FLAG_WIDE_HALO needs >= 4 (periodic) / 5 (mirror) planes per rank");
+      g->ghost = 4;
+    }
     g->zwrap = 0;
   } else {
     g->z0 = 0;
@@ -120,6 +125,8 @@ struct pf_handle {
   bool own_stream = false;
   bool step_open = false;
   double open_dt = 0.0;
+  bool wide = false;       // PF_FLAG_WIDE_HALO: 4 ghost planes; the kernels see them as (2 ghost + 2 extra owned) planes
+  int wide_phase = 0;      // 0: next step is A (ghosts must be fresh), 1: next step is B (no exchange)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t ev_used = 0;
@@ -142,6 +149,7 @@ void swap_buffers(pf_handle* h) {
 }
 // c changed behind the schemes' backs (set_field / set_ic / rollback)
 void invalidate_derived(pf_handle* h) {
+  h->wide_phase = 0;
   h->cbar_valid = false;
   h->have_prev = false;
   h->phi_valid = false;
@@ -174,6 +182,10 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
   a.ny = h->g.ny;
   a.nz = h->g.nz;
   a.ghost = h->g.ghost;
+  if (h->wide) {  // virtual view: planes [-2, nz+2) are "owned", 2 ghost planes remain; callers pass virtual plane ranges
+    a.nz = h->g.nz + 4;
+    a.ghost = 2;
+  }
   a.zwrap = h->g.zwrap;
   a.zlo = zlo;
   a.zhi = zhi;
@@ -503,6 +515,11 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     return fail(nullptr, PF_ERR_UNSUPPORTED,
                 "BM6 with the spectral scheme: periodic box on one GPU only (phi is eliminated in Fourier space)");
   if (cfg->kernel < PF_KERNEL_AUTO || cfg->kernel > PF_KERNEL_TWOPASS) return fail(nullptr, PF_ERR_INVALID, "bad kernel");
+  if ((cfg->flags & PF_FLAG_WIDE_HALO) && g.ghost != 0 &&
+      (cfg->scheme != PF_SCHEME_FD_EXPLICIT || cfg->kernel == PF_KERNEL_TWOPASS || (g.nx & 1) ||
+       (cfg->model == PF_MODEL_BM6 && !(cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI))))
+    return fail(nullptr, PF_ERR_UNSUPPORTED,
+                "PF_FLAG_WIDE_HALO: FD scheme with the fused kernel (even nx), BM1 or BM6 with phi eliminated");
   if ((cfg->ext_c[0] == nullptr) != (cfg->ext_c[1] == nullptr))
     return fail(nullptr, PF_ERR_INVALID, "ext_c: give both buffers or none");
 
@@ -511,6 +528,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   h->cfg = *cfg;
   h->g = g;
   h->elim = (cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI) != 0;
+  h->wide = (cfg->flags & PF_FLAG_WIDE_HALO) != 0 && g.ghost == 4;
   auto bail = [&](int code) {
     g_create_error = h->err;
     pf_destroy(h);
@@ -876,7 +894,7 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out) {
   out->rank_lo = (g.zends & 1) ? -1 : (h->cfg.rank + h->cfg.nranks - 1) % h->cfg.nranks;  // -1: wall, no neighbour
   out->rank_hi = (g.zends & 2) ? -1 : (h->cfg.rank + 1) % h->cfg.nranks;
   out->cur_index = h->cur;
-  out->reserved0 = 0;
+  out->needs_exchange = (h->wide && h->wide_phase == 1) ? 0 : 1;
   return PF_OK;
 }
 
@@ -889,7 +907,14 @@ int pf_step_begin(pf_handle* h, double dt) {
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
   const int g = h->g.ghost, nz = h->g.nz;
   PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], h->g.plane, nz, g, h->g.zends, h->stream));  // walls (z-line only)
-  int rc = launch_step(h, dt, g, nz - g);  // interior planes need owned data only
+  int rc;
+  if (h->wide) {
+    // virtual plane v = real plane + 2.  A: interior real [2, nz-2) now, the two 4-plane strips in pf_step_finish;
+    // B: real [0, nz) in one launch (its inputs [-2, nz+2) were computed by step A), nothing left for pf_step_finish
+    rc = h->wide_phase == 0 ? launch_step(h, dt, 4, nz) : launch_step(h, dt, 2, nz + 2);
+  } else {
+    rc = launch_step(h, dt, g, nz - g);  // interior planes need owned data only
+  }
   if (rc) return rc;
   h->step_open = true;
   h->open_dt = dt;
@@ -901,6 +926,17 @@ int pf_step_finish(pf_handle* h) {
   if (!h->step_open) return fail(h, PF_ERR_STATE, "pf_step_finish without pf_step_begin");
   const int g = h->g.ghost, nz = h->g.nz;
   int rc;
+  if (h->wide) {
+    if (h->wide_phase == 0) {  // step A: real planes [-2, 2) and [nz-2, nz+2) = virtual [0, 4) and [nz, nz+4)
+      rc = nz > 4 ? launch_step(h, h->open_dt, 0, 4, 1, nz, nz + 4) : launch_step(h, h->open_dt, 0, nz + 4);
+      if (rc) return rc;
+    }
+    const int next = 1 - h->wide_phase;
+    swap_buffers(h);
+    h->wide_phase = next;
+    h->step_open = false;
+    return PF_OK;
+  }
   if (nz - g > g) {
     rc = launch_step(h, h->open_dt, 0, g, 1, nz - g, nz);  // both boundary strips in one launch
     if (rc) return rc;
@@ -920,6 +956,7 @@ int pf_step_slab_fused(pf_handle* h, double dt, const int64_t* flag_lo, const in
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: not in slab mode");
   if (h->sf && !h->elim) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: a begin / finish step is open");
+  if (h->wide) return fail(h, PF_ERR_UNSUPPORTED, "pf_step_slab_fused: not with PF_FLAG_WIDE_HALO");
   const int g = h->g.ghost, nz = h->g.nz;
   if (nz - g <= g) return fail(h, PF_ERR_UNSUPPORTED, "pf_step_slab_fused: needs more than 2 * ghost planes per rank");
   PF_HIP(h, launch_reflect_ghosts(h->c[h->cur], h->g.plane, nz, g, h->g.zends, h->stream));  // walls (z-line only)

@@ -16,6 +16,7 @@ PF_MODEL_BM1, PF_MODEL_BM6, PF_MODEL_BM2, PF_MODEL_BM3 = 1, 6, 2, 3
 PF_FIELD_C, PF_FIELD_MU, PF_FIELD_PHI, PF_FIELD_ETA1, PF_FIELD_U = 0, 1, 2, 3, 7
 PF_KERNEL_AUTO, PF_KERNEL_FUSED, PF_KERNEL_TWOPASS = 0, 1, 2
 PF_FLAG_BM6_ELIMINATE_PHI = 1
+PF_FLAG_WIDE_HALO = 2
 
 
 class PfConfig(C.Structure):
@@ -41,7 +42,7 @@ class PfHaloLayout(C.Structure):
         ("base", C.c_void_p), ("plane_elems", C.c_int64), ("ghost", C.c_int32), ("n_local", C.c_int32),
         ("send_lo_off", C.c_int64), ("send_hi_off", C.c_int64), ("recv_lo_off", C.c_int64),
         ("recv_hi_off", C.c_int64), ("rank_lo", C.c_int32), ("rank_hi", C.c_int32), ("cur_index", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("needs_exchange", C.c_int32),
     ]
 
 

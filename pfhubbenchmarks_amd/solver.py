@@ -234,8 +234,10 @@ class HipSlabEngine:
     extension, so a buffer plane is 2(ny-1) x 2(nx-1) while set_local / get_local speak physical nodes."""
 
     ghost = 2
+    wide = False
 
-    def __init__(self, n, h, nranks, rank, device, bc="periodic", **params):
+    def __init__(self, n, h, nranks, rank, device, bc="periodic", wide=False, **params):
+        """wide=True: PF_FLAG_WIDE_HALO -- 4 ghost planes exchanged every second step (pfhip.h)"""
         import torch
         self.torch = torch
         self._lib = _lib.load()
@@ -245,6 +247,10 @@ class HipSlabEngine:
         cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
         cfg.force_slab = 1          # nranks == 1: the rank is its own ring neighbour (single-GPU tests of this path)
         cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
+        self.wide = bool(wide)
+        if wide:
+            cfg.flags |= _lib.PF_FLAG_WIDE_HALO
+            self.ghost = 4
         for k, v in params.items():
             setattr(cfg, k, float(v))
         self.device = torch.device("cuda", device)
@@ -255,7 +261,7 @@ class HipSlabEngine:
         lx, ly = (2 * (nx - 1), 2 * (ny - 1)) if bc == "mirror" else (nx, ny)
         elems = int(self._lib.pf_field_elems_with_ghosts(C.byref(cfg)))
         if elems < 0:
-            raise ValueError("invalid slab configuration (mirror bc needs >= 3 planes per rank, periodic >= 2)")
+            raise ValueError("invalid slab configuration (planes per rank: mirror bc >= 3, periodic >= 2; wide halo >= 5 / 4)")
         assert elems == (self.nz + 2 * self.ghost) * ly * lx
         self._block, self.buffers = _placed_buffers(torch, self._lib, cfg, (self.nz + 2 * self.ghost, ly, lx),
                                                     self.device)
@@ -290,6 +296,14 @@ class HipSlabEngine:
         self._ck(self._lib.pf_halo_layout_get(self._h, C.byref(lay)))
         assert lay.base == self.buffers[lay.cur_index].data_ptr()
         return lay.cur_index
+
+    def needs_exchange(self):
+        """does the next step read the ghost planes of the current buffer?  (every step; every second step when wide)"""
+        if not self.wide:
+            return True
+        lay = _lib.PfHaloLayout()
+        self._ck(self._lib.pf_halo_layout_get(self._h, C.byref(lay)))
+        return bool(lay.needs_exchange)
 
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
@@ -472,6 +486,8 @@ class SlabSolver:
         self.t = 0.0
         # "rccl": torch.distributed isend / irecv (any backend, incl. gloo in the CPU tests);
         # "ipc":  peer-mapped ghost planes written by a side-stream kernel (one node, IpcHaloTransport)
+        if transport == "ipc" and getattr(engine, "wide", False):
+            raise ValueError("the peer-copy transport works on 2 ghost planes; use transport='rccl' with a wide-halo engine")
         self.transport = IpcHaloTransport(engine, group) if transport == "ipc" else None
         # fused: one launch per step -- the boundary-strip workgroups wait for the neighbours' flags inside the kernel
         # (pf_step_slab_fused); needs the flag words of the peer-copy transport
@@ -527,9 +543,11 @@ class SlabSolver:
                 e.step_fused(dt, tr.flags, tr.seq, tr.timeout)
             self.ghosts_fresh = False
             self.t += dt
+        need = getattr(e, "needs_exchange", None)
         for _ in range(0 if self.fused else nsteps):
             with e.stream_context():
-                reqs = [] if self.ghosts_fresh else self._post_exchange()
+                # wide-halo engines read their ghost planes every second step only (PF_FLAG_WIDE_HALO)
+                reqs = [] if (self.ghosts_fresh or (need is not None and not need())) else self._post_exchange()
                 e.step_begin(dt)
                 for r in reqs:
                     r.wait()

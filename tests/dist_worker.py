@@ -13,15 +13,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     import torch.distributed as dist
-    from oracle_engine import OracleSlabEngine
+    from oracle_engine import OracleSlabEngine, OracleWideSlabEngine
     from pfhubbenchmarks_amd.solver import SlabSolver
     out, nsteps = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     bc = sys.argv[3] if len(sys.argv) > 3 else "periodic"
-    nzg = max(12, 3 * world)                                 # >= 3 planes per rank (the mirror line needs them)
+    wide = len(sys.argv) > 4 and sys.argv[4] == "wide"
+    nzg = max(12, (5 if wide else 3) * world)               # planes per rank: >= 3 (mirror line), >= 5 with the wide halo
     n = (16, 10, nzg) if bc == "periodic" else (9, 6, nzg)   # mirror: nodes of the no-flux box
-    eng = OracleSlabEngine(n, 1.0, world, rank, bc=bc)
+    eng = (OracleWideSlabEngine if wide else OracleSlabEngine)(n, 1.0, world, rank, bc=bc)
     rng = np.random.default_rng(3)
     full = 0.5 + 0.1 * rng.standard_normal((n[2], n[1], n[0]))
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])

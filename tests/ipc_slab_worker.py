@@ -23,10 +23,10 @@ def main():
     n = (128, 24, nzg) if bc == "periodic" else (65, 13, nzg)
     rng = np.random.default_rng(41)
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
-    eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc)
-    eng.set_local(full[eng.z0:eng.z0 + eng.nz])
     mode = sys.argv[3] if len(sys.argv) > 3 else "split"
-    if mode == "p2p":             # torch.distributed isend / irecv of the GPU ghost planes (gloo stages them on the host)
+    eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc, wide=mode == "p2p_wide")
+    eng.set_local(full[eng.z0:eng.z0 + eng.nz])
+    if mode in ("p2p", "p2p_wide"):             # torch.distributed isend / irecv of the GPU ghost planes (gloo stages them on the host)
         s = SlabSolver(eng, transport="rccl")
     else:
         s = SlabSolver(eng, transport="ipc", fused=mode == "fused")

@@ -44,6 +44,26 @@ def main():
     eng.close()
     print("FD slab path over NCCL: ok", flush=True)
 
+    # --- the same with PF_FLAG_WIDE_HALO (4 ghost planes every second step) through SlabSolver over RCCL, incl. a step
+    # right after diagnostics and the no-flux line with both walls on this rank
+    for bc, nn in (("periodic", n), ("mirror", (65, 17, 12))):
+        fw = 0.5 + 0.05 * rng.standard_normal(nn[::-1])
+        eng = HipSlabEngine(nn, 1.0, 1, 0, 0, bc=bc, wide=True)
+        eng.set_local(fw)
+        s = SlabSolver(eng)
+        with PhaseFieldSolver(dim=3, n=nn, h=1.0, bc=bc) as ref:
+            ref.set_c(fw)
+            s.step(1e-3, 5)
+            ref.step(1e-3, 5)
+            d1, r1 = s.diagnostics(), ref.diagnostics()
+            assert abs(d1[0] - r1[0]) <= 1e-13 * abs(r1[0]) and abs(d1[1] - r1[1]) <= 1e-13 * abs(r1[1]), (bc, d1, r1)
+            s.step(1e-3, 4)
+            ref.step(1e-3, 4)
+            eng.sync()
+            assert np.array_equal(s.gather_field(), ref.get_c()), "wide-halo slab path differs (%s)" % bc
+        eng.close()
+    print("wide-halo slab path over NCCL: ok", flush=True)
+
     # --- BASELINE.json config 4's per-GPU shape: one 1024 x 1024 x 128 slab of the 1024^3 box over 8 GPUs (8 MiB planes,
     # 16 MiB ghost messages, 32-bit in-plane offsets at their largest) on the production path, against the plain
     # single-domain handle on the same planes, bit for bit

@@ -109,6 +109,79 @@ class OracleSlabEngine:
         pass
 
 
+class OracleWideSlabEngine(OracleSlabEngine):
+    """CPU mirror of HipSlabEngine(wide=True) -- PF_FLAG_WIDE_HALO (include/pfhip.h): 4 ghost planes exchanged every second
+    step.  Step A (ghosts fresh) computes real planes [-2, nz+2): begin = the interior [2, nz-2), finish = the two 4-plane
+    strips; step B computes [0, nz) in one go, no exchange.  The oracle sees the buffer as nz + 4 owned planes with 2
+    ghost planes (virtual plane = real plane + 2), exactly as the library hands it to the fused kernel."""
+    ghost = 4
+    wide = True
+
+    def __init__(self, n, h, nranks, rank, bc="periodic", **params):
+        super().__init__(n, h, nranks, rank, bc=bc, **params)
+        assert self.nz >= (5 if bc == "mirror" else 4)
+        shape = (self.nz + 8,) + tuple(self.buffers[0].shape[1:])
+        self.buffers = [torch.zeros(shape, dtype=torch.float64) for _ in range(2)]
+        self.phase = 0
+
+    def needs_exchange(self):
+        return self.phase == 0
+
+    def _reflect(self):
+        if self.bc != "mirror":
+            return
+        b, nz, g = self.buffers[self._cur], self.nz, 4
+        for k in range(1, g + 1):
+            if self.rank_lo < 0:
+                b[g - k] = b[g + k].clone()
+            if self.rank_hi < 0:
+                b[g + nz - 1 + k] = b[g + nz - 1 - k].clone()
+
+    def set_local(self, arr):
+        a = np.ascontiguousarray(arr)
+        if self.bc == "mirror":
+            a = np.stack([ch_fd.even_extend(p) for p in a])
+        self.buffers[self._cur][4:4 + self.nz] = torch.from_numpy(np.ascontiguousarray(a))
+        self.phase = 0
+
+    def get_local(self):
+        return self.buffers[self._cur][4:4 + self.nz, :self.ny, :self.nx].numpy().copy()
+
+    def step_begin(self, dt):
+        assert self._open is None
+        self._reflect()
+        nz = self.nz
+        if self.phase == 0:
+            self._launch(dt, 4, nz)                # real [2, nz - 2)
+        else:
+            self._launch(dt, 2, nz + 2)            # real [0, nz)
+        self._open = dt
+
+    def step_finish(self):
+        dt, nz = self._open, self.nz
+        if self.phase == 0:
+            if nz > 4:
+                self._launch(dt, 0, 4)             # real [-2, 2)
+                self._launch(dt, nz, nz + 4)       # real [nz - 2, nz + 2)
+            else:
+                self._launch(dt, 0, nz + 4)
+        self._cur ^= 1
+        self.phase ^= 1
+        self._open = None
+
+    def diag_local(self):
+        if self.bc == "mirror":
+            self._reflect()
+            b = self.buffers[self._cur]
+            narrow = OracleSlabEngine.__new__(OracleSlabEngine)       # reuse the 2-ghost trapezoid sums on a view
+            narrow.__dict__.update(self.__dict__)
+            narrow.buffers = [b[2:-2], b[2:-2]]
+            narrow._cur = 0
+            return OracleSlabEngine._diag_mirror(narrow)
+        F, C, E = ch_fd.diagnostics(self.buffers[self._cur].numpy(), h=self.h, dim=3, ghost=4, zwrap=0)
+        return [F, C, E]
+
+
 class OracleFFTSlabEngine(OracleSlabEngine):
     """CPU mirror of HipFFTSlabEngine: the same distributed state machine (pf_dist_begin / pf_dist_advance in
     csrc/pfhip_api.hip) restated with numpy FFTs, so FFTSlabSolver's collectives run under gloo without a GPU."""

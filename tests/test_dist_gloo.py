@@ -20,17 +20,19 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_slab_solver_matches_single_domain(world, tmp_path, orc):
+@pytest.mark.parametrize("world,halo", [(2, "narrow"), (3, "narrow"), (8, "narrow"), (2, "wide"), (3, "wide"), (8, "wide")])
+def test_slab_solver_matches_single_domain(world, halo, tmp_path, orc):
+    """halo = "wide": PF_FLAG_WIDE_HALO's protocol (4 ghost planes every second step) through SlabSolver; 5 steps so that
+    both step kinds, an odd count and a step right after diagnostics are exercised"""
     out = str(tmp_path / "res.npz")
-    nsteps = 4
+    nsteps = 4 if halo == "narrow" else 5
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), out,
-                                       str(nsteps)], env=env, cwd=ROOT))
+                                       str(nsteps), "periodic", halo], env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=300) == 0
     res = np.load(out)
@@ -45,19 +47,19 @@ def test_slab_solver_matches_single_domain(world, tmp_path, orc):
     np.testing.assert_array_equal(res["field"], c)
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_mirror_bc_line_of_slabs_matches_even_extension(world, tmp_path, orc):
+@pytest.mark.parametrize("world,halo", [(2, "narrow"), (3, "narrow"), (8, "narrow"), (2, "wide"), (3, "wide")])
+def test_mirror_bc_line_of_slabs_matches_even_extension(world, halo, tmp_path, orc):
     """PF_BC_MIRROR in slab mode ('a line with local reflection at the ends'): SlabSolver skips the wall
     neighbours (-1), the engine mirrors its own planes; result = the whole-domain oracle on the 3-D even extension."""
     out = str(tmp_path / "res.npz")
-    nsteps = 4
+    nsteps = 4 if halo == "narrow" else 5
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), out,
-                                       str(nsteps), "mirror"], env=env, cwd=ROOT))
+                                       str(nsteps), "mirror", halo], env=env, cwd=ROOT))
     for p in procs:
         assert p.wait(timeout=300) == 0
     res = np.load(out)

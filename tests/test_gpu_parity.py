@@ -216,6 +216,56 @@ def test_slab_engines_with_manual_exchange_equal_single_domain(lib, orc):
         e.close()
 
 
+@pytest.mark.parametrize("bc", ["periodic", "mirror"])
+def test_wide_halo_slab_engines_equal_single_domain(lib, orc, bc):
+    """PF_FLAG_WIDE_HALO: 4 ghost planes exchanged every SECOND step (step A: interior + two 4-plane strips, outputs
+    [-2, nz+2); step B: one launch, no exchange).  Three slab handles on the one GPU, ghost planes copied by hand only when
+    the library asks for them (pf_halo_layout.needs_exchange); 7 steps (both step kinds, odd count); bit-identical to the
+    whole-domain oracle (periodic ring) / to the even extension (mirror line), and to the 2-ghost path by transitivity."""
+    n = (128, 24, 18) if bc == "periodic" else (65, 13, 17)
+    rng = np.random.default_rng(31)
+    full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
+    engs = [HipSlabEngine(n, 1.0, 3, r, 0, bc=bc, wide=True) for r in range(3)]
+    assert all(e.ghost == 4 and e.buffers[0].shape[0] == e.nz + 8 for e in engs)
+    for e in engs:
+        e.set_local(full[e.z0:e.z0 + e.nz])
+
+    def exchange():
+        torch.cuda.synchronize()
+        pairs = ((0, 1), (1, 2), (2, 0)) if bc == "periodic" else ((0, 1), (1, 2))
+        for lo, hi in pairs:                               # `hi` sits above `lo`
+            el, eh = engs[lo], engs[hi]
+            bl, bh = el.buffers[el.cur], eh.buffers[eh.cur]
+            bl[el.nz + 4:el.nz + 8].copy_(bh[4:8])         # lo's upper ghosts <- hi's bottom 4 planes
+            bh[0:4].copy_(bl[el.nz:el.nz + 4])             # hi's lower ghosts <- lo's top 4 planes
+        torch.cuda.synchronize()
+
+    ref = orc.even_extend(full) if bc == "mirror" else full
+    exchanges = 0
+    for k in range(7):
+        need = [e.needs_exchange() for e in engs]
+        assert len(set(need)) == 1 and need[0] == (k % 2 == 0)
+        if need[0]:
+            exchange()
+            exchanges += 1
+        for e in engs:
+            e.step_begin(1e-3)
+        for e in engs:
+            e.step_finish()
+        ref = orc.fd_step(ref, 1e-3)
+    assert exchanges == 4
+    got = np.concatenate([e.get_local() for e in engs], 0)
+    np.testing.assert_array_equal(got, ref[:n[2], :n[1], :n[0]] if bc == "mirror" else ref)
+    exchange()
+    d = np.sum([e.diag_local() for e in engs], 0)
+    Fo, Co, _ = orc.diagnostics(ref, h=1.0, mirror=bc == "mirror")
+    assert abs(d[0] - Fo) <= 1e-13 * abs(Fo) and abs(d[1] - Co) <= 1e-13 * abs(Co)
+    for e in engs:
+        e.close()
+    with pytest.raises(Exception):                         # too few planes per rank for 4 ghost planes
+        HipSlabEngine((128, 24, 9), 1.0, 3, 0, 0, wide=True)
+
+
 def test_mirror_bc_line_of_slabs_equals_even_extension(lib, orc):
     """PF_BC_MIRROR in slab mode (b13d.py's no-flux box across GPUs): three slab handles on the one GPU in a LINE,
     inner ghost planes copied by hand, wall ghosts mirrored by the library; the result is bit for bit the whole-domain
@@ -958,7 +1008,8 @@ def test_nccl_path_single_rank(lib):
 
 @pytest.mark.parametrize("world,bc,mode", [(2, "periodic", "split"), (3, "periodic", "split"), (3, "mirror", "split"),
                                            (2, "periodic", "fused"), (3, "periodic", "fused"), (3, "mirror", "fused"),
-                                           (2, "periodic", "p2p"), (3, "mirror", "p2p")])
+                                           (2, "periodic", "p2p"), (3, "mirror", "p2p"),
+                                           (2, "periodic", "p2p_wide"), (3, "mirror", "p2p_wide")])
 def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, world, bc, mode, tmp_path):
     """2 and 3 ranks as separate processes sharing the GPU: HipSlabEngine + SlabSolver(transport="ipc") -- ghost planes
     pushed into the neighbour's buffer through CUDA IPC, flag-ordered (pfk_push_planes / pfk_wait_flag); must equal the
@@ -966,7 +1017,7 @@ def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, w
     mode "fused": one launch per step, the boundary-strip workgroups poll the arrival flags inside the kernel
     (pf_step_slab_fused).  mode "p2p": the DEFAULT exchange code (batch_isend_irecv of the GPU ghost planes, the path
     RCCL serves on a multi-GPU node) over gloo -- two ranks, so both neighbours are the same peer and the message
-    order matters."""
+    order matters.  mode "p2p_wide": the same with PF_FLAG_WIDE_HALO engines (4 ghost planes every second step)."""
     import os
     import socket
     import subprocess
