@@ -20,7 +20,7 @@ for p in ("p1", "p2", "p3"):
         v = v[len(v) // 3:]                      # skip the first third (pre-heat start)
         means[k] = sum(v) / len(v)
 cyc = means["GRBM_GUI_ACTIVE"] / 8.0
-short = kernel[kernel.index("ch_fd3d"):kernel.index("(")] if "(" in kernel else kernel
+short = kernel[kernel.index("ch_fd3d"):kernel.index("(", kernel.index("ch_fd3d"))] if "(" in kernel[kernel.index("ch_fd3d"):] else kernel
 d = {"round": 2, "workload": workload, "kernel": short, "per_launch_means": means, "derived": {
     "gpu_cycles_per_launch(GRBM_GUI_ACTIVE/8 XCDs)": cyc,
     "valu_utilisation = SQ_ACTIVE_INST_VALU*4 / (256 CUs * 4 SIMDs * cycles)": means["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc),
