@@ -8,6 +8,9 @@ What is copied is *data* (result CSVs, decoded point-data of VTU snapshots), nev
   results/bench1/conc00000{0..5}.vtu  PointData f_13-0     -> bm1_fields.npz  (c at the 20 201 mesh vertices)
   results/bench6/{conc,phi}00000{0..5}.vtu  f_3357-{0,2}   -> bm6_fields.npz  (c, phi)
   results/bench{1,6}/conc.pvd                              -> frame times inside the npz files
+  results/bench2_out.csv, results/bench3_out.csv      -> verbatim (BM2: ..., total_solute; BM3: ..., solid_fraction)
+  results/bench2/{conc,eta1..eta4}00000{0..3}.vtu          -> bm2_fields.npz  (c and the four order parameters, 4 frames)
+  results/bench3: only the .pvd index files are committed there (no field data to decode)
 
 VTU layout (VTK XML UnstructuredGrid): bench1 files are zlib-compressed base64 ("binary"), header
 UInt32 [nblocks, blocksize, last_blocksize, csize_1..csize_nblocks]; bench6 files are ASCII.
@@ -82,7 +85,7 @@ def pvd_times(path):
 
 def main():
     res = os.path.join(REF, "results")
-    for name in ("bench1_out.csv", "bench6_out.csv"):
+    for name in ("bench1_out.csv", "bench6_out.csv", "bench2_out.csv", "bench3_out.csv"):
         shutil.copyfile(os.path.join(res, name), os.path.join(OUT, name))
         os.chmod(os.path.join(OUT, name), 0o644)
 
@@ -116,6 +119,19 @@ def main():
         assert len(pd) == 1, pd
         ps.append(b[pd[0]].astype(np.float64))
     np.savez_compressed(os.path.join(OUT, "bm6_fields.npz"), times=t6[:6], c=np.stack(cs), phi=np.stack(ps))
+    # ---- BM2 fields: c, eta1..eta4 of the first 4 frames (the frame times are the CSV's rows 0..3)
+    t2 = pvd_times(os.path.join(res, "bench2", "conc.pvd"))
+    fields = {}
+    for stem, key in (("conc", "c"), ("eta1", "eta1"), ("eta2", "eta2"), ("eta3", "eta3"), ("eta4", "eta4")):
+        fr = []
+        for i in range(4):
+            a = read_vtu(os.path.join(res, "bench2", "%s%06d.vtu" % (stem, i)))
+            pd = [k for k in a if k.startswith("f_")]
+            assert len(pd) == 1, pd
+            fr.append(a[pd[0]].astype(np.float64))
+        fields[key] = np.stack(fr)
+        assert fields[key].shape == (4, 20201)
+    np.savez_compressed(os.path.join(OUT, "bm2_fields.npz"), times=t2[:4], **fields)
     print("wrote", sorted(os.listdir(OUT)))
 
 
