@@ -19,6 +19,7 @@ import numpy as np
 from .solver import PhaseFieldSolver, stable_dt
 
 L_BM1 = 200.0          # dolfin/bench1.py:21
+L_BM6 = 100.0          # dolfin/bench6.py:22
 
 
 def _march(s, times, dt):
@@ -33,26 +34,28 @@ def _march(s, times, dt):
     return np.array(out)
 
 
-def fem_be_energy(intervals, dt, times):
-    """the reference's algorithm at mesh size h = 200 / intervals with fixed BE steps"""
+def fem_be_energy(intervals, dt, times, model="bm1"):
+    """the reference's algorithm at mesh size h = L / intervals with fixed BE steps"""
     out, t = [], 0.0
-    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L_BM1 / intervals, bc="mirror", scheme="fem_be") as s:
-        s.set_ic_bm1(0.5, 0.05)
+    L = L_BM1 if model == "bm1" else L_BM6
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L / intervals, bc="mirror", scheme="fem_be", model=model) as s:
+        (s.set_ic_bm1 if model == "bm1" else s.set_ic_bm6)()
         for T in times:
             n = int(round((T - t) / dt))
             assert abs(n * dt - (T - t)) < 1e-9
             for _ in range(n):
                 ok, _, _ = s.step(dt, 1, check=True)
                 if not ok:
-                    raise RuntimeError("fem_be: Newton failed at t = %g (h = %g, dt = %g)" % (s.t, L_BM1 / intervals, dt))
+                    raise RuntimeError("fem_be: Newton failed at t = %g (h = %g, dt = %g)" % (s.t, L / intervals, dt))
             t = T
             out.append(s.diagnostics()[0])
     return np.array(out)
 
 
-def grid_energy(scheme, intervals, dt, times):
-    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L_BM1 / intervals, bc="mirror", scheme=scheme) as s:
-        s.set_ic_bm1(0.5, 0.05)
+def grid_energy(scheme, intervals, dt, times, model="bm1"):
+    L = L_BM1 if model == "bm1" else L_BM6
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L / intervals, bc="mirror", scheme=scheme, model=model) as s:
+        (s.set_ic_bm1 if model == "bm1" else s.set_ic_bm6)()
         return _march(s, times, dt)
 
 
@@ -64,13 +67,14 @@ def quad_extrapolate(f1, f2, f4):
     return f1 - bdt - b2dt2, b2dt2
 
 
-def fem_be_limit(times, dt=0.1, log=None):
+def fem_be_limit(times, dt=0.1, log=None, model="bm1"):
     """F*(t) of the reference's algorithm, (h, dt) -> (0, 0)"""
     runs = {}
+    L = L_BM1 if model == "bm1" else L_BM6
     for N, d in ((100, dt), (100, dt / 2), (100, dt / 4), (200, dt), (200, dt / 2)):
-        runs[(N, d)] = fem_be_energy(N, d, times)
+        runs[(N, d)] = fem_be_energy(N, d, times, model)
         if log:
-            log("fem_be h = %g dt = %g: %s" % (L_BM1 / N, d, np.array2string(runs[(N, d)], precision=6)))
+            log("fem_be %s h = %g dt = %g: %s" % (model, L / N, d, np.array2string(runs[(N, d)], precision=6)))
     g2, b2dt2 = quad_extrapolate(runs[(100, dt)], runs[(100, dt / 2)], runs[(100, dt / 4)])      # h = 2, dt -> 0
     # h = 1: remove the dt^2 term found at h = 2, then linear extrapolation in dt
     a, b = runs[(200, dt)] - b2dt2, runs[(200, dt / 2)] - b2dt2 / 4.0
@@ -101,3 +105,19 @@ def spectral_limit(times, intervals=256, dt=0.01, log=None):
             log("spectral N = %d dt = %g: %s" % (intervals, d, np.array2string(v, precision=6)))
     lim, _ = quad_extrapolate(*f)
     return lim, {"runs": f}
+
+
+def fd_limit_bm6(times, log=None):
+    """BM6 (CH + Poisson with the reference's Dirichlet / no-flux phi, explicit coupling): FD scheme, (h, dt) -> (0, 0).
+    h = 1, 0.5 on the 100 x 100 domain (bench6.py:22-24)."""
+    lim = {}
+    for N in (100, 200):
+        h = L_BM6 / N
+        d = stable_dt(h, dim=2, safety=0.4)
+        d = 0.1 / np.ceil(0.1 / d - 1e-9)
+        f1, f2 = grid_energy("fd", N, d, times, "bm6"), grid_energy("fd", N, d / 2, times, "bm6")
+        lim[N] = 2.0 * f2 - f1
+        if log:
+            log("fd bm6 h = %g dt = %.4g / half: %s / %s" % (h, d, np.array2string(f1, precision=6),
+                                                               np.array2string(f2, precision=6)))
+    return (4.0 * lim[200] - lim[100]) / 3.0, {"h1_dt0": lim[100], "h05_dt0": lim[200]}

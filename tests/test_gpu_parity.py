@@ -769,6 +769,20 @@ def test_schemes_converge_to_the_reference_algorithm(lib):
     assert (np.abs(raw - fem) <= 3e-4 * np.abs(fem)).all(), (raw, fem)
 
 
+def test_bm6_fd_scheme_converges_to_the_reference_algorithm(lib):
+    """The same pin for BM6's throughput scheme (explicit FD Cahn-Hilliard + FFT Poisson solve with the reference's
+    Dirichlet / no-flux phi, explicit coupling): GPU fem_be runs (monolithic c, mu, phi backward Euler = bench6.py,
+    reproduces results/bench6_out.csv to 5.6e-7) Richardson-extrapolated in dt (0.01 / 0.005 / 0.0025) and h (1 / 0.5)
+    against the FD scheme extrapolated in dt and h (1 / 0.5) at t = 0.1, 0.3.  Measured: 2.3e-9 and 2.4e-8 relative."""
+    from pfhubbenchmarks_amd import verification as V
+    ts = (0.1, 0.3)
+    fem, _ = V.fem_be_limit(ts, dt=0.01, model="bm6")
+    fd, _ = V.fd_limit_bm6(ts)
+    assert (np.abs(fd - fem) <= 1e-6 * np.abs(fem)).all(), (fd, fem)
+    # the energy moves by 1e-3 relative over this interval: the agreement is 4 orders finer than the signal
+    assert abs(fem[1] - fem[0]) > 5e-4 * fem[0]
+
+
 def test_drivers_save_solution_and_process_bench1(lib, golden_dir, tmp_path):
     """the drivers' per-step field dump (bench1.py:116-119,190-191) read back by the counterpart of
     dolfin/process_bench1.py:9-43 with stats.csv and re-emitted as a PVD series -- BE-parity mode (crossed mesh) and a
