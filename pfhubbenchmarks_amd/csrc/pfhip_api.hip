@@ -111,6 +111,7 @@ struct pf_handle {
   Spectral* sp = nullptr;
   Poisson* po = nullptr;   // BM6
   FemBE* fb = nullptr;     // PF_SCHEME_FEM_BE
+  MultiFD* mf = nullptr;   // PF_SCHEME_FD_EXPLICIT with PF_MODEL_BM2 / BM3
   SlabFFT* sf = nullptr;   // slab FFT modes (nranks > 1 spectral / BM6)
   bool own_phi = false;
   bool chat_valid = false; // slab spectral: resident spectrum consistent with c[cur]
@@ -491,8 +492,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   if (rc != PF_OK) return fail(nullptr, rc, err);
   const bool multi = cfg->model == PF_MODEL_BM2 || cfg->model == PF_MODEL_BM3;
   if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6 && !multi) return fail(nullptr, PF_ERR_INVALID, "bad model");
-  if (multi && cfg->scheme != PF_SCHEME_FEM_BE)
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3 run in the BE-parity mode (PF_SCHEME_FEM_BE) only");
+  if (multi && cfg->scheme != PF_SCHEME_FEM_BE && cfg->scheme != PF_SCHEME_FD_EXPLICIT)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3: PF_SCHEME_FEM_BE (parity mode) or PF_SCHEME_FD_EXPLICIT");
+  if (multi && cfg->scheme == PF_SCHEME_FD_EXPLICIT && (cfg->nranks != 1 || cfg->force_slab == 1))
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3 with the FD scheme: one GPU (replicas only)");
   if (cfg->scheme != PF_SCHEME_FD_EXPLICIT && cfg->scheme != PF_SCHEME_SPECTRAL_SI && cfg->scheme != PF_SCHEME_FEM_BE)
     return fail(nullptr, PF_ERR_INVALID, "bad scheme");
   if (cfg->scheme == PF_SCHEME_FEM_BE &&
@@ -581,6 +584,17 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     }
     if (frc != 0) return bail(PF_ERR_HIP);
     fembe_set_max_newton(h->fb, cfg->max_newton);
+  } else if (multi) {
+    double mp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (cfg->model == PF_MODEL_BM2) {
+      const double v[9] = {cfg->c_alpha, cfg->c_beta, cfg->rho_s, cfg->kappa, cfg->M, cfg->model_params[0],
+                           cfg->model_params[1], cfg->model_params[2], cfg->model_params[3]};
+      for (int i = 0; i < 9; ++i) mp[i] = v[i];
+    } else {
+      for (int i = 0; i < 4; ++i) mp[i] = cfg->model_params[i];
+    }
+    if (multifd_create(&h->mf, cfg->model == PF_MODEL_BM2 ? 2 : 3, g.nx, g.ny, g.nz, cfg->h, mp, h->stream, &h->err) != 0)
+      return bail(PF_ERR_HIP);
   } else if (cfg->model == PF_MODEL_BM6 && slab_fft) {
     if (cfg->ext_phi) {
       h->phi = cfg->ext_phi;
@@ -619,7 +633,9 @@ const char* pf_status_string(const pf_handle* h) {
   if (!h) return "";
   pf_handle* m = const_cast<pf_handle*>(h);
   const pf_config& c = h->cfg;
-  if (h->fb) {
+  if (h->mf) {
+    m->status = "fd: explicit multi-field scheme (BM2 / BM3), one thread per cell";
+  } else if (h->fb) {
     m->status = "fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction";
   } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
     m->status = "spectral: semi-implicit Fourier";
@@ -654,6 +670,7 @@ int pf_destroy(pf_handle* h) {
   if (h->sp) spectral_destroy(h->sp);
   if (h->po) poisson_destroy(h->po);
   if (h->fb) fembe_destroy(h->fb);
+  if (h->mf) multifd_destroy(h->mf);
   if (h->phi && h->own_phi) (void)hipFree(h->phi);
   if (h->sf) slabfft_destroy(h->sf);
   if (h->partials) (void)hipFree(h->partials);
@@ -667,6 +684,7 @@ int pf_destroy(pf_handle* h) {
 static int set_ic(pf_handle* h, double c0, double amp, double w0) {
   if (!h) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->mf) return fail(h, PF_ERR_STATE, "use pf_set_ic_bm2 / pf_set_ic_bm3 for this model");
   if (h->fb) {
     if (fembe_model(h->fb) != 0) return fail(h, PF_ERR_STATE, "use pf_set_ic_bm2 / pf_set_ic_bm3 for this model");
     if (fembe_set_ic(h->fb, c0, amp, w0) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
@@ -692,8 +710,72 @@ static int gen_field_index(const pf_handle* h, int field) {
   return -1;
 }
 
+// the multi-field FD path stores c, eta1..4 (BM2) or U, phi (BM3); mu exists only inside a step
+static int mfd_field_index(const pf_handle* h, int field) {
+  if (h->cfg.model == PF_MODEL_BM2) {
+    if (field == PF_FIELD_C) return 0;
+    if (field >= PF_FIELD_ETA1 && field < PF_FIELD_ETA1 + 4) return 1 + (field - PF_FIELD_ETA1);
+  } else if (h->cfg.model == PF_MODEL_BM3) {
+    if (field == PF_FIELD_U) return 0;
+    if (field == PF_FIELD_PHI) return 1;
+  }
+  return -1;
+}
+
+// host nodes of the physical domain <-> lattice field (even extension for the reference's no-flux boxes)
+static int lattice_put(pf_handle* h, double* dst, const double* host, size_t n) {
+  const Geometry& g = h->g;
+  if (!g.mirror) {
+    if ((int64_t)n != g.plane * g.nz) return fail(h, PF_ERR_INVALID, "wrong element count");
+    PF_HIP(h, hipMemcpyAsync(dst, host, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+  }
+  if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+    return fail(h, PF_ERR_INVALID, "wrong element count (mirror: nodes of the physical domain)");
+  std::vector<double> ext((size_t)(g.plane * g.nz));
+  auto refl = [](int i, int np) { return i < np ? i : 2 * (np - 1) - i; };
+  for (int z = 0; z < g.nz; ++z) {
+    const int zs = h->cfg.dim == 3 ? refl(z, g.np[2]) : 0;
+    for (int y = 0; y < g.ny; ++y) {
+      const double* src = host + ((int64_t)zs * g.np[1] + refl(y, g.np[1])) * g.np[0];
+      double* d = ext.data() + ((int64_t)z * g.ny + y) * g.nx;
+      for (int x = 0; x < g.nx; ++x) d[x] = src[refl(x, g.np[0])];
+    }
+  }
+  PF_HIP(h, hipMemcpyAsync(dst, ext.data(), sizeof(double) * ext.size(), hipMemcpyHostToDevice, h->stream));
+  PF_HIP(h, hipStreamSynchronize(h->stream));
+  return PF_OK;
+}
+
+static int lattice_get(pf_handle* h, const double* src, double* host, size_t n) {
+  const Geometry& g = h->g;
+  if (!g.mirror) {
+    if ((int64_t)n != g.plane * g.nz) return fail(h, PF_ERR_INVALID, "wrong element count");
+    PF_HIP(h, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    return PF_OK;
+  }
+  if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+    return fail(h, PF_ERR_INVALID, "wrong element count (mirror: nodes of the physical domain)");
+  std::vector<double> ext((size_t)(g.plane * g.nz));
+  PF_HIP(h, hipMemcpyAsync(ext.data(), src, sizeof(double) * ext.size(), hipMemcpyDeviceToHost, h->stream));
+  PF_HIP(h, hipStreamSynchronize(h->stream));
+  for (int z = 0; z < g.np[2]; ++z)
+    for (int y = 0; y < g.np[1]; ++y)
+      std::memcpy(host + ((int64_t)z * g.np[1] + y) * g.np[0], ext.data() + ((int64_t)z * g.ny + y) * g.nx,
+                  sizeof(double) * g.np[0]);
+  return PF_OK;
+}
+
 int pf_set_ic_bm2(pf_handle* h, double c0, double eps, double eps_eta, double psi) {
   if (!h) return PF_ERR_INVALID;
+  if (h->mf && h->cfg.model == PF_MODEL_BM2) {
+    const double a5[5] = {c0, eps, eps_eta, psi, 0.0};
+    if (multifd_set_ic(h->mf, h->g.mirror ? h->g.np[0] : 0, h->g.mirror ? h->g.np[1] : 0, a5) != 0)
+      return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+    return PF_OK;
+  }
   if (!h->fb || h->cfg.model != PF_MODEL_BM2) return fail(h, PF_ERR_STATE, "pf_set_ic_bm2: handle is not a BM2 model");
   const double icp[4] = {c0, eps, eps_eta, psi};
   if (fembe_set_ic_gen(h->fb, icp) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
@@ -702,6 +784,13 @@ int pf_set_ic_bm2(pf_handle* h, double c0, double eps, double eps_eta, double ps
 
 int pf_set_ic_bm3(pf_handle* h, double r, double w, double vin, double vout) {
   if (!h) return PF_ERR_INVALID;
+  if (h->mf && h->cfg.model == PF_MODEL_BM3) {
+    if (!(w > 0.0)) return fail(h, PF_ERR_INVALID, "pf_set_ic_bm3: need w > 0");
+    const double a5[5] = {h->cfg.model_params[3], r, w, vin, vout};
+    if (multifd_set_ic(h->mf, h->g.mirror ? h->g.np[0] : 0, h->g.mirror ? h->g.np[1] : 0, a5) != 0)
+      return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+    return PF_OK;
+  }
   if (!h->fb || h->cfg.model != PF_MODEL_BM3) return fail(h, PF_ERR_STATE, "pf_set_ic_bm3: handle is not a BM3 model");
   if (!(w > 0.0)) return fail(h, PF_ERR_INVALID, "pf_set_ic_bm3: need w > 0");
   const double icp[4] = {r, w, vin, vout};
@@ -714,6 +803,14 @@ int pf_set_ic_bm6(pf_handle* h, double c0, double c1) { return set_ic(h, c0, c1,
 
 int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
+  if (h->mf) {
+    const int f = mfd_field_index(h, field);
+    if (f < 0) return fail(h, PF_ERR_INVALID, "pf_set_field: not a stored field of this model (FD scheme: c, eta1..4 / U, phi)");
+    int rc = lattice_put(h, multifd_field_ptr(h->mf, f), host, n);
+    if (rc) return rc;
+    multifd_touch(h->mf);
+    return PF_OK;
+  }
   if (h->fb && fembe_model(h->fb) != 0) {  // BM2 / BM3: any field of the model
     const int f = gen_field_index(h, field);
     if (f < 0) return fail(h, PF_ERR_INVALID, "pf_set_field: not a field of this model");
@@ -757,6 +854,11 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
 
 int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
   if (!h || !host) return PF_ERR_INVALID;
+  if (h->mf) {
+    const int f = mfd_field_index(h, field);
+    if (f < 0) return fail(h, PF_ERR_INVALID, "pf_get_field: not a stored field of this model (FD scheme: c, eta1..4 / U, phi)");
+    return lattice_get(h, multifd_field_ptr(h->mf, f), host, n);
+  }
   if (h->fb && fembe_model(h->fb) != 0) {
     const int f = gen_field_index(h, field);
     if (f < 0) return fail(h, PF_ERR_INVALID, "pf_get_field: not a field of this model");
@@ -803,6 +905,21 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   if (!h) return PF_ERR_INVALID;
   if (nsteps < 0 || !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step: need dt > 0 and nsteps >= 0");
   if (h->g.ghost != 0) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
+  if (h->mf) {
+    if (multifd_step(h->mf, dt, nsteps) != 0) return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+    if (info) {  // blow-up guard: every field finite and inside a generous band
+      double raw[5];
+      if (multifd_diag_raw(h->mf, raw) != 0) return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+      info->cmin = raw[3];
+      info->cmax = raw[4];
+      // fmin / fmax skip NaNs, the sums do not: a NaN or an infinity anywhere shows up in raw[0..2]
+      const bool finite = std::isfinite(raw[0]) && std::isfinite(raw[1]) && std::isfinite(raw[2]);
+      info->ok = (finite && raw[3] > -10.0 && raw[4] < 10.0) ? 1 : 0;
+      info->nsteps = nsteps;
+      info->iters = 0;
+    }
+    return PF_OK;
+  }
   if (h->fb) {
     // one backward-Euler Newton solve per step; a failed solve leaves the state untouched and reports ok = 0
     int conv = 1, its = 0, done = 0;
@@ -853,6 +970,10 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
 int pf_rollback(pf_handle* h) {
   if (!h) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->mf) {
+    if (multifd_rollback(h->mf) != 0) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
+    return PF_OK;
+  }
   if (h->fb) {
     int r = fembe_rollback(h->fb);
     if (r == -4) return fail(h, PF_ERR_STATE, "pf_rollback: no previous state (call after pf_step)");
@@ -1120,6 +1241,25 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
 int pf_diagnostics_local(pf_handle* h, double out[3]) {
   if (!h || !out) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
+  if (h->mf) {
+    // out = {total free energy, BM2: total solute / BM3: solid fraction, 0}; discrete energy with forward differences,
+    // volume element h^d (x 2^-d on the even extension of a no-flux box)
+    double raw[5];
+    if (multifd_diag_raw(h->mf, raw) != 0) return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+    const pf_config& c = h->cfg;
+    double vol = 1.0;
+    for (int d = 0; d < c.dim; ++d) vol *= c.h * (h->g.mirror ? 0.5 : 1.0);
+    out[0] = vol * (raw[1] + 0.5 / (c.h * c.h) * raw[2]);
+    if (c.model == PF_MODEL_BM3) {
+      double dom = 1.0;
+      for (int d = 0; d < c.dim; ++d) dom *= c.h * (h->g.mirror ? (h->g.np[d] - 1) : h->g.np[d]);
+      out[1] = vol * raw[0] / dom;
+    } else {
+      out[1] = vol * raw[0];
+    }
+    out[2] = 0.0;
+    return PF_OK;
+  }
   if (h->fb) {
     if (fembe_diagnostics(h->fb, out) != 0) return fail(h, PF_ERR_HIP, fembe_error(h->fb));
     return PF_OK;

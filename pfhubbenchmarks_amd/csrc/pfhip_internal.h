@@ -141,4 +141,18 @@ void fembe_set_max_newton(FemBE* fb, int n);  // n <= 0: keep the default (10, b
 int fembe_diagnostics(FemBE* fb, double out[3]);
 const char* fembe_error(const FemBE* fb);
 
+// explicit finite-difference schemes of the multi-field benchmarks BM2 / BM3 (multi_fd.hip)
+struct MultiFD;
+int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, const double* mp, hipStream_t stream,
+                   std::string* err);
+void multifd_destroy(MultiFD* mf);
+int multifd_nfields(const MultiFD* mf);
+int multifd_set_ic(MultiFD* mf, int mnx, int mny, const double* a);
+double* multifd_field_ptr(MultiFD* mf, int f);  // device pointer of field f of the current time level (lattice, no ghosts)
+void multifd_touch(MultiFD* mf);                // a field was overwritten: no rollback state
+int multifd_step(MultiFD* mf, double dt, int nsteps);
+int multifd_rollback(MultiFD* mf);
+int multifd_diag_raw(MultiFD* mf, double raw[5]);
+const char* multifd_error(const MultiFD* mf);
+
 }  // namespace pfhip

@@ -288,8 +288,50 @@ def run_b13d(intervals=50, L=100.0, dt=None, end_time=50.0, out_dir="results", d
     return np.array(rows), spent
 
 
+def run_multi_fd(bench, end_time=None, out_dir="results", device=0, verbose=True, intervals=None, dt=None,
+                 max_rows=None):
+    """BM2 / BM3 with the explicit multi-field FD scheme (csrc/multi_fd.hip): rows at the accepted times of the reference's
+    committed run, each reached by sub-steps of a stable size (the throughput counterpart of the BE-parity default, as
+    `--scheme fd` is for bench1 / bench6)."""
+    from .verification import L_DOM, N_REF, multi_fd_dt
+    model = {"bench2": "bm2", "bench3": "bm3"}[bench]
+    N = intervals or (2 * N_REF[model] if model == "bm2" else N_REF[model])       # BM2: h = 1, BM3: the reference's h
+    L = L_DOM[model]
+    h = L / N
+    end_time = 100.0 if end_time is None else end_time
+    times = report_times(bench)
+    times = times[[i for i, t in enumerate(times) if i == 0 or times[i - 1] < end_time + 1e-12]]
+    if max_rows:
+        times = times[:max_rows]
+    dt = multi_fd_dt(model, h) if dt is None else dt
+    header = "time,total_free_energy," + ("total_solute" if model == "bm2" else "solid_fraction")
+    rows = []
+    t1 = time.time()
+    with PhaseFieldSolver(dim=2, n=N + 1, h=h, bc="mirror", scheme="fd", model=model, device=device) as s:
+        (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+        tprev = 0.0
+        for it, tn in enumerate(times):
+            n = max(1, int(np.ceil((float(tn) - tprev) / dt - 1e-12)))
+            ok, _, _ = s.step((float(tn) - tprev) / n, n, check=True)
+            if not ok:
+                raise RuntimeError("%s fd: the state left the guard band before t = %g (dt = %g)" % (bench, tn, dt))
+            tprev = float(tn)
+            F, C, _ = s.diagnostics()
+            rows.append([tprev, F, C])
+            if verbose:
+                print("Iteration #%d. Time: %g, second: %.10f, TFE: %.10f" % (it + 1, tn, C, F))
+    spent = time.time() - t1
+    print("Time spent is %s" % spent)
+    write_csv(os.path.join(out_dir, "%s_out.csv" % bench), rows, header)
+    return np.array(rows), spent
+
+
 def _main_multi(bench, desc, argv=None):
     ap = argparse.ArgumentParser(description=desc)
+    ap.add_argument("--scheme", default="fem_be", choices=["fem_be", "fd"],
+                    help="fem_be (default): the reference's own discretisation -- the CSV matches the reference's committed one; "
+                         "fd: explicit finite differences (the throughput scheme; its own discretisation error)")
+    ap.add_argument("--intervals", type=int, default=None, help="--scheme fd: grid intervals per side")
     ap.add_argument("--controller", default="fixture", choices=["fixture", "reference"],
                     help="fixture: the committed run's time grid; reference: the script's own dt rule")
     ap.add_argument("--end-time", type=float, default=None)
@@ -298,6 +340,9 @@ def _main_multi(bench, desc, argv=None):
     ap.add_argument("--save-solution", action="store_true")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
+    if a.scheme == "fd":
+        run_multi_fd(bench, a.end_time, a.out_dir, 0, not a.quiet, a.intervals, None, a.max_rows)
+        return
     run_fem_be(bench, a.controller, a.end_time, a.out_dir, 0, not a.quiet, a.max_rows, a.save_solution)
 
 

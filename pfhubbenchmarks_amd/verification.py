@@ -121,3 +121,67 @@ def fd_limit_bm6(times, log=None):
             log("fd bm6 h = %g dt = %.4g / half: %s / %s" % (h, d, np.array2string(f1, precision=6),
                                                                np.array2string(f2, precision=6)))
     return (4.0 * lim[200] - lim[100]) / 3.0, {"h1_dt0": lim[100], "h05_dt0": lim[200]}
+
+
+# ---- BM2 / BM3 (round 2): the explicit multi-field FD schemes against the reference's algorithm ----------------------
+L_DOM = {"bm2": 200.0, "bm3": 960.0}          # bench2.py:21, bench3.py:21
+N_REF = {"bm2": 100, "bm3": 350}              # bench2.py:22, bench3.py:22
+
+
+def multi_fd_dt(model, h, safety=0.4):
+    """forward-Euler limits: BM2 is bound by its Cahn-Hilliard part (M kappa_c lap_h^2), BM3 by the heat equation (D lap_h)"""
+    if model == "bm2":
+        return stable_dt(h, M=5.0, kappa=3.0, dim=2, safety=safety)
+    return safety * h * h / (4.0 * 10.0)
+
+
+def multi_energy(model, scheme, intervals, dt, times, max_newton=100):
+    """F(t) and the second CSV column at the report times, fixed steps (all times multiples of dt)"""
+    L = L_DOM[model]
+    kw = dict(max_newton=max_newton) if scheme == "fem_be" else {}
+    out, t = [], 0.0
+    with PhaseFieldSolver(dim=2, n=intervals + 1, h=L / intervals, bc="mirror", scheme=scheme, model=model, **kw) as s:
+        (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+        for T in times:
+            n = int(round((T - t) / dt))
+            assert abs(n * dt - (T - t)) < 1e-9 * max(1.0, T), (T, t, dt)
+            if scheme == "fem_be":
+                for _ in range(n):
+                    ok, _, _ = s.step(dt, 1, check=True)
+                    if not ok:
+                        raise RuntimeError("%s fem_be: Newton failed at t = %g (dt = %g)" % (model, s.t, dt))
+            else:
+                ok, _, _ = s.step(dt, n, check=True)
+                if not ok:
+                    raise RuntimeError("%s fd: blow-up before t = %g (dt = %g)" % (model, T, dt))
+            t = T
+            out.append(s.diagnostics()[:2])
+    return np.array(out)          # (ntimes, 2)
+
+
+def multi_fd_limit(model, times, intervals=None, log=None):
+    """explicit FD, (h, dt) -> (0, 0): first order in dt, second order in h; intervals = (coarse, fine = 2 coarse)"""
+    n0 = intervals or (2 * N_REF[model] if model == "bm2" else N_REF[model])
+    lim = {}
+    for N in (n0, 2 * n0):
+        h = L_DOM[model] / N
+        d = multi_fd_dt(model, h)
+        d = min(times) / np.ceil(min(times) / d - 1e-9)
+        f1 = multi_energy(model, "fd", N, d, times)
+        f2 = multi_energy(model, "fd", N, d / 2, times)
+        lim[N] = 2.0 * f2 - f1
+        if log:
+            log("%s fd h = %g dt = %.4g / half: F %s / %s" % (model, h, d, np.array2string(f1[:, 0], precision=6),
+                                                              np.array2string(f2[:, 0], precision=6)))
+    return (4.0 * lim[2 * n0] - lim[n0]) / 3.0, lim
+
+
+def multi_fem_dt_limit(model, times, dt, intervals=None, log=None):
+    """the reference's algorithm at its own mesh (h fixed), dt -> 0 by quadratic extrapolation over dt, dt/2, dt/4"""
+    N = intervals or N_REF[model]
+    f = [multi_energy(model, "fem_be", N, d, times) for d in (dt, dt / 2, dt / 4)]
+    if log:
+        for d, v in zip((dt, dt / 2, dt / 4), f):
+            log("%s fem_be h = %g dt = %g: F %s" % (model, L_DOM[model] / N, d, np.array2string(v[:, 0], precision=6)))
+    lim, _ = quad_extrapolate(*f)
+    return lim, f
