@@ -7,7 +7,9 @@ A "step" is one explicit FD Cahn-Hilliard update of the whole grid (the fused HI
 pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
   bm1_fd_512c   (default, BASELINE.json config 3)  512^3 per GPU, fp64, BM1 initial condition extruded in z;
                 N > 1: each rank owns a 512 x 512 x 512 slab of a 512 x 512 x (512 N) periodic box (weak scaling),
-                ghost planes exchanged over RCCL (torch.distributed "nccl") overlapped with the interior kernel.
+                ghost planes exchanged over RCCL (torch.distributed "nccl") overlapped with the interior kernel; default
+                --halo wide = PF_FLAG_WIDE_HALO: 4 ghost planes every second step (5.7 % instead of 11.8 % slab-path overhead
+                on one GPU, bit-identical; --halo narrow = 2 ghost planes every step).
   bm1_fd_1024c  1024^3 on 1 GPU, or 1024 x 1024 x (1024/N) slabs on N GPUs (BASELINE.json config 4, strong)
   bm1_fd_512s   512^2 2-D (launch-latency bound; reported for completeness)
   bm1_spectral_512s / _256c / _512c   semi-implicit spectral scheme (BASELINE.json config 2); _512c also runs on N > 1
@@ -23,7 +25,8 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
 Why config 3 and not config 2 is the default: BASELINE.json's metric is "cell-updates/s at 512^2 and 512^3, 1/2/4/8
 GPUs" and its roofline target is the fused stencil.  Config 2 (512^2 spectral) is a 14 us, launch-latency-bound step
 that does not shard (replicas only, DESIGN.md section 4), so the N = 1, 2, 4, 8 series is run on the 512^3 stencil;
-the same default run also times both 512^2 workloads and reports them under "also" in the same JSON line.
+the same default run also times both 512^2 workloads, the 1024^3 stencil (north_star's roofline target) and the
+BE-parity mode with its CPU restatement, and reports them under "also" in the same JSON line.
 Timed region (DESIGN.md section 6 "power transient"): the chip answers an HBM-heavy load that starts from
 idle (>= 3-10 ms without work) by dropping its shader clock from 2.4 to ~1.7 GHz for ~25 ms (tools/ramp_probe.py,
 profiles/r02/ramp_probe_512.log), which a 20-step / 9 ms timed region sits entirely inside.  So the run first does a
