@@ -330,7 +330,7 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
             solver = FFTSlabSolver(eng)
         else:
-            wide = a.halo == "wide" and a.transport == "rccl" and eng_planes(gn[2], world, rank) >= 4
+            wide = a.halo == "wide" and not a.fused_slab and eng_planes(gn[2], world, rank) >= 4
             eng = HipSlabEngine(gn, h, world, rank, local_rank, wide=wide)
             eng.set_ic_bm1(0.5, 0.05)
             solver = SlabSolver(eng, transport=a.transport, fused=a.fused_slab)

@@ -314,6 +314,9 @@ int pfk_stream_copy(const double* src, double* dst, int64_t n, void* stream);
 int pfk_push_planes(const double* src, double* dst, int64_t n, int64_t* flag, int64_t seq, uint32_t* ticket,
                     void* stream);
 int pfk_wait_flag(const int64_t* flag, int64_t seq, int32_t* timeout, void* stream);
+/* stream-ordered *flag = seq with system-scope release (flag may be a peer-mapped IPC pointer): the consumer's
+ * acknowledgement "I have read the ghost planes of exchange seq", which a sender waits for before it overwrites them */
+int pfk_signal_flag(int64_t* flag, int64_t seq, void* stream);
 
 /* Flag words of the peer-copy transport.  A flag is polled by a RUNNING kernel on its home GPU while a PEER GPU writes it
  * (pfk_push_planes), so it must not live in ordinary (coarse-grained) device memory, whose lines the home GPU's L2 may

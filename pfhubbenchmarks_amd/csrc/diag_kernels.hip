@@ -429,6 +429,11 @@ __global__ void wait_flag_kernel(const long long* flag, long long seq, int* time
   __hip_atomic_store(timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// signal: *flag = seq with system-scope release, stream-ordered behind the kernels that read what the peer may overwrite next
+__global__ void signal_flag_kernel(long long* flag, long long seq) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // one 16-byte element per thread, one short-lived workgroup per 4 KB: the dispatcher walks the buffer in address order
 __global__ __launch_bounds__(256) void stream_copy_flat_kernel(const double2* __restrict__ src,
                                                                double2* __restrict__ dst, int64_t n2) {
@@ -463,6 +468,11 @@ hipError_t launch_push_planes(const double* src, double* dst, int64_t n, long lo
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(push_planes_kernel, dim3((int)nb), dim3(256), 0, stream, reinterpret_cast<const double2*>(src),
                      reinterpret_cast<double2*>(dst), n2, flag, seq, ticket);
+  return hipGetLastError();
+}
+
+hipError_t launch_signal_flag(long long* flag, long long seq, hipStream_t stream) {
+  hipLaunchKernelGGL(signal_flag_kernel, dim3(1), dim3(64), 0, stream, flag, seq);
   return hipGetLastError();
 }
 

@@ -55,6 +55,7 @@ void set_copy_tuning(int wgs_per_cu, int mode);  // <= 0 / < 0: keep
 hipError_t launch_push_planes(const double* src, double* dst, int64_t n, long long* flag, long long seq,
                               unsigned* ticket, hipStream_t stream);
 void set_push_wgs(int n);
+hipError_t launch_signal_flag(long long* flag, long long seq, hipStream_t stream);
 hipError_t launch_wait_flag(const long long* flag, long long seq, int* timeout, hipStream_t stream);
 hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* ms_per_barrier, int* ok);
 hipError_t launch_clock_probe(double* out, int nblocks, int spin_us, int busy, hipStream_t stream);

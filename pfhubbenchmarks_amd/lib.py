@@ -111,6 +111,7 @@ SYMBOLS = {
     "pfk_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pfk_grid_barrier_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
     "pfk_push_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pfk_signal_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "pfk_wait_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 

@@ -385,9 +385,11 @@ class IpcHaloTransport:
         self.torch, self.e, self._lib = torch, engine, _lib.load()
         dev = engine.buffers[0].device
         fl, to = C.c_void_p(), C.c_void_p()
-        _lib.check(self._lib.pfk_flags_alloc(2, C.byref(fl), C.byref(to)))
+        _lib.check(self._lib.pfk_flags_alloc(4, C.byref(fl), C.byref(to)))
         self._flags_ptr, self._timeout_ptr = fl.value, to.value
-        self.flags = _Words(fl.value)        # [0]: written by the lo neighbour, [1]: by the hi neighbour
+        # words [0] / [1]: arrival flags written by the lo / hi neighbour's push; words [2] / [3]: acknowledgements written
+        # by the lo / hi neighbour once ITS step has read the ghost planes I pushed (I wait for them before pushing again)
+        self.flags = _Words(fl.value)
         self.timeout = _Words(to.value)      # mapped host int32: device address == host address (HIP unified addressing)
         self.tickets = torch.zeros(2, dtype=torch.int32, device=dev)
         self.side = torch.cuda.Stream(device=dev)
@@ -431,6 +433,8 @@ class IpcHaloTransport:
         """push my boundary planes of the CURRENT buffer into the neighbours' ghost planes (side stream); returns
         the handle whose wait() makes the current stream wait for the neighbours' pushes of the same exchange"""
         torch, e, lib = self.torch, self.e, self._lib
+        if self.seq > 0:
+            self.ack()        # every reader of the planes received in exchange `seq` is already enqueued on this stream
         self.seq += 1
         g, nz, P, cur = e.ghost, e.nz, self.plane, e.cur
         buf = e.buffers[cur]
@@ -438,6 +442,14 @@ class IpcHaloTransport:
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
         sp = C.c_void_p(self.side.cuda_stream)
+        # write-after-read: the neighbour must have consumed the planes of my previous push before I overwrite them.  With 2
+        # ghost planes every step the dependency chain already guarantees it; with the wide halo (the same buffer receives
+        # every exchange) it does not.  So every rank acknowledges exchange seq - 1 on its compute stream when it posts
+        # exchange seq (all readers of those planes are enqueued before that point), and every push waits for it
+        for i, nb in ((2, self.lo), (3, self.hi)):
+            if nb is not None and self.seq > 1:
+                _lib.check(lib.pfk_wait_flag(C.c_void_p(self.flags.data_ptr() + 8 * i), self.seq - 1,
+                                             C.c_void_p(self.timeout.data_ptr()), sp))
         if self.lo is not None:       # my lowest owned planes -> the lo neighbour's upper ghost planes, its flag [1]
             blk, flags, o1, pnz = self.lo
             dst = blk.data_ptr() + 8 * (cur * o1 + (pnz + g) * P)
@@ -450,14 +462,29 @@ class IpcHaloTransport:
             _lib.check(lib.pfk_push_planes(C.c_void_p(buf[nz:nz + g].data_ptr()), C.c_void_p(dst), g * P,
                                            C.c_void_p(flags.data_ptr()), self.seq,
                                            C.c_void_p(self.tickets.data_ptr() + 4), sp))
+        # my pushes READ my boundary planes: the launch that overwrites them next must not start before they are done.
+        # (2 ghost planes: the neighbours' flag chain already implies it; wide halo: step B rewrites the whole buffer
+        # without any dependency on my own pushes -- so wait() makes the compute stream wait for this event too)
+        self._push_done = torch.cuda.Event()
+        self._push_done.record(self.side)
         return [self]
 
     def wait(self):
+        self.torch.cuda.current_stream().wait_event(self._push_done)
         st = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
         for i, nb in ((0, self.lo), (1, self.hi)):
             if nb is not None:
                 _lib.check(self._lib.pfk_wait_flag(C.c_void_p(self.flags.data_ptr() + 8 * i), self.seq,
                                                    C.c_void_p(self.timeout.data_ptr()), st))
+
+    def ack(self):
+        """current stream: tell both neighbours that the kernels enqueued so far have read the ghost planes of exchange
+        self.seq (stream-ordered behind them)"""
+        st = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        if self.lo is not None:       # I am the lo neighbour's HI neighbour: its word [3]
+            _lib.check(self._lib.pfk_signal_flag(C.c_void_p(self.lo[1].data_ptr() + 24), self.seq, st))
+        if self.hi is not None:       # I am the hi neighbour's LO neighbour: its word [2]
+            _lib.check(self._lib.pfk_signal_flag(C.c_void_p(self.hi[1].data_ptr() + 16), self.seq, st))
 
     def check(self):
         """raise if a bounded wait gave up (a neighbour never published its planes: the step then ran on stale ghost
@@ -486,13 +513,13 @@ class SlabSolver:
         self.t = 0.0
         # "rccl": torch.distributed isend / irecv (any backend, incl. gloo in the CPU tests);
         # "ipc":  peer-mapped ghost planes written by a side-stream kernel (one node, IpcHaloTransport)
-        if transport == "ipc" and getattr(engine, "wide", False):
-            raise ValueError("the peer-copy transport works on 2 ghost planes; use transport='rccl' with a wide-halo engine")
         self.transport = IpcHaloTransport(engine, group) if transport == "ipc" else None
         # fused: one launch per step -- the boundary-strip workgroups wait for the neighbours' flags inside the kernel
         # (pf_step_slab_fused); needs the flag words of the peer-copy transport
         if fused and self.transport is None:
             raise ValueError("SlabSolver(fused=True) needs transport='ipc'")
+        if fused and getattr(engine, "wide", False):
+            raise ValueError("SlabSolver(fused=True) works on 2 ghost planes; the wide halo uses the two-launch step")
         self.fused = bool(fused)
 
     def _host_ordered(self):
@@ -535,15 +562,15 @@ class SlabSolver:
 
     def step(self, dt, nsteps=1):
         e = self.engine
+        need = getattr(e, "needs_exchange", None)
         for _ in range(nsteps if self.fused else 0):
             tr = self.transport
             with e.stream_context():
-                if not self.ghosts_fresh:
+                if not self.ghosts_fresh and (need is None or need()):
                     tr.post()                 # fresh ghosts: the flags already hold tr.seq, the strips will not wait
                 e.step_fused(dt, tr.flags, tr.seq, tr.timeout)
             self.ghosts_fresh = False
             self.t += dt
-        need = getattr(e, "needs_exchange", None)
         for _ in range(0 if self.fused else nsteps):
             with e.stream_context():
                 # wide-halo engines read their ghost planes every second step only (PF_FLAG_WIDE_HALO)

@@ -24,12 +24,12 @@ def main():
     rng = np.random.default_rng(41)
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
     mode = sys.argv[3] if len(sys.argv) > 3 else "split"
-    eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc, wide=mode == "p2p_wide")
+    eng = HipSlabEngine(n, 1.0, world, rank, 0, bc=bc, wide=mode.endswith("_wide"))
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])
     if mode in ("p2p", "p2p_wide"):             # torch.distributed isend / irecv of the GPU ghost planes (gloo stages them on the host)
         s = SlabSolver(eng, transport="rccl")
     else:
-        s = SlabSolver(eng, transport="ipc", fused=mode == "fused")
+        s = SlabSolver(eng, transport="ipc", fused=mode.startswith("fused"))
     d0 = s.diagnostics()
     s.step(1e-3, 25)
     d1 = s.diagnostics()

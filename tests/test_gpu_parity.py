@@ -1155,7 +1155,8 @@ def test_nccl_path_single_rank(lib):
 @pytest.mark.parametrize("world,bc,mode", [(2, "periodic", "split"), (3, "periodic", "split"), (3, "mirror", "split"),
                                            (2, "periodic", "fused"), (3, "periodic", "fused"), (3, "mirror", "fused"),
                                            (2, "periodic", "p2p"), (3, "mirror", "p2p"),
-                                           (2, "periodic", "p2p_wide"), (3, "mirror", "p2p_wide")])
+                                           (2, "periodic", "p2p_wide"), (3, "mirror", "p2p_wide"),
+                                           (3, "periodic", "split_wide"), (3, "mirror", "split_wide")])
 def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, world, bc, mode, tmp_path):
     """2 and 3 ranks as separate processes sharing the GPU: HipSlabEngine + SlabSolver(transport="ipc") -- ghost planes
     pushed into the neighbour's buffer through CUDA IPC, flag-ordered (pfk_push_planes / pfk_wait_flag); must equal the
