@@ -186,7 +186,7 @@ def main():
                     help="FD slab path (N > 1 or --slab): 'wide' = PF_FLAG_WIDE_HALO, 4 ghost planes exchanged every second "
                          "step (half the hand-offs, 8 instead of 12 redundant plane reads per step); 'narrow' = 2 ghost "
                          "planes every step.  Bit-identical results.")
-    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c",
+    ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c", "bm1_spectral_1024c",
                              "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
@@ -281,6 +281,10 @@ def workload_table(workload, world):
             sys.exit("bm6_spectral_512c is single-GPU")
     elif workload == "bm1_spectral_512c":
         w.update(scheme="spectral", bytes_per_cell=72.0, gn=(512, 512, 512 * world), dt=1e-2)
+    elif workload == "bm1_spectral_1024c":
+        w.update(scheme="spectral", bytes_per_cell=72.0, gn=(1024, 1024, 1024), dt=1e-2)
+        if world > 1:
+            sys.exit("bm1_spectral_1024c is single-GPU")
     elif workload in ("bm1_spectral_512s", "bm1_spectral_256c"):
         # BASELINE.json config 2: semi-implicit spectral; 72 B/cell-update = one-pass-per-transform idealisation
         # (f' 16 + r2c 16 + k-space 24 + c2r 16) -- 512^2 is launch-latency bound, not HBM bound
@@ -425,8 +429,8 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
     out = {
         "metric": "cell-updates/sec on PFHub %s (%s)" % (
             "BM1 Cahn-Hilliard" if model == "bm1" else "BM6 Cahn-Hilliard + Poisson",
-            ("explicit FD, fused HIP stencil" + (" + rocFFT Poisson" if model == "bm6" else "")) if scheme == "fd"
-            else "semi-implicit spectral; rocFFT + HIP k-space kernels, fused LDS-FFT kernels for 2-D power-of-two grids"),
+            ("explicit FD, fused HIP stencil" + (" + FFT Poisson" if model == "bm6" else "")) if scheme == "fd"
+            else "semi-implicit spectral; hand-written LDS-FFT passes on power-of-two grids 128..1024, rocFFT + HIP k-space kernels otherwise"),
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",

@@ -59,11 +59,11 @@ __device__ __forceinline__ int xcd_band_block() {
 // in-place radix-2 DIT FFT of x[0..N) (LDS, bit-reversed input -> natural output) by ONE wave; tw[k] = e^{-2 pi i k/N}.
 // SIGN = -1: forward (e^{-i...}); +1: inverse (unnormalised).  Every stage ends with a workgroup barrier (the waves of
 // a workgroup run independent transforms in lockstep).
-template <int SIGN, int G>  // G = threads cooperating on one transform (t = index inside the group)
+template <int SIGN, int G, int NMAX = 1024>  // G = threads cooperating on one transform (t = index inside the group)
 __device__ __forceinline__ void fft_inplace(double2* x, const double2* tw, int N, int lgN, int t) {
   // Radix-2 DIT stages merged two at a time (stages s and s+1 on the 4 elements j, j+h, j+2h, j+3h, h = 2^(s-1)):
   // half the LDS round trips and barriers of a plain radix-2 sweep, same data order.  A last single stage if lgN is odd.
-  constexpr int MAXQ4 = 256 / G > 0 ? 256 / G : 1;  // 4-element groups per thread: (N/4) / G, N <= 1024
+  constexpr int MAXQ4 = NMAX / 4 / G > 0 ? NMAX / 4 / G : 1;  // 4-element groups per thread: (N/4) / G, N <= NMAX
   auto cmul = [](double2 w, double2 v) { return make_double2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x); };
   int s = 1;
   for (; s + 1 <= lgN; s += 2) {
@@ -112,7 +112,7 @@ __device__ __forceinline__ void fft_inplace(double2* x, const double2* tw, int N
     __syncthreads();
   }
   if (s == lgN) {  // odd number of stages: one plain radix-2 stage
-    constexpr int MAXB = 512 / G > 0 ? 512 / G : 1;
+    constexpr int MAXB = NMAX / 2 / G > 0 ? NMAX / 2 / G : 1;
     const int half = 1 << (s - 1);
     const int tstep = N >> s;
     double2 w[MAXB], u[MAXB], v[MAXB];
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double
         c_out[(int64_t)y1 * N + x] = z[i].y;
       }
     }
+    if (from_spectrum == 2) return;  // inverse only (Poisson solve)
     __syncthreads();
   } else {
 #pragma unroll
@@ -639,14 +640,14 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
     }
     __syncthreads();
     if (MODE == 4) {
-      // Poisson solve, z pass: multiply by 1 / eigenvalue of the 7-point Laplacian (tables sym[0..512) per axis hold
-      // 2 cos(2 pi m / n) - 2; `chat` carries the three tables back to back), zero mode -> 0; then inverse z in place
+      // Poisson solve, z pass: multiply by 1 / eigenvalue of the 7-point Laplacian (tables of 2 cos(2 pi m / n) - 2 for the
+      // x, y and z axis back to back, carried in `chat`), zero mode -> 0; then inverse z in place
       const double* sym = reinterpret_cast<const double*>(chat);
-      const double cxy = sym[kx < a.nxh ? kx : 0] + sym[N + b];
+      const double cxy = sym[kx < a.nxh ? kx : 0] + sym[a.nx + b];
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int kz = (tid + NT * i) / CW3;
-        const double lam = (cxy + sym[2 * N + kz]) * a.dtM;          // dtM = 1 / h^2 here
+        const double lam = (cxy + sym[a.nx + a.ny + kz]) * a.dtM;    // dtM = 1 / h^2 here
         const double sc = (kx == 0 && b == 0 && kz == 0) ? 0.0 : (a.inv_n / lam) * a.dtMkappa;  // dtMkappa = -k / eps
         const double2 gh = Lc[nat(kz)];
         Lc[nat(kz)] = make_double2(gh.x * sc, gh.y * sc);
@@ -707,6 +708,103 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
   }
 }
 
+// Column passes for the other power-of-two axis lengths (128, 256, 1024): the multi-stage radix-2^2 LDS transform of the
+// 2-D path (fft_inplace), G threads per column (one radix-4 group each: 64 up to 256 points, 256 for 1024 -- sized so
+// that the kernels stay under 64 VGPRs and fill the CU: the first form, one wave per 1024-capable column, needed 162-178
+// VGPRs), CWG adjacent k_x columns per workgroup moved with the column index fastest.  Same MODEs as f3_col512_kernel.
+template <int MODE, int CWG, int G, int NMAX>  // G threads per column, axis length N <= NMAX
+__global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, double2* __restrict__ A,
+                                                          double2* __restrict__ chat, double2* __restrict__ H,
+                                                          int64_t col_stride, int64_t batch_stride, int nblk, int nitems,
+                                                          int N, int lg, const double2* __restrict__ tw_g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int NP = px(N) + 1;
+  double2* X = reinterpret_cast<double2*>(smem_raw);  // [CWG][NP]
+  double2* TW = X + CWG * NP;
+  constexpr int NT = G * CWG, MAXP = NMAX / G;  // N / G elements per thread
+  const int tid = threadIdx.x, lane = tid % G, wave = tid / G, ci = tid % CWG;
+  int lb = blockIdx.x;
+  if (CWG == 4) {  // two items per 128-byte line: hand the halves to workgroups that land on the same XCD (i, i + 8)
+    const int grp = lb >> 4, r = lb & 15;
+    if ((grp << 4) + 16 <= nitems) lb = (grp << 4) + ((r & 7) << 1) + (r >> 3);
+  }
+  const int b = lb / nblk, kx = (lb % nblk) * CWG + ci;
+  const bool on = kx < a.nxh;
+  const int64_t base = (int64_t)b * batch_stride + kx;
+  for (int k = tid; k < N / 2; k += NT) TW[k] = tw_g[k];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int r = (tid + NT * i) / CWG;
+    if (r < N) X[ci * NP + px(brev(r, lg))] = on ? A[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  if (MODE == 1)
+    fft_inplace<+1, G, NMAX>(X + wave * NP, TW, N, lg, lane);
+  else
+    fft_inplace<-1, G, NMAX>(X + wave * NP, TW, N, lg, lane);
+  if (MODE == 0 || MODE == 1 || MODE == 3) {
+    double2* dst = MODE == 3 ? chat : A;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int r = (tid + NT * i) / CWG;
+      if (r < N && on) dst[base + (int64_t)r * col_stride] = X[ci * NP + px(r)];
+    }
+    return;
+  }
+  double2 o[MAXP];
+  if (MODE == 2) {  // z pass: b is the y index, the row along the column is k_z
+    const int my = 2 * b > a.ny ? b - a.ny : b;
+    const double kxv = a.kx0 * kx, kyv = a.ky0 * my;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int kz = (tid + NT * i) / CWG;
+      if (kz < N) {
+        const int mz = 2 * kz > N ? kz - N : kz;
+        const double kzv = a.kz0 * mz;
+        const double k2 = (kxv * kxv + kyv * kyv) + kzv * kzv;  // same grouping as spectral.hip's ksq
+        const double num = a.dtM * k2;
+        const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
+        const double2 gh = X[ci * NP + px(kz)];
+        const double2 ch = on ? chat[base + (int64_t)kz * col_stride] : make_double2(0.0, 0.0);
+        double2 r;
+        r.x = fma(-num, gh.x, ch.x) * den;
+        r.y = fma(-num, gh.y, ch.y) * den;
+        if (on) chat[base + (int64_t)kz * col_stride] = r;
+        o[i] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
+      }
+    }
+  } else {  // MODE 4: Poisson solve, divide by the eigenvalue of the 7-point Laplacian (see f3_col512_kernel)
+    const double* sym = reinterpret_cast<const double*>(chat);
+    const double cxy = sym[on ? kx : 0] + sym[a.nx + b];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int kz = (tid + NT * i) / CWG;
+      if (kz < N) {
+        const double lam = (cxy + sym[a.nx + a.ny + kz]) * a.dtM;
+        const double sc = (kx == 0 && b == 0 && kz == 0) ? 0.0 : (a.inv_n / lam) * a.dtMkappa;
+        const double2 gh = X[ci * NP + px(kz)];
+        o[i] = make_double2(gh.x * sc, gh.y * sc);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int r = (tid + NT * i) / CWG;
+    if (r < N) X[ci * NP + px(brev(r, lg))] = o[i];
+  }
+  __syncthreads();
+  fft_inplace<+1, G, NMAX>(X + wave * NP, TW, N, lg, lane);
+  double2* dst = MODE == 2 ? H : A;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int r = (tid + NT * i) / CWG;
+    if (r < N && on) dst[base + (int64_t)r * col_stride] = X[ci * NP + px(r)];
+  }
+}
+
+int g_generic512 = 0;  // PFHIP_FFT3D_GENERIC512 = 1: 512-point columns by f3_col_kernel too (A/B against the radix-8 wave kernel)
+int g_cwg = 0;  // columns per workgroup of f3_col_kernel on 128- / 256-point axes: 0 = 8; PFHIP_FFT3D_CWG = 4 | 8
 int g_zearly = 0;  // z pass: request the resident spectrum before the forward FFT (PFHIP_FFT3D_ZEARLY = 0 | 1)
 int g_cw3 = 0;  // k_x columns per workgroup of the 3-D column passes: 0 = per pass (z: 4, y: 8), PFHIP_FFT3D_CW = 4 | 8 forces one
 int g_cw512 = 1;  // columns per workgroup of the 2-D column kernel (PFHIP_FFT512_CW = 1 | 2 | 4): 13.05 / 14.3 / 17.5 us
@@ -725,7 +823,10 @@ struct Fused2D {
   double2 *tw8a = nullptr, *tw8b = nullptr;  // radix-8 tables of the 512-point fast path
   bool row512 = false, col512 = false;
   double* sym = nullptr;  // 512^3 Poisson: 3 x 512 doubles, 2 cos(2 pi m / n) - 2 per axis
-  bool cube512 = false;  // 3-D 512^3: x rows by f2_row512_kernel, y / z columns by f3_col512_kernel
+  bool cube512 = false;  // 3-D box: x rows by f2_row512_kernel / f2_row_kernel, y and z columns by f3_col512_kernel (512-point
+                         // axes) / f3_col_kernel (128, 256, 1024)
+  double2* twz = nullptr;
+  int lgz = 0;
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
   bool g_valid = false;  // G holds the row transform of f'(current c)
@@ -734,7 +835,12 @@ struct Fused2D {
 bool fused2d_supported(int dim, int nx, int ny, int nz) {
   if (dim == 3) {
     const char* e = getenv("PFHIP_SPECTRAL_3D");  // "rocfft" forces the library path (A/B comparison)
-    return nx == 512 && ny == 512 && nz == 512 && !(e && std::string(e) == "rocfft");
+    if (e && std::string(e) == "rocfft") return false;
+    const int lx = ilog2(nx), ly = ilog2(ny), lz = ilog2(nz);
+    if (!(lx >= 7 && lx <= 10 && ly >= 7 && ly <= 10 && lz >= 7 && lz <= 10)) return false;
+    // measured per step against the rocFFT path (profiles/r02/spectral3d_ab_sizes.log, bench_spectral_sizes.log):
+    // 128^3 0.080 ms vs 0.088; 256^3 0.375 vs 0.567; 512^3 2.64 vs 3.5; 1024^3 24.9 vs 49.3
+    return true;
   }
   const int lx = ilog2(nx), ly = ilog2(ny);
   return dim == 2 && lx >= 7 && lx <= 10 && ly >= 7 && ly <= 10;
@@ -783,12 +889,21 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     return hipMemcpy(*dev, t.data(), sizeof(double2) * t.size(), hipMemcpyHostToDevice);
   };
   if (table(nx, &f->twx) != hipSuccess || table(ny, &f->twy) != hipSuccess) return -3;
+  if (nz > 1) {
+    f->lgz = ilog2(nz);
+    if (table(nz, &f->twz) != hipSuccess) return -3;
+  }
   const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
   const bool allow8 = !(e && std::string(e) == "radix2");
   f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
-  f->col512 = (allow8 || f->cube512) && ny == 512;
+  f->col512 = (allow8 || f->cube512) && (ny == 512 || nz == 512);  // (3-D: "some column pass needs the radix-8 tables")
   if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : 8;
   if (const char* ze = getenv("PFHIP_FFT3D_ZEARLY")) g_zearly = std::atoi(ze) != 0;
+  if (const char* gg = getenv("PFHIP_FFT3D_GENERIC512")) g_generic512 = std::atoi(gg) != 0;
+  if (const char* cg = getenv("PFHIP_FFT3D_CWG")) {
+    const int c = std::atoi(cg);
+    g_cwg = (c == 4 || c == 8) ? c : 0;
+  }
 
   if (const char* cw = getenv("PFHIP_FFT512_CW")) {
     const int c = std::atoi(cw);
@@ -818,11 +933,28 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
       hipFuncSetAttribute(reinterpret_cast<const void*>(f2_col_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)f->lds_col) != hipSuccess)
     return -3;
+  if (f->cube512) {  // 1024-point columns: 4 columns of 1057 slots + 512 twiddles = 76 KB of LDS per workgroup
+    auto big = [](const void* k) {
+      return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    };
+    if (!big(reinterpret_cast<const void*>(f3_col_kernel<0, 8, 128, 512>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<1, 8, 128, 512>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<2, 8, 128, 512>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<3, 8, 128, 512>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<4, 8, 128, 512>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<0, 4, 256, 1024>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<1, 4, 256, 1024>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<2, 4, 256, 1024>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<3, 4, 256, 1024>)) ||
+        !big(reinterpret_cast<const void*>(f3_col_kernel<4, 4, 256, 1024>)))
+      return -3;
+  }
   return 0;
 }
 
 void fused2d_destroy(Fused2D* f) {
   if (!f) return;
+  if (f->twz) (void)hipFree(f->twz);
   if (f->twx) (void)hipFree(f->twx);
   if (f->twy) (void)hipFree(f->twy);
   if (f->tw8a) (void)hipFree(f->tw8a);
@@ -863,8 +995,23 @@ namespace {
 // 3-D passes (512^3).  Rows: f2_row512_kernel over ny*nz/2 row pairs (its row index is the flattened (z, y) index).
 void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
                  int from_spectrum, int use_fprime) {
-  hipLaunchKernelGGL(f2_row512_kernel<true>, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
-                     (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
+  if (f->row512)
+    hipLaunchKernelGGL(f2_row512_kernel<true>, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
+                       (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
+  else
+    hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny * a.nz / 2), dim3(RT), f->lds_row, f->stream, a, H, c_in, c_out, G,
+                       (const double2*)f->twx, from_spectrum, use_fprime);
+}
+template <int MODE, int CWG, int G, int NMAX>
+void launch_col3_g(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
+  const int nblk = (a.nxh + CWG - 1) / CWG;
+  const int64_t row = a.pitch, plane = (int64_t)a.pitch * a.ny;
+  const int64_t col_stride = axis == 1 ? row : plane, batch_stride = axis == 1 ? plane : row;
+  const int nbatch = axis == 1 ? a.nz : a.ny, N = axis == 1 ? a.ny : a.nz, lg = axis == 1 ? a.lgy : f->lgz;
+  const size_t lds = sizeof(double2) * ((size_t)CWG * (N + N / 32 + 1) + N / 2);
+  hipLaunchKernelGGL((f3_col_kernel<MODE, CWG, G, NMAX>), dim3(nblk * nbatch), dim3(G * CWG), lds, f->stream, a, A, chat, H,
+                     col_stride, batch_stride, nblk, nblk * nbatch, N, lg,
+                     (const double2*)(axis == 1 ? f->twy : f->twz));
 }
 template <int MODE, int CW3>
 void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
@@ -885,6 +1032,25 @@ template <int MODE>
 void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
   // measured after the aligned pitch (rocprofv3, 512^3): z pass 999 us with 4 columns per workgroup (4 workgroups of 4
   // waves per CU) vs 1073 us with 8; y passes 441-452 us with 8 vs 466-471 us with 4
+  const int N = axis == 1 ? a.ny : a.nz;
+  if (N != 512 || g_generic512) {
+    if (N == 512) {
+      if (g_cwg == 4)
+        launch_col3_g<MODE, 4, 128, 512>(f, a, A, chat, H, axis);
+      else
+        launch_col3_g<MODE, 8, 128, 512>(f, a, A, chat, H, axis);
+      return;
+    }
+    // columns per workgroup, measured at 256^3: 8 -> 0.363 ms per step, 4 -> 0.379 (rocFFT path 0.578)
+    const int cwg = g_cwg ? g_cwg : 8;
+    if (N > 512)  // 4 columns of 1024 points: 76 KB of LDS, 1024 threads
+      launch_col3_g<MODE, 4, 256, 1024>(f, a, A, chat, H, axis);
+    else if (cwg == 8)
+      launch_col3_g<MODE, 8, 64, 256>(f, a, A, chat, H, axis);
+    else
+      launch_col3_g<MODE, 4, 64, 256>(f, a, A, chat, H, axis);
+    return;
+  }
   const int cw = g_cw3 ? g_cw3 : ((MODE == 2 || MODE == 4 || MODE == 3) ? 4 : 8);
   if (cw == 4)
     launch_col3_t<MODE, 4>(f, a, A, chat, H, axis);
@@ -898,9 +1064,10 @@ void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, d
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2) {
   if (!f->cube512) return -3;
   if (!f->sym) {
-    std::vector<double> t(3 * 512);
+    const int nn[3] = {f->a.nx, f->a.ny, f->a.nz};
+    std::vector<double> t;
     for (int d = 0; d < 3; ++d)
-      for (int m = 0; m < 512; ++m) t[d * 512 + m] = 2.0 * std::cos(TWO_PI_F * m / 512.0) - 2.0;
+      for (int m = 0; m < nn[d]; ++m) t.push_back(2.0 * std::cos(TWO_PI_F * m / nn[d]) - 2.0);
     if (hipMalloc(&f->sym, sizeof(double) * t.size()) != hipSuccess ||
         hipMemcpy(f->sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice) != hipSuccess)
       return -3;

@@ -363,14 +363,18 @@ def test_full_size_properties_1024cubed(lib):
 
 
 @pytest.mark.parametrize("shape", [(512, 512), (128, 256), (1024, 128), (256, 512), (512, 128), (96, 40), (34, 18, 10),
-                                   (64, 64, 64)])
-def test_spectral_scheme_matches_numpy_oracle(lib, shape):
+                                   (64, 64, 64), (128, 128, 128), (256, 128, 512), (128, 512, 256), (1024, 128, 128),
+                                   (128, 128, 1024), (128, 1024, 128)])
+def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
     """BASELINE.json config 2 (512^2 semi-implicit spectral) vs the pocketfft oracle, 1e-11 relative: 2-D power-of-two
     shapes take the fused LDS-FFT path (csrc/spectral2d_fused.hip: one-wave radix-8 kernels on 512-point axes -- (256, 512)
-    and (512, 128) pair one of them with the generic radix-2^2 kernel of the other axis), everything else rocFFT."""
+    and (512, 128) pair one of them with the generic radix-2^2 kernel of the other axis); 3-D boxes whose axes are all
+    powers of two in 128..1024 take the hand-written 4-pass path too (every axis length on every axis: 128, 256, 512 and
+    1024 along x, y and z); everything else rocFFT."""
     from oracle import ch_spectral
     dim = len(shape)
     n = shape[::-1]                      # (nx, ny[, nz])
+    monkeypatch.setenv("PFHIP_SPECTRAL_3D", "lds")   # 128^3 would default to rocFFT (faster there); no effect on other shapes
     rng = np.random.default_rng(sum(shape))
     if shape == (512, 512):
         from oracle import ch_fd
@@ -400,14 +404,15 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape):
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
 
 
-@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10)])
-def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape):
+@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10), (128, 128, 128), (256, 128, 512)])
+def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
     """BM6 with the semi-implicit spectral scheme in a periodic box: phi eliminated in Fourier space (one more implicit
     term in the k-space update, every kernel form: radix-8 LDS FFT, radix-2^2 LDS FFT, rocFFT 2-D and 3-D), f_elec by
     Parseval; against oracle/ch_spectral.py (1e-11); and consistent with the FD scheme's phi-eliminated step in the
     small-dt limit is left to the convergence study."""
     from oracle import ch_spectral
     dim = len(shape)
+    monkeypatch.setenv("PFHIP_SPECTRAL_3D", "lds")
     rng = np.random.default_rng(sum(shape) + 1)
     c = 0.5 + 0.04 * rng.standard_normal(shape)
     sp = ch_spectral.SpectralCH(c, h=1.0, bm6=True)
@@ -578,10 +583,13 @@ def test_bm6_reference_boundary_conditions(lib, golden_dir):
         assert abs(C - csv[0, 2]) / csv[0, 2] < 1e-4
 
 
-def test_bm6_periodic_box_3d(lib):
+@pytest.mark.parametrize("shape", [(12, 20, 128), (128, 128, 128), (256, 128, 1024)])
+def test_bm6_periodic_box_3d(lib, shape, monkeypatch):
+    """BM6 FD scheme in a periodic box; the Poisson solve runs on rocFFT for general shapes and on the hand-written
+    passes (fused3d_poisson: f2_row_kernel + f3_col_kernel MODE 4) for power-of-two boxes (forced here for 128^3)."""
     from oracle import bm6_fd
+    monkeypatch.setenv("PFHIP_SPECTRAL_3D", "lds")
     rng = np.random.default_rng(21)
-    shape = (12, 20, 128)
     c = 0.5 + 0.04 * rng.standard_normal(shape)
     o = bm6_fd.BM6FD(c, 1.0)
     with PhaseFieldSolver(dim=3, n=shape[::-1], h=1.0, model="bm6") as s:

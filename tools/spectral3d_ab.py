@@ -1,5 +1,5 @@
-"""512^3 semi-implicit spectral step: hand-written radix-8 LDS-FFT passes vs rocFFT (PFHIP_SPECTRAL_3D=rocfft), same
-initial state: max field difference, diagnostics, ms per step.  Usage on the GPU box: python tools/spectral3d_ab.py"""
+"""n^3 semi-implicit spectral step: hand-written LDS-FFT passes vs rocFFT (PFHIP_SPECTRAL_3D=rocfft), same initial
+state: max field difference, diagnostics, ms per step.  Usage on the GPU box: python tools/spectral3d_ab.py [n=512]"""
 import os
 import sys
 import time
@@ -10,16 +10,19 @@ import numpy as np
 from pfhubbenchmarks_amd.solver import PhaseFieldSolver
 
 
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+
+
 def make(env):
     os.environ.pop("PFHIP_SPECTRAL_3D", None)
     os.environ.update(env)
-    return PhaseFieldSolver(dim=3, n=512, h=1.0, scheme="spectral")
+    return PhaseFieldSolver(dim=3, n=N, h=1.0, scheme="spectral")
 
 
 rng = np.random.default_rng(5)
-c0 = (0.5 + 0.05 * rng.standard_normal((512, 512, 512))).astype(np.float64)
+c0 = 0.5 + 0.05 * rng.standard_normal((N, N, N), dtype=np.float32).astype(np.float64)
 res = {}
-for name, env in (("lds-fft", {}), ("rocfft", {"PFHIP_SPECTRAL_3D": "rocfft"})):
+for name, env in (("lds-fft", {"PFHIP_SPECTRAL_3D": "lds"}), ("rocfft", {"PFHIP_SPECTRAL_3D": "rocfft"})):
     with make(env) as s:
         s.set_c(c0)
         d0 = s.diagnostics()
@@ -31,7 +34,7 @@ for name, env in (("lds-fft", {}), ("rocfft", {"PFHIP_SPECTRAL_3D": "rocfft"})):
         ms = (time.perf_counter() - t0) / 20 * 1e3
         d1 = s.diagnostics()
         res[name] = (s.get_c(), d0, d1, ms)
-    print("%-8s %.3f ms/step  %.3e cell-updates/s  F0=%.10e F=%.10e C=%.10e" % (name, ms, 512 ** 3 / ms * 1e3, d0[0], d1[0], d1[1]),
+    print("%-8s %.3f ms/step  %.3e cell-updates/s  F0=%.10e F=%.10e C=%.10e" % (name, ms, N ** 3 / ms * 1e3, d0[0], d1[0], d1[1]),
           flush=True)
 a, b = res["lds-fft"][0], res["rocfft"][0]
 print("max |c_lds - c_rocfft| = %.3e  (max |c| %.3f)" % (np.abs(a - b).max(), np.abs(b).max()))
