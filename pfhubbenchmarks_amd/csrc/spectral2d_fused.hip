@@ -896,6 +896,8 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
   const bool allow8 = !(e && std::string(e) == "radix2");
   f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
+  if (const char* rg = getenv("PFHIP_FFT3D_ROW"))  // "generic": 512-point rows of a 3-D box by f2_row_kernel (A/B)
+    if (f->cube512 && std::string(rg) == "generic") f->row512 = false;
   f->col512 = (allow8 || f->cube512) && (ny == 512 || nz == 512);  // (3-D: "some column pass needs the radix-8 tables")
   if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : 8;
   if (const char* ze = getenv("PFHIP_FFT3D_ZEARLY")) g_zearly = std::atoi(ze) != 0;

@@ -14,8 +14,9 @@ rng = np.random.default_rng(5)
 c0 = 0.5 + 0.05 * rng.standard_normal((N, N, N), dtype=np.float32).astype(np.float64)
 ref = None
 for name, env in (("radix-8 wave", {}), ("generic cw8", {"PFHIP_FFT3D_GENERIC512": "1", "PFHIP_FFT3D_CWG": "8"}),
-                  ("generic cw4", {"PFHIP_FFT3D_GENERIC512": "1", "PFHIP_FFT3D_CWG": "4"})):
-    for k in ("PFHIP_FFT3D_GENERIC512", "PFHIP_FFT3D_CWG"):
+                  ("generic cw4", {"PFHIP_FFT3D_GENERIC512": "1", "PFHIP_FFT3D_CWG": "4"}),
+                  ("generic row", {"PFHIP_FFT3D_ROW": "generic"}), ("radix-8 again", {})):
+    for k in ("PFHIP_FFT3D_GENERIC512", "PFHIP_FFT3D_CWG", "PFHIP_FFT3D_ROW"):
         os.environ.pop(k, None)
     os.environ.update(env)
     with PhaseFieldSolver(dim=3, n=N, h=1.0, scheme="spectral") as s:
