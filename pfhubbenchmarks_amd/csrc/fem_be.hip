@@ -43,6 +43,7 @@ struct FemParams {
   double h, area;
   double ca, cb, two_rho, rho, kappa, Mob, kq, k_over_eps;
   double L;
+  int cond = 0;  // generic path: cell-centre unknowns eliminated before the block solve (blocks hold corner rows only)
 };
 
 __device__ __forceinline__ double d_fp(const FemParams& p, double c) {
@@ -69,6 +70,14 @@ __device__ __forceinline__ void node_block(const FemParams& p, int n, int& g, in
     g = m / p.N;
     l = n1 + m % p.N;
   }
+}
+// generic path: offset of node n's NF unknowns in the residual / solution vector.  Condensed layout: node-major (the
+// n1^2 corner nodes first -- exactly the block layout of n1 groups of n1 * NF rows -- then the cell centres).
+__device__ __forceinline__ int64_t gen_row(const FemParams& p, int n, int NF) {
+  if (p.cond) return (int64_t)n * NF;
+  int g, l;
+  node_block(p, n, g, l);
+  return (int64_t)g * p.nb + l * NF;
 }
 __device__ __forceinline__ bool is_dirichlet(const FemParams& p, int n) {  // phi rows, BM6: x = 0 or x = L corners
   const int n1 = p.N + 1;
@@ -457,9 +466,7 @@ __global__ __launch_bounds__(256) void gen_residual_kernel(const FemParams p, co
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] += a[f] * (p.area / 6.0);
   }
-  int grp, loc;
-  node_block(p, n, grp, loc);
-  double* r = rhs + (int64_t)grp * p.nb + loc * NF;
+  double* r = rhs + gen_row(p, n, NF);
 #pragma unroll
   for (int e = 0; e < NF; ++e) {
     double R = acc[e];
@@ -469,16 +476,10 @@ __global__ __launch_bounds__(256) void gen_residual_kernel(const FemParams p, co
   }
 }
 
-// one thread per (triangle, equation e): the 3 x 3 element blocks of row e against every field f
+// G[f] = int dS_e/du_f lambda_i lambda_j over one triangle (6-point rule), symmetric 3 x 3 as (00, 01, 02, 11, 12, 22)
 template <int NF>
-__global__ __launch_bounds__(256) void gen_jacobian_kernel(const FemParams p, const GenModel m,
-                                                           const int* __restrict__ tri, const double* __restrict__ Ke,
-                                                           const FieldPtrs u, double inv_dt, double* D, double* Lo,
-                                                           double* Up) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.ntri * NF) return;
-  const int t = idx / NF, e = idx % NF;
-  const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+__device__ __forceinline__ void gen_elem_quadrature(const FemParams& p, const GenModel& m, int e, const int (&n)[3],
+                                                    const FieldPtrs& u, double (&G)[NF][6]) {
   double ue[NF][3];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
@@ -486,7 +487,6 @@ __global__ __launch_bounds__(256) void gen_jacobian_kernel(const FemParams p, co
     ue[f][1] = u.u[f][n[1]];
     ue[f][2] = u.u[f][n[2]];
   }
-  double G[NF][6];  // symmetric 3 x 3 per field: (00, 01, 02, 11, 12, 22)
 #pragma unroll
   for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -514,6 +514,20 @@ __global__ __launch_bounds__(256) void gen_jacobian_kernel(const FemParams p, co
       }
     }
   }
+}
+
+// one thread per (triangle, equation e): the 3 x 3 element blocks of row e against every field f
+template <int NF>
+__global__ __launch_bounds__(256) void gen_jacobian_kernel(const FemParams p, const GenModel m,
+                                                           const int* __restrict__ tri, const double* __restrict__ Ke,
+                                                           const FieldPtrs u, double inv_dt, double* D, double* Lo,
+                                                           double* Up) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.ntri * NF) return;
+  const int t = idx / NF, e = idx % NF;
+  const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+  double G[NF][6];
+  gen_elem_quadrature<NF>(p, m, e, n, u, G);
   int g[3], l[3];
   for (int i = 0; i < 3; ++i) node_block(p, n[i], g[i], l[i]);
   const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
@@ -529,14 +543,162 @@ __global__ __launch_bounds__(256) void gen_jacobian_kernel(const FemParams p, co
   }
 }
 
+// ---- static condensation of the cell-centre unknowns ------------------------------------------------------------
+// On the crossed mesh a centre node couples only to the four corners of its own cell, so its NF unknowns can be
+// eliminated cell by cell before the block-tridiagonal solve: the blocks then hold the n1 corner rows only
+// (n1 * NF instead of (2N + 1) * NF unknowns per group -- 8x fewer flops in the cyclic reduction) and the Newton
+// direction is the same up to rounding.  Local numbering inside a cell: 0 sw, 1 se, 2 nw, 3 ne, 4 centre; the local
+// matrix is (5 NF) x (5 NF), row-major, row = local node * NF + equation.
+// One thread per (cell, equation e): rows (., e) of the cell's four element matrices -- a single writer per row.
+template <int NF>
+__global__ __launch_bounds__(256) void gen_cell_jacobian_kernel(const FemParams p, const GenModel m,
+                                                                const int* __restrict__ tri,
+                                                                const double* __restrict__ Ke, const FieldPtrs u,
+                                                                double inv_dt, double* __restrict__ Aloc) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.N * p.N * NF) return;
+  const int cell = idx / NF, e = idx % NF;
+  constexpr int W = 5 * NF;
+  double* A = Aloc + (int64_t)cell * W * W;
+  for (int a = 0; a < 5; ++a)
+    for (int c = 0; c < W; ++c) A[(a * NF + e) * W + c] = 0.0;
+  const int la4[4][3] = {{0, 1, 4}, {0, 2, 4}, {1, 3, 4}, {2, 3, 4}};  // the triangle order of fembe_create
+  const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int k = 0; k < 4; ++k) {
+    const int t = 4 * cell + k;
+    const int n[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    double G[NF][6];
+    gen_elem_quadrature<NF>(p, m, e, n, u, G);
+    for (int f = 0; f < NF; ++f) {
+      const double cm = m.T[e][f] * inv_dt + m.A[e][f], ck = m.Kc[e][f];
+      if (cm == 0.0 && ck == 0.0 && !m.nl[e][f]) continue;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          const double Mij = p.area / 12.0 * (i == j ? 2.0 : 1.0);
+          const double val = (cm * Mij + ck * Ke[9 * t + 3 * i + j]) + G[f][sym[i][j]];
+          A[(la4[k][i] * NF + e) * W + la4[k][j] * NF + f] += val;
+        }
+    }
+  }
+}
+
+// B x = b for an NF x NF system held in registers (partial pivoting); b is overwritten with x
+template <int NF>
+__device__ __forceinline__ void small_solve(double (&B)[NF][NF], double (&b)[NF]) {
+#pragma unroll
+  for (int c = 0; c < NF; ++c) {
+    int pr = c;
+    double pv = fabs(B[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < NF; ++r)
+      if (fabs(B[r][c]) > pv) {
+        pv = fabs(B[r][c]);
+        pr = r;
+      }
+#pragma unroll
+    for (int r = c + 1; r < NF; ++r)
+      if (r == pr) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          const double tmp = B[r][k];
+          B[r][k] = B[c][k];
+          B[c][k] = tmp;
+        }
+        const double tb = b[r];
+        b[r] = b[c];
+        b[c] = tb;
+      }
+    const double inv = 1.0 / B[c][c];
+#pragma unroll
+    for (int r = c + 1; r < NF; ++r) {
+      const double fac = B[r][c] * inv;
+#pragma unroll
+      for (int k = c + 1; k < NF; ++k) B[r][k] -= fac * B[c][k];
+      b[r] -= fac * b[c];
+    }
+  }
+#pragma unroll
+  for (int c = NF - 1; c >= 0; --c) {
+    double acc = b[c];
+#pragma unroll
+    for (int k = c + 1; k < NF; ++k) acc -= B[c][k] * b[k];
+    b[c] = acc / B[c][c];
+  }
+}
+
+// One thread per (cell, corner row r = (a, e)): row r of the Schur complement A_cc - A_cm A_mm^-1 A_mc of the cell, added
+// into the corner blocks; the same elimination applied to the right-hand side (rhs: node-major, gen_row).
+template <int NF>
+__global__ __launch_bounds__(256) void gen_condense_kernel(const FemParams p, const double* __restrict__ Aloc,
+                                                           double* rhs, double* D, double* Lo, double* Up) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.N * p.N * 4 * NF) return;
+  const int cell = idx / (4 * NF), r = idx % (4 * NF), a = r / NF, e = r % NF;
+  constexpr int W = 5 * NF;
+  const double* A = Aloc + (int64_t)cell * W * W;
+  const int n1 = p.N + 1, ci = cell % p.N, cj = cell / p.N;
+  double B[NF][NF], w[NF];  // w A_mm = A_cm[r, :]  <=>  A_mm^T w^T = A_cm[r, :]^T
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    w[k] = A[r * W + 4 * NF + k];
+#pragma unroll
+    for (int k2 = 0; k2 < NF; ++k2) B[k][k2] = A[(4 * NF + k2) * W + 4 * NF + k];
+  }
+  small_solve<NF>(B, w);
+  const int ga = cj + (a >> 1), la = ci + (a & 1);
+  for (int b = 0; b < 4; ++b) {
+    const int gb = cj + (b >> 1), lb = ci + (b & 1);
+    for (int f = 0; f < NF; ++f) {
+      const int col = b * NF + f;
+      double sc = A[r * W + col];
+#pragma unroll
+      for (int k = 0; k < NF; ++k) sc -= w[k] * A[(4 * NF + k) * W + col];
+      if (sc != 0.0) jadd(p, D, Lo, Up, ga, la, e, gb, lb, f, sc);
+    }
+  }
+  const double* rm = rhs + ((int64_t)n1 * n1 + cell) * NF;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < NF; ++k) acc += w[k] * rm[k];
+  atomicAdd(rhs + ((int64_t)ga * n1 + la) * NF + e, -acc);
+}
+
+// One thread per cell, after the corner solve: centre part of the Newton direction, written over the centre residual
+template <int NF>
+__global__ __launch_bounds__(256) void gen_backsub_kernel(const FemParams p, const double* __restrict__ Aloc,
+                                                          double* rhs) {
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= p.N * p.N) return;
+  constexpr int W = 5 * NF;
+  const double* A = Aloc + (int64_t)cell * W * W;
+  const int n1 = p.N + 1, ci = cell % p.N, cj = cell / p.N;
+  double* rm = rhs + ((int64_t)n1 * n1 + cell) * NF;
+  double B[NF][NF], t[NF];
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    t[k] = rm[k];
+#pragma unroll
+    for (int k2 = 0; k2 < NF; ++k2) B[k][k2] = A[(4 * NF + k) * W + 4 * NF + k2];
+  }
+  for (int b = 0; b < 4; ++b) {
+    const double* sc = rhs + ((int64_t)(cj + (b >> 1)) * n1 + ci + (b & 1)) * NF;
+    for (int f = 0; f < NF; ++f) {
+      const double v = sc[f];
+#pragma unroll
+      for (int k = 0; k < NF; ++k) t[k] -= A[(4 * NF + k) * W + b * NF + f] * v;
+    }
+  }
+  small_solve<NF>(B, t);
+#pragma unroll
+  for (int k = 0; k < NF; ++k) rm[k] = t[k];
+}
+
 template <int NF>
 __global__ __launch_bounds__(256) void gen_update_kernel(const FemParams p, const double* __restrict__ sol, FieldPtrs u,
                                                          double scale) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= p.nn) return;
-  int g, l;
-  node_block(p, n, g, l);
-  const double* s = sol + (int64_t)g * p.nb + l * NF;
+  const double* s = sol + gen_row(p, n, NF);
 #pragma unroll
   for (int f = 0; f < NF; ++f) u.u[f][n] += scale * s[f];
 }
@@ -677,6 +839,8 @@ struct FemBE {
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
+  double* Aloc = nullptr;                          // condensed generic path: (5 nf)^2 local matrix per cell
+  size_t vec_len = 0;                              // unknowns in rhs (nb * ng; condensed: nn * nf, corners first)
   bool verbose = false;                            // PFHIP_FEM_VERBOSE=1: residual norm (and line-search data) per iteration
   int line_search = 0;                             // 0: full Newton steps ('basic'), 1: SNESLINESEARCHCP (one secant step)
   GenModel gm;                                     // model id 2 / 3: generic multi-field path (u, u0 hold the fields)
@@ -710,7 +874,7 @@ int fembe_nodes(const FemBE* fb) { return fb->p.nn; }
 int fembe_last_iters(const FemBE* fb) { return fb->last_iters; }
 
 int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, double ca, double cb, double kappa,
-                 double Mob, double k, double eps, hipStream_t stream, std::string* err) {
+                 double Mob, double k, double eps, hipStream_t stream, std::string* err, bool condensed) {
   FemBE* fb = new FemBE();
   *out = fb;
   FemParams& p = fb->p;
@@ -721,6 +885,8 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
   p.nf = nf;
   p.nb = (2 * N + 1) * nf;
   p.ng = N + 1;
+  p.cond = condensed ? 1 : 0;
+  if (condensed) p.nb = n1 * nf;
   p.h = h;
   p.area = h * h / 4.0;
   p.ca = ca;
@@ -833,7 +999,9 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       const char* v = getenv("PFHIP_FEM_VERBOSE");
       fb->verbose = v && v[0] == '1';
     }
-    FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * (size_t)p.nb * p.ng));
+    fb->vec_len = condensed ? (size_t)p.nn * nf : (size_t)p.nb * p.ng;
+    FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * fb->vec_len));
+    if (condensed) FB_HIP(hipMalloc(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
     FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
     FB_HIP(hipMalloc(&fb->info, sizeof(rocblas_int) * p.ng));
     FB_HIP(hipMalloc(&fb->scal, sizeof(double) * 4));
@@ -861,6 +1029,7 @@ void fembe_destroy(FemBE* fb) {
   if (fb->scal_host) (void)hipHostFree(fb->scal_host);
   if (fb->rhs0) (void)hipFree(fb->rhs0);
   if (fb->rhs1) (void)hipFree(fb->rhs1);
+  if (fb->Aloc) (void)hipFree(fb->Aloc);
   for (int f = 3; f < MAXF; ++f) {  // fields 0..2 alias c / mu / phi
     if (fb->u.u[f]) (void)hipFree(fb->u.u[f]);
     if (fb->u0.u[f]) (void)hipFree(fb->u0.u[f]);
@@ -873,7 +1042,9 @@ void fembe_destroy(FemBE* fb) {
 int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, const double* mp, hipStream_t stream,
                        std::string* err) {
   const int nf = model == 2 ? 6 : 2;
-  int rc = fembe_create(out, nodes_per_side, h, nf, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, stream, err);
+  const char* ce = getenv("PFHIP_FEM_CONDENSE");  // "0": keep the centre unknowns in the blocks (A/B, cross-check)
+  int rc = fembe_create(out, nodes_per_side, h, nf, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, stream, err,
+                        !(ce && ce[0] == '0'));
   if (rc) return rc;
   FemBE* fb = *out;
   GenModel& m = fb->gm;
@@ -938,8 +1109,8 @@ int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, con
     FB_HIP(hipMemset(fb->u0.u[f], 0, nbytes));
   }
   for (int f = nf; f < MAXF; ++f) fb->u.u[f] = fb->u0.u[f] = nullptr;
-  FB_HIP(hipMalloc(&fb->rhs0, sizeof(double) * (size_t)fb->p.nb * fb->p.ng));
-  FB_HIP(hipMalloc(&fb->rhs1, sizeof(double) * (size_t)fb->p.nb * fb->p.ng));
+  FB_HIP(hipMalloc(&fb->rhs0, sizeof(double) * fb->vec_len));
+  FB_HIP(hipMalloc(&fb->rhs1, sizeof(double) * fb->vec_len));
   // the reference's SNES line search: 'cp' for BM2 (bench2.py:140), 'basic' for BM3 (bench3.py:124)
   fb->line_search = model == 2 ? 1 : 0;
   if (const char* e = getenv("PFHIP_FEM_LINESEARCH")) fb->line_search = std::string(e) == "cp" ? 1 : 0;
@@ -1013,7 +1184,7 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
     double* r;
     ~Restore() { f->rhs = r; }
   } restore{fb, rhs_saved};
-  FB_HIP(hipMemsetAsync(fb->rhs, 0, sizeof(double) * (size_t)p.nb * p.ng, fb->stream));
+  FB_HIP(hipMemsetAsync(fb->rhs, 0, sizeof(double) * fb->vec_len, fb->stream));
   if (fb->gm.id == 2)
     hipLaunchKernelGGL(gen_residual_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
                        fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
@@ -1024,7 +1195,7 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
   hipLaunchKernelGGL(fem_residual_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->ell_col, fb->ell_K,
                      fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
                      fb->rhs);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, p.nb * p.ng, fb->scal);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, (int)fb->vec_len, fb->scal);
   FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, sizeof(double), hipMemcpyDeviceToHost, fb->stream));
   FB_HIP(hipStreamSynchronize(fb->stream));
   *nrm = std::sqrt(fb->scal_host[0]);
@@ -1164,7 +1335,21 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     FB_HIP(hipMemsetAsync(fb->D, 0, bsz, fb->stream));
     FB_HIP(hipMemsetAsync(fb->Lo, 0, bsz, fb->stream));
     FB_HIP(hipMemsetAsync(fb->Up, 0, bsz, fb->stream));
-    if (fb->gm.id == 2) {
+    const bool cp = fb->gm.id && fb->line_search == 1;
+    if (cp)  // keep -R(u): condensation and the solve overwrite rhs (with the Newton direction d in the end)
+      FB_HIP(hipMemcpyAsync(fb->rhs0, fb->rhs, sizeof(double) * fb->vec_len, hipMemcpyDeviceToDevice, fb->stream));
+    const int ncell = p.N * p.N;
+    if (fb->gm.id == 2 && p.cond) {
+      hipLaunchKernelGGL(gen_cell_jacobian_kernel<6>, dim3((ncell * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
+                         fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
+      hipLaunchKernelGGL(gen_condense_kernel<6>, dim3((ncell * 24 + 255) / 256), dim3(256), 0, fb->stream, p,
+                         (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
+    } else if (fb->gm.id == 3 && p.cond) {
+      hipLaunchKernelGGL(gen_cell_jacobian_kernel<2>, dim3((ncell * 2 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
+                         fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
+      hipLaunchKernelGGL(gen_condense_kernel<2>, dim3((ncell * 8 + 255) / 256), dim3(256), 0, fb->stream, p,
+                         (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
+    } else if (fb->gm.id == 2) {
       hipLaunchKernelGGL(gen_jacobian_kernel<6>, dim3((p.ntri * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
                          fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
       hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
@@ -1179,11 +1364,14 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     hipLaunchKernelGGL(fem_identity_kernel, dim3((nid + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
     }
     FB_HIP(hipGetLastError());
-    const bool cp = fb->gm.id && fb->line_search == 1;
-    if (cp)  // keep -R(u): the solve overwrites rhs with the Newton direction d
-      FB_HIP(hipMemcpyAsync(fb->rhs0, fb->rhs, sizeof(double) * (size_t)p.nb * p.ng, hipMemcpyDeviceToDevice, fb->stream));
     rc = fb->solver == 1 ? block_solve(fb) : block_solve_bcr(fb);
     if (rc) return rc;
+    if (fb->gm.id == 2 && p.cond)
+      hipLaunchKernelGGL(gen_backsub_kernel<6>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
+                         (const double*)fb->Aloc, fb->rhs);
+    else if (fb->gm.id == 3 && p.cond)
+      hipLaunchKernelGGL(gen_backsub_kernel<2>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
+                         (const double*)fb->Aloc, fb->rhs);
     auto gen_update = [&](double scale) {
       if (fb->gm.id == 2)
         hipLaunchKernelGGL(gen_update_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
@@ -1198,7 +1386,7 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
         // SNESLINESEARCHCP (bench2.py:140) with its default single secant iteration, restated from PETSc's
         // SNESLineSearchApply_CP including its two safeguards: one function evaluation at the full step, one secant
         // update of lambda from fty(0), fty(1)
-        const int ntot = p.nb * p.ng;
+        const int ntot = (int)fb->vec_len;
         double n1 = 0.0;
         rc = residual_norm(fb, inv_dt, &n1, fb->rhs1);  // -R(u + d)
         if (rc) return rc;

@@ -123,7 +123,7 @@ const char* slabfft_error(const SlabFFT* sf);
 // BE-parity mode (fem_be.hip): the reference's P1 crossed-mesh backward-Euler Newton solve on the GPU
 struct FemBE;
 int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, double ca, double cb, double kappa,
-                 double Mob, double k, double eps, hipStream_t stream, std::string* err);
+                 double Mob, double k, double eps, hipStream_t stream, std::string* err, bool condensed = false);
 void fembe_destroy(FemBE* fb);
 int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, const double* mp, hipStream_t stream,
                        std::string* err);  // model 2 = BM2, 3 = BM3 (generic multi-field path)

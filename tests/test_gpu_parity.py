@@ -993,6 +993,30 @@ def test_multifield_fd_no_flux_box_is_the_even_extension(lib, model):
         assert abs(F - Fo) <= 1e-13 * abs(Fo) and abs(C - Co) <= 1e-13 * abs(Co)
 
 
+@pytest.mark.parametrize("model,n,h", [("bm2", 41, 2.0), ("bm3", 61, 960.0 / 350)])
+def test_fem_be_static_condensation_equals_the_full_block_solve(lib, model, n, h, monkeypatch):
+    """The generic BE-parity path eliminates the cell-centre unknowns cell by cell before the block-tridiagonal solve
+    (gen_cell_jacobian_kernel / gen_condense_kernel / gen_backsub_kernel).  PFHIP_FEM_CONDENSE=0 keeps them in the blocks
+    (the first implementation, pinned to the reference CSVs in round 2): same Newton iterates up to rounding -- same
+    iteration counts, fields to 1e-10, incl. the cp line search (BM2)."""
+    out = {}
+    for cond in ("1", "0"):
+        monkeypatch.setenv("PFHIP_FEM_CONDENSE", cond)
+        with PhaseFieldSolver(dim=2, n=n, h=h, bc="mirror", scheme="fem_be", model=model, max_newton=100) as s:
+            s.set_ic_bm2() if model == "bm2" else s.set_ic_bm3()
+            its = []
+            for dt in (0.01, 0.04, 0.08):
+                ok, _, _ = s.step(dt, 1, check=True)
+                assert ok
+                its.append(s.last_iters)
+            names = ("c", "mu", "eta1", "eta4") if model == "bm2" else ("U", "phi")
+            out[cond] = (its, [s.get_field(k) for k in names], s.diagnostics())
+    assert out["1"][0] == out["0"][0] and max(out["1"][0]) >= 3, out["1"][0]
+    for a, b in zip(out["1"][1], out["0"][1]):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    assert abs(out["1"][2][0] - out["0"][2][0]) <= 1e-11 * abs(out["0"][2][0])
+
+
 def test_fem_be_bm3_against_reference_rows(lib, golden_dir):
     """PFHub BM3 (dolfin/bench3.py: U, phi on the 350 x 350 crossed mesh, 491 402 unknowns) through the same generic
     kernels: t = 0 known answers and the first rows of results/bench3_out.csv (F within 1e-8, solid fraction to the
