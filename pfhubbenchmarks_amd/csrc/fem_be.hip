@@ -836,6 +836,7 @@ struct FemBE {
   double *D = nullptr, *Lo = nullptr, *Up = nullptr, *rhs = nullptr;
   double *Lo2 = nullptr, *Up2 = nullptr;  // second coupling set (block cyclic reduction ping-pongs between the two)
   int solver = 0;                          // 0: block cyclic reduction (batched), 1: block Thomas (sequential)
+  bool pivot = true;                       // PFHIP_FEM_PIVOT=0: LU without row exchanges in the cyclic reduction (experiment)
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
@@ -996,6 +997,8 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
       fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
+      const char* pv = getenv("PFHIP_FEM_PIVOT");
+      fb->pivot = !(pv && pv[0] == '0');
       const char* v = getenv("PFHIP_FEM_VERBOSE");
       fb->verbose = v && v[0] == '1';
     }
@@ -1254,13 +1257,28 @@ static int block_solve_bcr(FemBE* fb) {
     double *Lc = Ls[set], *Uc = Us[set], *Ln = Ls[1 - set], *Un = Us[1 - set];
     double* De = fb->D + (int64_t)s * bs;
     rocblas_int* pe = fb->piv + (int64_t)s * nb;
-    FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
-    FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
-                                             Lc + (int64_t)s * bs, nb, st, ne));
-    FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
-                                             Uc + (int64_t)s * bs, nb, st, ne));
-    FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, 1, De, nb, st, pe, sv,
-                                             fb->rhs + (int64_t)s * nb, nb, sv, ne));
+    if (fb->pivot) {
+      FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
+      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
+                                               Lc + (int64_t)s * bs, nb, st, ne));
+      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
+                                               Uc + (int64_t)s * bs, nb, st, ne));
+      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, 1, De, nb, st, pe, sv,
+                                               fb->rhs + (int64_t)s * nb, nb, sv, ne));
+    } else {
+      FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, De, nb, st, fb->info, ne));
+      struct Rhs {
+        double* b;
+        int n;
+        int64_t stride;
+      } rr[3] = {{Lc + (int64_t)s * bs, nb, st}, {Uc + (int64_t)s * bs, nb, st}, {fb->rhs + (int64_t)s * nb, 1, sv}};
+      for (const Rhs& r : rr) {
+        FB_BLAS(rocblas_dtrsm_strided_batched(fb->bh, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
+                                              rocblas_diagonal_unit, nb, r.n, &one, De, nb, st, r.b, nb, r.stride, ne));
+        FB_BLAS(rocblas_dtrsm_strided_batched(fb->bh, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
+                                              rocblas_diagonal_non_unit, nb, r.n, &one, De, nb, st, r.b, nb, r.stride, ne));
+      }
+    }
     const int nl = nk - 1;  // kept blocks k = 2, 4, .. have a left neighbour
     if (nl > 0) {
       const int64_t j0 = 2 * (int64_t)s;
@@ -1290,8 +1308,16 @@ static int block_solve_bcr(FemBE* fb) {
     m = nk;
     set = 1 - set;
   }
-  FB_BLAS(rocsolver_dgetrf(fb->bh, nb, nb, fb->D, nb, fb->piv, fb->info));
-  FB_BLAS(rocsolver_dgetrs(fb->bh, rocblas_operation_none, nb, 1, fb->D, nb, fb->piv, fb->rhs, nb));
+  if (fb->pivot) {
+    FB_BLAS(rocsolver_dgetrf(fb->bh, nb, nb, fb->D, nb, fb->piv, fb->info));
+    FB_BLAS(rocsolver_dgetrs(fb->bh, rocblas_operation_none, nb, 1, fb->D, nb, fb->piv, fb->rhs, nb));
+  } else {
+    FB_BLAS(rocsolver_dgetrf_npvt(fb->bh, nb, nb, fb->D, nb, fb->info));
+    FB_BLAS(rocblas_dtrsm(fb->bh, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, nb,
+                          1, &one, fb->D, nb, fb->rhs, nb));
+    FB_BLAS(rocblas_dtrsm(fb->bh, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
+                          rocblas_diagonal_non_unit, nb, 1, &one, fb->D, nb, fb->rhs, nb));
+  }
   for (int l = (int)levels.size() - 1; l >= 0; --l) {
     const Level& L = levels[l];
     const int ne = L.m / 2;
