@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) void fem_ic_kernel(const FemParams p, double c
 // T, A, Kc are constant tables; S and dS_e/du_f are pointwise functions of the field values at a quadrature point.
 constexpr int MAXF = 6;
 struct GenModel {
-  int id = 0;  // 2: BM2 (c, mu, eta1..4), 3: BM3 (U, phi)
+  int id = 0;  // 2: BM2 (c, mu, eta1..4), 3: BM3 (U, phi); 0: BM1 / BM6 (the c, mu[, phi] interface of fembe_create)
+  int kind = 0;  // source terms: 1 BM1 (q = {c_alpha, c_beta, 2 rho}), 2 BM2, 3 BM3
   int nf = 0;
   double T[MAXF][MAXF], A[MAXF][MAXF], Kc[MAXF][MAXF];
   unsigned char nl[MAXF][MAXF];  // 1: dS_e/du_f is not identically zero
@@ -347,6 +348,9 @@ __device__ __forceinline__ void gen_source(const GenModel& m, const double (&v)[
       const double well = (2.0 * ei * ((1.0 - ei) * (1.0 - ei)) - 2.0 * (ei * ei) * (1.0 - ei)) + 2.0 * al * ei * (e2 - ei * ei);
       S[2 + i] = L * ((fb - fa) * bm2_hp(ei) + w * well);
     }
+  } else if (m.kind == 1) {  // BM1: mu row carries - int f'(c) lambda (bench1.py:60-66, d_fp)
+    const double a = v[0] - m.q[0], b = m.q[1] - v[0];
+    S[1] = -(m.q[2] * ((a * b) * (b - a)));
   } else {
     const double lam = m.q[0], it = m.q[1];
     const double U = v[0], p = v[1], P = 1.0 - p * p;
@@ -380,6 +384,11 @@ __device__ __forceinline__ void gen_dsource_row(const GenModel& m, int e, const 
       const double well2 = ((2.0 * ((1.0 - ei) * (1.0 - ei)) - 8.0 * ei * (1.0 - ei)) + 2.0 * (ei * ei)) + 2.0 * al * (e2 - ei * ei);
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[2 + j] = j == i ? L * ((fb - fa) * bm2_hpp(ei) + w * well2) : L * w * 4.0 * al * ei * v[2 + j];
+    }
+  } else if (m.kind == 1) {
+    if (e == 1) {
+      const double a = v[0] - m.q[0], b = m.q[1] - v[0];
+      d[0] = -(m.q[2] * ((b * b - 4.0 * (a * b)) + a * a));  // - f''(c), d_fpp
     }
   } else {
     const double lam = m.q[0], it = m.q[1];
@@ -840,6 +849,8 @@ struct FemBE {
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
+  int gen_nf = 0;                                  // Newton solve by the generic kernels with this many fields (0: the
+                                                   // c / mu / phi kernels: BM6, or BM1 with PFHIP_FEM_CONDENSE=0)
   double* Aloc = nullptr;                          // condensed generic path: (5 nf)^2 local matrix per cell
   size_t vec_len = 0;                              // unknowns in rhs (nb * ng; condensed: nn * nf, corners first)
   bool verbose = false;                            // PFHIP_FEM_VERBOSE=1: residual norm (and line-search data) per iteration
@@ -1013,6 +1024,36 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_BLAS(rocblas_create_handle(&fb->bh));
     FB_BLAS(rocblas_set_stream(fb->bh, stream));
     FB_BLAS(rocblas_set_pointer_mode(fb->bh, rocblas_pointer_mode_host));
+    if (condensed && nf == 2 && rho != 0.0) {
+      // BM1 (bench1.py:60-77): the same two residual blocks written in the generic form, so that the Newton solve runs
+      // on the condensed kernels -- R_c = M (c - c0)/dt + Mob K mu,  R_mu = M mu - kappa K c - int f'(c) lambda
+      GenModel& m = fb->gm;
+      m.id = 0;
+      m.kind = 1;
+      m.nf = 2;
+      for (int e = 0; e < MAXF; ++e) {
+        m.gradc[e] = 0.0;
+        for (int f = 0; f < MAXF; ++f) {
+          m.T[e][f] = m.A[e][f] = m.Kc[e][f] = 0.0;
+          m.nl[e][f] = 0;
+        }
+      }
+      for (double& q : m.q) q = 0.0;
+      for (double& q : m.icp) q = 0.0;
+      m.q[0] = ca;
+      m.q[1] = cb;
+      m.q[2] = 2.0 * rho;
+      m.T[0][0] = 1.0;
+      m.Kc[0][1] = Mob;
+      m.A[1][1] = 1.0;
+      m.Kc[1][0] = -kappa;
+      m.nl[1][0] = 1;
+      fb->u.u[0] = fb->c;
+      fb->u.u[1] = fb->mu;
+      fb->u0.u[0] = fb->c0;
+      fb->u0.u[1] = fb->mu0;
+      fb->gen_nf = 2;
+    }
     return 0;
   };
   int rc = body();
@@ -1052,7 +1093,9 @@ int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, con
   FemBE* fb = *out;
   GenModel& m = fb->gm;
   m.id = model;
+  m.kind = model;
   m.nf = nf;
+  fb->gen_nf = nf;
   for (int e = 0; e < MAXF; ++e) {
     m.gradc[e] = 0.0;
     for (int f = 0; f < MAXF; ++f) {
@@ -1188,10 +1231,10 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
     ~Restore() { f->rhs = r; }
   } restore{fb, rhs_saved};
   FB_HIP(hipMemsetAsync(fb->rhs, 0, sizeof(double) * fb->vec_len, fb->stream));
-  if (fb->gm.id == 2)
+  if (fb->gen_nf == 6)
     hipLaunchKernelGGL(gen_residual_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
                        fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
-  else if (fb->gm.id == 3)
+  else if (fb->gen_nf == 2)
     hipLaunchKernelGGL(gen_residual_kernel<2>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
                        fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
   else
@@ -1365,21 +1408,21 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     if (cp)  // keep -R(u): condensation and the solve overwrite rhs (with the Newton direction d in the end)
       FB_HIP(hipMemcpyAsync(fb->rhs0, fb->rhs, sizeof(double) * fb->vec_len, hipMemcpyDeviceToDevice, fb->stream));
     const int ncell = p.N * p.N;
-    if (fb->gm.id == 2 && p.cond) {
+    if (fb->gen_nf == 6 && p.cond) {
       hipLaunchKernelGGL(gen_cell_jacobian_kernel<6>, dim3((ncell * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
                          fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
       hipLaunchKernelGGL(gen_condense_kernel<6>, dim3((ncell * 24 + 255) / 256), dim3(256), 0, fb->stream, p,
                          (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
-    } else if (fb->gm.id == 3 && p.cond) {
+    } else if (fb->gen_nf == 2 && p.cond) {
       hipLaunchKernelGGL(gen_cell_jacobian_kernel<2>, dim3((ncell * 2 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
                          fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
       hipLaunchKernelGGL(gen_condense_kernel<2>, dim3((ncell * 8 + 255) / 256), dim3(256), 0, fb->stream, p,
                          (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
-    } else if (fb->gm.id == 2) {
+    } else if (fb->gen_nf == 6) {
       hipLaunchKernelGGL(gen_jacobian_kernel<6>, dim3((p.ntri * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
                          fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
       hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
-    } else if (fb->gm.id == 3) {
+    } else if (fb->gen_nf == 2) {
       hipLaunchKernelGGL(gen_jacobian_kernel<2>, dim3((p.ntri * 2 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
                          fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
       hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
@@ -1392,21 +1435,21 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     FB_HIP(hipGetLastError());
     rc = fb->solver == 1 ? block_solve(fb) : block_solve_bcr(fb);
     if (rc) return rc;
-    if (fb->gm.id == 2 && p.cond)
+    if (fb->gen_nf == 6 && p.cond)
       hipLaunchKernelGGL(gen_backsub_kernel<6>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
                          (const double*)fb->Aloc, fb->rhs);
-    else if (fb->gm.id == 3 && p.cond)
+    else if (fb->gen_nf == 2 && p.cond)
       hipLaunchKernelGGL(gen_backsub_kernel<2>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
                          (const double*)fb->Aloc, fb->rhs);
     auto gen_update = [&](double scale) {
-      if (fb->gm.id == 2)
+      if (fb->gen_nf == 6)
         hipLaunchKernelGGL(gen_update_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
                            (const double*)fb->rhs, fb->u, scale);
       else
         hipLaunchKernelGGL(gen_update_kernel<2>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
                            (const double*)fb->rhs, fb->u, scale);
     };
-    if (fb->gm.id) {
+    if (fb->gen_nf) {
       gen_update(1.0);
       if (cp) {
         // SNESLINESEARCHCP (bench2.py:140) with its default single secant iteration, restated from PETSc's
