@@ -1170,9 +1170,7 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
           h->d_phase = 3;
           return a2a(0);
         case 3:
-          SF_CALL(slabfft_z(h->sf, 0));
-          SF_CALL(slabfft_spectral_update_on_T(h->sf, h->d_dt * c.M, h->d_dt * c.M * c.kappa));
-          SF_CALL(slabfft_z(h->sf, 1));
+          SF_CALL(slabfft_z_update(h->sf, h->d_dt * c.M, h->d_dt * c.M * c.kappa));
           h->d_phase = 4;
           return a2a(1);
         default: {

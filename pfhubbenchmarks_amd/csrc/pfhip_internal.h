@@ -88,6 +88,13 @@ int fused_spectrum_pitch(int dim, int nx, int ny, int nz);  // complex elements 
 int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream);
 void fused2d_destroy(Fused2D* f);
 void fused2d_invalidate(Fused2D* f);
+// slab-decomposed transforms: local x / y passes with the all-to-all layout written / read directly, z pass on the
+// transposed layout (spectral2d_fused.hip; used by slabfft.hip when every axis is a power of two in 128..1024)
+bool fusedslab_supported(int nx, int ny, int nz, int P);
+int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double2* A, int nzl, int P, int use_fprime,
+                         double ca, double cb, double two_rho);
+int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out, int nzl, int P);
+int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa);
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
@@ -117,6 +124,7 @@ int slabfft_inverse_local(SlabFFT* sf, double* real_out);
 int slabfft_poisson_on_T(SlabFFT* sf, double k_over_eps);
 int slabfft_store_chat(SlabFFT* sf);
 int slabfft_spectral_update_on_T(SlabFFT* sf, double dtM, double dtMkappa);
+int slabfft_z_update(SlabFFT* sf, double dtM, double dtMkappa);
 int slabfft_grad_energy_local(SlabFFT* sf, double* out_dev);
 const char* slabfft_error(const SlabFFT* sf);
 

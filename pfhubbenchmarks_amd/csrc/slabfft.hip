@@ -21,6 +21,8 @@ constexpr double TWO_PI_S = 6.283185307179586476925286766559;
 
 struct SfGeom {
   int nx, ny, nz, nxh, P, rank, nzl, nyl;
+  int pitch;  // complex elements per k_x row of every spectrum array: nxh (rocFFT path) or the padded pitch of the
+              // hand-written passes (fused_spectrum_pitch); the pad columns are zero and skipped by the k-space kernels
   double h;
 };
 
@@ -49,20 +51,21 @@ __global__ __launch_bounds__(256) void sf_unpack_kernel(const double2* __restric
 }
 
 __device__ __forceinline__ void t_index(const SfGeom& g, int64_t i, int& kx, int& ky, int& kz) {
-  kx = (int)(i % g.nxh);
-  const int yq = (int)((i / g.nxh) % g.nyl);
-  kz = (int)(i / ((int64_t)g.nxh * g.nyl));
+  kx = (int)(i % g.pitch);
+  const int yq = (int)((i / g.pitch) % g.nyl);
+  kz = (int)(i / ((int64_t)g.pitch * g.nyl));
   ky = g.rank * g.nyl + yq;
 }
 
 // Poisson on T: B <- -(k/eps) B / lambda_h / N   (5/7-point eigenvalues; zero mode dropped)
 __global__ __launch_bounds__(256) void sf_poisson_kernel(double2* __restrict__ B, const SfGeom g, double k_over_eps,
                                                          double inv_n) {
-  const int64_t n = (int64_t)g.nz * g.nyl * g.nxh;
+  const int64_t n = (int64_t)g.nz * g.nyl * g.pitch;
   const double inv_h2 = 1.0 / (g.h * g.h);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     int kx, ky, kz;
     t_index(g, i, kx, ky, kz);
+    if (kx >= g.nxh) continue;
     double lam = (2.0 * cos(TWO_PI_S * kx / g.nx) - 2.0) + (2.0 * cos(TWO_PI_S * ky / g.ny) - 2.0);
     lam += 2.0 * cos(TWO_PI_S * kz / g.nz) - 2.0;
     lam *= inv_h2;
@@ -85,8 +88,9 @@ __device__ __forceinline__ double t_ksq(const SfGeom& g, int64_t i) {
 __global__ __launch_bounds__(256) void sf_spectral_update_kernel(double2* __restrict__ chat, double2* __restrict__ B,
                                                                  const SfGeom g, double dtM, double dtMkappa,
                                                                  double inv_n) {
-  const int64_t n = (int64_t)g.nz * g.nyl * g.nxh;
+  const int64_t n = (int64_t)g.nz * g.nyl * g.pitch;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if ((int)(i % g.pitch) >= g.nxh) continue;
     const double k2 = t_ksq(g, i);
     const double num = dtM * k2;
     const double den = 1.0 / fma(dtMkappa, k2 * k2, 1.0);
@@ -103,10 +107,11 @@ __global__ __launch_bounds__(256) void sf_spectral_update_kernel(double2* __rest
 __global__ __launch_bounds__(256) void sf_grad_energy_kernel(const double2* __restrict__ chat, const SfGeom g,
                                                              double* __restrict__ partials) {
   __shared__ double sh[4];
-  const int64_t n = (int64_t)g.nz * g.nyl * g.nxh;
+  const int64_t n = (int64_t)g.nz * g.nyl * g.pitch;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int kx = (int)(i % g.nxh);
+    const int kx = (int)(i % g.pitch);
+    if (kx >= g.nxh) continue;
     const double w = (kx == 0 || 2 * kx == g.nx) ? 1.0 : 2.0;
     const double2 c = chat[i];
     acc += w * t_ksq(g, i) * (c.x * c.x + c.y * c.y);
@@ -150,6 +155,7 @@ struct SlabFFT {
   int64_t blk;  // complex elements per peer block
   hipfftHandle p2f = 0, p2i = 0, pz = 0;
   bool have_plans = false;
+  Fused2D* fast = nullptr;  // power-of-two boxes: the hand-written LDS-FFT passes instead of rocFFT + pack / unpack
   double2 *tmp = nullptr, *A = nullptr, *B = nullptr, *chat = nullptr;
   bool own_ab = false;
   double *greal = nullptr, *partials = nullptr;
@@ -181,7 +187,8 @@ double* slabfft_buf(const SlabFFT* sf, int which) { return reinterpret_cast<doub
 // doubles each of the two all-to-all buffers must hold (pure host arithmetic; <0 if the box does not divide)
 int64_t slabfft_buffer_doubles(int nx, int ny, int nz, int P) {
   if (P < 1 || ny % P || nz % P) return -1;
-  return 2 * (int64_t)(nz / P) * ny * (nx / 2 + 1);
+  const int pitch = fusedslab_supported(nx, ny, nz, P) ? fused_spectrum_pitch(3, nx, ny, nz) : nx / 2 + 1;
+  return 2 * (int64_t)(nz / P) * ny * pitch;
 }
 
 int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, double h, bool with_spectral, double* extA,
@@ -204,19 +211,28 @@ int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, doubl
     }
     g.nzl = nz / P;
     g.nyl = ny / P;
-    sf->blk = (int64_t)g.nzl * g.nyl * g.nxh;
-    int n2[2] = {ny, nx};
-    SF_FFT(hipfftPlanMany(&sf->p2f, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, g.nzl));
-    SF_FFT(hipfftPlanMany(&sf->p2i, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, g.nzl));
-    int n1[1] = {nz};
-    int emb[1] = {nz};
-    const int stride = g.nyl * g.nxh;
-    SF_FFT(hipfftPlanMany(&sf->pz, 1, n1, emb, stride, 1, emb, stride, 1, HIPFFT_Z2Z, stride));
-    sf->have_plans = true;
-    SF_FFT(hipfftSetStream(sf->p2f, stream));
-    SF_FFT(hipfftSetStream(sf->p2i, stream));
-    SF_FFT(hipfftSetStream(sf->pz, stream));
-    const size_t loc = sizeof(double2) * (size_t)g.nzl * ny * g.nxh;
+    const bool fast = fusedslab_supported(nx, ny, nz, P);
+    g.pitch = fast ? fused_spectrum_pitch(3, nx, ny, nz) : g.nxh;
+    sf->blk = (int64_t)g.nzl * g.nyl * g.pitch;
+    if (fast) {
+      if (fused2d_create(&sf->fast, nx, ny, nz, h, stream) != 0) {
+        sf->err = "fused2d_create failed";
+        return -3;
+      }
+    } else {
+      int n2[2] = {ny, nx};
+      SF_FFT(hipfftPlanMany(&sf->p2f, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, g.nzl));
+      SF_FFT(hipfftPlanMany(&sf->p2i, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, g.nzl));
+      int n1[1] = {nz};
+      int emb[1] = {nz};
+      const int stride = g.nyl * g.nxh;
+      SF_FFT(hipfftPlanMany(&sf->pz, 1, n1, emb, stride, 1, emb, stride, 1, HIPFFT_Z2Z, stride));
+      sf->have_plans = true;
+      SF_FFT(hipfftSetStream(sf->p2f, stream));
+      SF_FFT(hipfftSetStream(sf->p2i, stream));
+      SF_FFT(hipfftSetStream(sf->pz, stream));
+    }
+    const size_t loc = sizeof(double2) * (size_t)g.nzl * ny * g.pitch;
     SF_HIP(hipMalloc(&sf->tmp, loc));
     if (extA && extB) {
       sf->A = reinterpret_cast<double2*>(extA);
@@ -229,7 +245,13 @@ int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, doubl
     SF_HIP(hipMalloc(&sf->partials, sizeof(double) * 2049));
     if (with_spectral) {
       SF_HIP(hipMalloc(&sf->chat, loc));
-      SF_HIP(hipMalloc(&sf->greal, sizeof(double) * (size_t)g.nzl * ny * nx));
+      if (!fast) SF_HIP(hipMalloc(&sf->greal, sizeof(double) * (size_t)g.nzl * ny * nx));
+    }
+    if (fast) {  // the passes never write the pad columns: keep them zero in every array they travel through
+      SF_HIP(hipMemsetAsync(sf->tmp, 0, loc, stream));
+      SF_HIP(hipMemsetAsync(sf->A, 0, loc, stream));
+      SF_HIP(hipMemsetAsync(sf->B, 0, loc, stream));
+      if (sf->chat) SF_HIP(hipMemsetAsync(sf->chat, 0, loc, stream));
     }
     return 0;
   };
@@ -245,6 +267,7 @@ void slabfft_destroy(SlabFFT* sf) {
     (void)hipfftDestroy(sf->p2i);
     (void)hipfftDestroy(sf->pz);
   }
+  if (sf->fast) fused2d_destroy(sf->fast);
   if (sf->tmp) (void)hipFree(sf->tmp);
   if (sf->own_ab) {
     if (sf->A) (void)hipFree(sf->A);
@@ -258,6 +281,13 @@ void slabfft_destroy(SlabFFT* sf) {
 
 // real slab (nzl contiguous planes) -> A, ready for the all-to-all A -> B
 int slabfft_forward_local(SlabFFT* sf, const double* real_in) {
+  if (sf->fast) {
+    if (fusedslab_forward_xy(sf->fast, real_in, sf->tmp, sf->A, sf->g.nzl, sf->g.P, 0, 0.0, 0.0, 0.0) != 0) {
+      sf->err = "fusedslab_forward_xy launch failed";
+      return -3;
+    }
+    return 0;
+  }
   const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nxh;
   SF_FFT(hipfftExecD2Z(sf->p2f, const_cast<double*>(real_in), reinterpret_cast<hipfftDoubleComplex*>(sf->tmp)));
   hipLaunchKernelGGL(sf_pack_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, (const double2*)sf->tmp, sf->A, sf->g);
@@ -266,17 +296,38 @@ int slabfft_forward_local(SlabFFT* sf, const double* real_in) {
 }
 // same for f'(c) of the slab (spectral scheme)
 int slabfft_forward_local_dfdc(SlabFFT* sf, const double* c, double ca, double cb, double two_rho) {
+  if (sf->fast) {  // f'(c) is evaluated inside the row kernel
+    if (fusedslab_forward_xy(sf->fast, c, sf->tmp, sf->A, sf->g.nzl, sf->g.P, 1, ca, cb, two_rho) != 0) {
+      sf->err = "fusedslab_forward_xy launch failed";
+      return -3;
+    }
+    return 0;
+  }
   const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nx;
   hipLaunchKernelGGL(sf_dfdc_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, c, sf->greal, n, ca, cb, two_rho);
   return slabfft_forward_local(sf, sf->greal);
 }
 int slabfft_z(SlabFFT* sf, int inverse) {
+  if (sf->fast) {
+    if (fusedslab_z(sf->fast, sf->B, nullptr, inverse ? 1 : 0, sf->g.nyl, sf->g.rank * sf->g.nyl, 0.0, 0.0) != 0) {
+      sf->err = "fusedslab_z launch failed";
+      return -3;
+    }
+    return 0;
+  }
   SF_FFT(hipfftExecZ2Z(sf->pz, reinterpret_cast<hipfftDoubleComplex*>(sf->B),
                        reinterpret_cast<hipfftDoubleComplex*>(sf->B), inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
   return 0;
 }
 // A (after the all-to-all B -> A) -> real slab
 int slabfft_inverse_local(SlabFFT* sf, double* real_out) {
+  if (sf->fast) {
+    if (fusedslab_inverse_yx(sf->fast, sf->A, sf->tmp, real_out, sf->g.nzl, sf->g.P) != 0) {
+      sf->err = "fusedslab_inverse_yx launch failed";
+      return -3;
+    }
+    return 0;
+  }
   const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nxh;
   hipLaunchKernelGGL(sf_unpack_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, (const double2*)sf->A, sf->tmp, sf->g);
   SF_FFT(hipfftExecZ2D(sf->p2i, reinterpret_cast<hipfftDoubleComplex*>(sf->tmp), real_out));
@@ -284,28 +335,42 @@ int slabfft_inverse_local(SlabFFT* sf, double* real_out) {
   return 0;
 }
 int slabfft_poisson_on_T(SlabFFT* sf, double k_over_eps) {
-  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.nxh;
+  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.pitch;
   const double inv_n = 1.0 / ((double)sf->g.nx * sf->g.ny * sf->g.nz);
   hipLaunchKernelGGL(sf_poisson_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, sf->B, sf->g, k_over_eps, inv_n);
   SF_HIP(hipGetLastError());
   return 0;
 }
 int slabfft_store_chat(SlabFFT* sf) {  // B (spectrum of c on T) -> resident chat
-  SF_HIP(hipMemcpyAsync(sf->chat, sf->B, sizeof(double2) * (size_t)sf->g.nz * sf->g.nyl * sf->g.nxh,
+  SF_HIP(hipMemcpyAsync(sf->chat, sf->B, sizeof(double2) * (size_t)sf->g.nz * sf->g.nyl * sf->g.pitch,
                         hipMemcpyDeviceToDevice, sf->stream));
   return 0;
 }
 int slabfft_spectral_update_on_T(SlabFFT* sf, double dtM, double dtMkappa) {
-  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.nxh;
+  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.pitch;
   const double inv_n = 1.0 / ((double)sf->g.nx * sf->g.ny * sf->g.nz);
   hipLaunchKernelGGL(sf_spectral_update_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, sf->chat, sf->B, sf->g, dtM,
                      dtMkappa, inv_n);
   SF_HIP(hipGetLastError());
   return 0;
 }
+// forward z transform of B (ghat on T) -> k-space update of the resident chat -> inverse z transform of chat / N in B
+int slabfft_z_update(SlabFFT* sf, double dtM, double dtMkappa) {
+  if (sf->fast) {  // one pass: the z columns stay in LDS between the two transforms
+    if (fusedslab_z(sf->fast, sf->B, sf->chat, 2, sf->g.nyl, sf->g.rank * sf->g.nyl, dtM, dtMkappa) != 0) {
+      sf->err = "fusedslab_z launch failed";
+      return -3;
+    }
+    return 0;
+  }
+  int rc = slabfft_z(sf, 0);
+  if (rc == 0) rc = slabfft_spectral_update_on_T(sf, dtM, dtMkappa);
+  if (rc == 0) rc = slabfft_z(sf, 1);
+  return rc;
+}
 // this rank's share of sum_k w_k k^2 |chat_k|^2 -> out_dev[0]
 int slabfft_grad_energy_local(SlabFFT* sf, double* out_dev) {
-  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.nxh;
+  const int64_t n = (int64_t)sf->g.nz * sf->g.nyl * sf->g.pitch;
   const int nb = sf_grid(n);
   hipLaunchKernelGGL(sf_grad_energy_kernel, dim3(nb), dim3(256), 0, sf->stream, (const double2*)sf->chat, sf->g,
                      sf->partials);

@@ -38,7 +38,20 @@ struct F2Args {
   int nz = 1;        // 3-D path (512^3) only
   double kz0 = 0.0;
   double gam = 0.0;  // BM6: dt M k_c^2 / eps added to the implicit denominator for k != 0
+  int yoff = 0;      // slab-decomposed z pass: global k_y index of the first local y-row
 };
+
+// Column passes of the slab-decomposed transforms (csrc/slabfft.hip) move their columns between the natural layout
+// [batch][row][kx] and the all-to-all layout [row / split][batch][row % split][kx] on the fly: element r of the column of
+// batch b sits at (r >> lg) * chunk + b * bstride + (r & (2^lg - 1)) * col_stride + kx.  on = 1: the store side of a
+// MODE 0 pass (written to H instead of in place); on = 2: the load side of a MODE 1 pass (read from A, written to H).
+struct ColSplit {
+  int on = 0, lg = 0;
+  int64_t chunk = 0, bstride = 0;
+};
+__device__ __forceinline__ int64_t split_addr(const ColSplit& sp, int b, int kx, int r, int64_t col_stride) {
+  return (int64_t)(r >> sp.lg) * sp.chunk + (int64_t)b * sp.bstride + (int64_t)(r & ((1 << sp.lg) - 1)) * col_stride + kx;
+}
 
 __device__ __forceinline__ int brev(int i, int lg) { return (int)(__brev((unsigned)i) >> (32 - lg)); }
 // LDS index skew: one 16-byte pad slot every 32 elements, so the power-of-two strides of bit-reversed and butterfly
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
                                                              double2* __restrict__ chat, double2* __restrict__ H,
                                                              int64_t col_stride, int64_t batch_stride, int nblk,
                                                              int nitems, const double2* __restrict__ twA_g,
-                                                             const double2* __restrict__ twB_g) {
+                                                             const double2* __restrict__ twB_g, const ColSplit sp) {
   __shared__ __attribute__((aligned(16))) double2 Lall[CW3 * W8C];
   constexpr int N = 512, NT = 64 * CW3, PER = 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -609,7 +622,8 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int r = (tid + NT * i) / CW3;
-      v[i] = on ? A[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+      const int64_t src = (MODE == 1 && sp.on == 2) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+      v[i] = on ? A[src] : make_double2(0.0, 0.0);
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) Lc[nat((tid + NT * i) / CW3)] = v[i];
@@ -666,15 +680,17 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
         if (on) A[base + (int64_t)r * col_stride] = Lc[nat(r)];
       }
     } else if (MODE == 0 || MODE == 1 || MODE == 3) {
-      double2* dst = MODE == 3 ? chat : A;
+      double2* dst = MODE == 3 ? chat : (sp.on ? H : A);
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        if (on) dst[base + (int64_t)r * col_stride] = Lc[nat(r)];
+        const int64_t di = (MODE == 0 && sp.on == 1) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+        if (on) dst[di] = Lc[nat(r)];
       }
     } else {
-      // MODE 2: this is the z pass -- b is the y index, the row along the column is k_z
-      const int my = 2 * b > a.ny ? b - a.ny : b;
+      // MODE 2: this is the z pass -- b is the (local) y index, the row along the column is k_z
+      const int gy = b + a.yoff;
+      const int my = 2 * gy > a.ny ? gy - a.ny : gy;
       const double kxv = a.kx0 * kx, kyv = a.ky0 * my;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
@@ -716,7 +732,8 @@ template <int MODE, int CWG, int G, int NMAX>  // G threads per column, axis len
 __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, double2* __restrict__ A,
                                                           double2* __restrict__ chat, double2* __restrict__ H,
                                                           int64_t col_stride, int64_t batch_stride, int nblk, int nitems,
-                                                          int N, int lg, const double2* __restrict__ tw_g) {
+                                                          int N, int lg, const double2* __restrict__ tw_g,
+                                                          const ColSplit sp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int NP = px(N) + 1;
   double2* X = reinterpret_cast<double2*>(smem_raw);  // [CWG][NP]
@@ -735,7 +752,8 @@ __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, doub
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int r = (tid + NT * i) / CWG;
-    if (r < N) X[ci * NP + px(brev(r, lg))] = on ? A[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+    const int64_t src = (MODE == 1 && sp.on == 2) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+    if (r < N) X[ci * NP + px(brev(r, lg))] = on ? A[src] : make_double2(0.0, 0.0);
   }
   __syncthreads();
   if (MODE == 1)
@@ -743,17 +761,19 @@ __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, doub
   else
     fft_inplace<-1, G, NMAX>(X + wave * NP, TW, N, lg, lane);
   if (MODE == 0 || MODE == 1 || MODE == 3) {
-    double2* dst = MODE == 3 ? chat : A;
+    double2* dst = MODE == 3 ? chat : (sp.on ? H : A);
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       const int r = (tid + NT * i) / CWG;
-      if (r < N && on) dst[base + (int64_t)r * col_stride] = X[ci * NP + px(r)];
+      const int64_t di = (MODE == 0 && sp.on == 1) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+      if (r < N && on) dst[di] = X[ci * NP + px(r)];
     }
     return;
   }
   double2 o[MAXP];
-  if (MODE == 2) {  // z pass: b is the y index, the row along the column is k_z
-    const int my = 2 * b > a.ny ? b - a.ny : b;
+  if (MODE == 2) {  // z pass: b is the (local) y index, the row along the column is k_z
+    const int gy = b + a.yoff;
+    const int my = 2 * gy > a.ny ? gy - a.ny : gy;
     const double kxv = a.kx0 * kx, kyv = a.ky0 * my;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
@@ -1004,60 +1024,76 @@ void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const doub
     hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny * a.nz / 2), dim3(RT), f->lds_row, f->stream, a, H, c_in, c_out, G,
                        (const double2*)f->twx, from_spectrum, use_fprime);
 }
-template <int MODE, int CWG, int G, int NMAX>
-void launch_col3_g(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
-  const int nblk = (a.nxh + CWG - 1) / CWG;
+// where the columns of a pass live: N points along the column, nbatch batches of ceil(nxh / CW) column blocks
+struct ColGeom {
+  int N, lg;
+  const double2* tw;
+  int64_t col_stride, batch_stride;
+  int nbatch;
+  ColSplit sp;
+};
+ColGeom axis_geom(const Fused2D* f, const F2Args& a, int axis) {
   const int64_t row = a.pitch, plane = (int64_t)a.pitch * a.ny;
-  const int64_t col_stride = axis == 1 ? row : plane, batch_stride = axis == 1 ? plane : row;
-  const int nbatch = axis == 1 ? a.nz : a.ny, N = axis == 1 ? a.ny : a.nz, lg = axis == 1 ? a.lgy : f->lgz;
-  const size_t lds = sizeof(double2) * ((size_t)CWG * (N + N / 32 + 1) + N / 2);
-  hipLaunchKernelGGL((f3_col_kernel<MODE, CWG, G, NMAX>), dim3(nblk * nbatch), dim3(G * CWG), lds, f->stream, a, A, chat, H,
-                     col_stride, batch_stride, nblk, nblk * nbatch, N, lg,
-                     (const double2*)(axis == 1 ? f->twy : f->twz));
+  ColGeom g;
+  // axis 1: columns along y (stride one x-row), one batch per z-plane; axis 2: columns along z, one batch per y-row
+  g.N = axis == 1 ? a.ny : a.nz;
+  g.lg = axis == 1 ? a.lgy : f->lgz;
+  g.tw = axis == 1 ? f->twy : f->twz;
+  g.col_stride = axis == 1 ? row : plane;
+  g.batch_stride = axis == 1 ? plane : row;
+  g.nbatch = axis == 1 ? a.nz : a.ny;
+  return g;
+}
+template <int MODE, int CWG, int G, int NMAX>
+void launch_col3_g(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
+  const int nblk = (a.nxh + CWG - 1) / CWG;
+  const size_t lds = sizeof(double2) * ((size_t)CWG * (g.N + g.N / 32 + 1) + g.N / 2);
+  hipLaunchKernelGGL((f3_col_kernel<MODE, CWG, G, NMAX>), dim3(nblk * g.nbatch), dim3(G * CWG), lds, f->stream, a, A, chat,
+                     H, g.col_stride, g.batch_stride, nblk, nblk * g.nbatch, g.N, g.lg, g.tw, g.sp);
 }
 template <int MODE, int CW3>
-void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
+void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
   const int nblk = (a.nxh + CW3 - 1) / CW3;
-  const int64_t row = a.pitch, plane = (int64_t)a.pitch * a.ny;
-  // axis 1: columns along y (stride one x-row), one batch per z-plane; axis 2: columns along z, one batch per y-row
-  const int64_t col_stride = axis == 1 ? row : plane, batch_stride = axis == 1 ? plane : row;
-  const int nbatch = axis == 1 ? a.nz : a.ny;
-  const int nitems = nblk * nbatch;
+  const int nitems = nblk * g.nbatch;
   if (MODE == 2 && g_zearly)
     hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, true>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                       col_stride, batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b);
+                       g.col_stride, g.batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, g.sp);
   else
     hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, false>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                       col_stride, batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b);
+                       g.col_stride, g.batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, g.sp);
 }
 template <int MODE>
-void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
-  // measured after the aligned pitch (rocprofv3, 512^3): z pass 999 us with 4 columns per workgroup (4 workgroups of 4
-  // waves per CU) vs 1073 us with 8; y passes 441-452 us with 8 vs 466-471 us with 4
-  const int N = axis == 1 ? a.ny : a.nz;
+void launch_col3_geom(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
+  const int N = g.N;
   if (N != 512 || g_generic512) {
     if (N == 512) {
       if (g_cwg == 4)
-        launch_col3_g<MODE, 4, 128, 512>(f, a, A, chat, H, axis);
+        launch_col3_g<MODE, 4, 128, 512>(f, a, A, chat, H, g);
       else
-        launch_col3_g<MODE, 8, 128, 512>(f, a, A, chat, H, axis);
+        launch_col3_g<MODE, 8, 128, 512>(f, a, A, chat, H, g);
       return;
     }
     // columns per workgroup, measured at 256^3: 8 -> 0.363 ms per step, 4 -> 0.379 (rocFFT path 0.578)
     const int cwg = g_cwg ? g_cwg : 8;
     if (N > 512)  // 4 columns of 1024 points: 76 KB of LDS, 1024 threads
-      launch_col3_g<MODE, 4, 256, 1024>(f, a, A, chat, H, axis);
+      launch_col3_g<MODE, 4, 256, 1024>(f, a, A, chat, H, g);
     else if (cwg == 8)
-      launch_col3_g<MODE, 8, 64, 256>(f, a, A, chat, H, axis);
+      launch_col3_g<MODE, 8, 64, 256>(f, a, A, chat, H, g);
     else
-      launch_col3_g<MODE, 4, 64, 256>(f, a, A, chat, H, axis);
+      launch_col3_g<MODE, 4, 64, 256>(f, a, A, chat, H, g);
     return;
   }
+  // measured after the aligned pitch (rocprofv3, 512^3): z pass 999 us with 4 columns per workgroup (4 workgroups of 4
+  // waves per CU) vs 1073 us with 8; y passes 441-452 us with 8 vs 466-471 us with 4
   const int cw = g_cw3 ? g_cw3 : ((MODE == 2 || MODE == 4 || MODE == 3) ? 4 : 8);
   if (cw == 4)
-    launch_col3_t<MODE, 4>(f, a, A, chat, H, axis);
+    launch_col3_t<MODE, 4>(f, a, A, chat, H, g);
   else
-    launch_col3_t<MODE, 8>(f, a, A, chat, H, axis);
+    launch_col3_t<MODE, 8>(f, a, A, chat, H, g);
+}
+template <int MODE>
+void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
+  launch_col3_geom<MODE>(f, a, A, chat, H, axis_geom(f, a, axis));
 }
 }  // namespace
 
@@ -1128,6 +1164,69 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
   launch_col(f, a, G, chat, H, 0);
   launch_row(f, a, H, nullptr, c_out, G, 1, 1);
   f->g_valid = true;
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---- slab-decomposed transforms (csrc/slabfft.hip) ----------------------------------------------------------------------
+// The local passes of a rank that owns nzl z-planes for the x and y transforms and, after the all-to-all, nyl = ny / P
+// y-rows of every z-plane for the z transform ("T" layout [z][yq][kx]).  Every spectrum array uses the padded pitch.
+bool fusedslab_supported(int nx, int ny, int nz, int P) {
+  return P >= 1 && ny % P == 0 && nz % P == 0 && ilog2(P) >= 0 && fused2d_supported(3, nx, ny, nz);
+}
+namespace {
+ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
+  ColGeom g = axis_geom(f, a, 1);  // a.nz == nzl: one batch per local plane
+  const int nyl = a.ny / P;
+  g.sp.on = on;
+  g.sp.lg = ilog2(nyl);
+  g.sp.chunk = (int64_t)nzl * nyl * a.pitch;
+  g.sp.bstride = (int64_t)nyl * a.pitch;
+  return g;
+}
+}  // namespace
+// real planes -> x rows (of f'(c) if use_fprime) -> tmp [zl][y][kx] -> y columns -> A [q][zl][yq][kx] (all-to-all layout)
+int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double2* A, int nzl, int P, int use_fprime,
+                         double ca, double cb, double two_rho) {
+  F2Args a = f->a;
+  a.nz = nzl;
+  a.ca = ca;
+  a.cb = cb;
+  a.two_rho = two_rho;
+  launch_row3(f, a, nullptr, real_in, nullptr, tmp, 0, use_fprime);
+  launch_col3_geom<0>(f, a, tmp, nullptr, A, slab_y_geom(f, a, nzl, P, 1));
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// A [q][zl][yq][kx] -> inverse y columns -> tmp [zl][y][kx] -> inverse x rows -> real planes
+int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out, int nzl, int P) {
+  F2Args a = f->a;
+  a.nz = nzl;
+  launch_col3_geom<1>(f, a, A, nullptr, tmp, slab_y_geom(f, a, nzl, P, 2));
+  launch_row3(f, a, tmp, nullptr, real_out, nullptr, 2, 0);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+// z columns of B (T layout, nyl local y-rows starting at global row yoff), in place.  mode 0: forward; 1: inverse
+// (unnormalised); 2: forward -> k-space update of the resident chat -> inverse of chat / N; 3: forward, stored to chat.
+int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa) {
+  F2Args a = f->a;
+  a.yoff = yoff;
+  a.dtM = dtM;
+  a.dtMkappa = dtMkappa;
+  a.gam = 0.0;
+  ColGeom g;
+  g.N = a.nz;
+  g.lg = f->lgz;
+  g.tw = f->twz;
+  g.col_stride = (int64_t)nyl * a.pitch;
+  g.batch_stride = a.pitch;
+  g.nbatch = nyl;
+  if (mode == 0)
+    launch_col3_geom<0>(f, a, B, nullptr, nullptr, g);
+  else if (mode == 1)
+    launch_col3_geom<1>(f, a, B, nullptr, nullptr, g);
+  else if (mode == 2)
+    launch_col3_geom<2>(f, a, B, chat, B, g);
+  else
+    launch_col3_geom<3>(f, a, B, chat, nullptr, g);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -1068,16 +1068,17 @@ def _lockstep(engs, op, dt=0.0):
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,P", [((64, 24, 16), 2), ((128, 128, 128), 2), ((128, 256, 512), 4), ((512, 128, 128), 1)])
 @pytest.mark.parametrize("mode", ["spectral", "bm6"])
-def test_fft_slab_modes_on_one_gpu(lib, mode):
-    """slab FFT modes (pf_dist_begin / pf_dist_advance): two rank handles on the one GPU, collectives emulated by
-    copies, against the single-domain numpy oracles"""
+def test_fft_slab_modes_on_one_gpu(lib, mode, n, P):
+    """slab FFT modes (pf_dist_begin / pf_dist_advance): P rank handles on the one GPU, collectives emulated by
+    copies, against the single-domain numpy oracles.  (64, 24, 16): rocFFT + pack / unpack kernels; the power-of-two
+    boxes: the hand-written LDS-FFT passes with the all-to-all layout written / read by the y pass itself
+    (fusedslab_*: radix-2^2 and radix-8 column kernels, 2 / 4 ranks and the single-rank ring)."""
     from oracle import bm6_fd, ch_spectral
     from pfhubbenchmarks_amd.solver import HipFFTSlabEngine
-    n = (64, 24, 16)
     rng = np.random.default_rng(31)
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
-    P = 2
     engs = [HipFFTSlabEngine(n, 1.0, P, r, 0, scheme="spectral" if mode == "spectral" else "fd",
                              model="bm6" if mode == "bm6" else "bm1") for r in range(P)]
     for e in engs:
