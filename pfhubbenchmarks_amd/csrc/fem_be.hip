@@ -702,6 +702,198 @@ __global__ __launch_bounds__(256) void gen_backsub_kernel(const FemParams p, con
   for (int k = 0; k < NF; ++k) rm[k] = t[k];
 }
 
+// ---- level 0 of the cyclic reduction on the condensed system: the blocks are still banded ---------------------------
+// Before any fill-in a corner row's diagonal block D_e and its couplings L_e, U_e are block tridiagonal with NF x NF
+// blocks (corner l couples to l - 1, l, l + 1 of its own and of the adjacent rows).  The first level -- half of all the
+// eliminations -- therefore needs no dense LU: D_e^-1 [L_e | U_e | r_e] is a block Thomas sweep per right-hand-side
+// column, and the products with the banded L_k / U_k touch 3 NF entries per row.
+// fac: per matrix and corner l the three NF x NF blocks S_l^-1, G_l = S_l^-1 C_l, A_l  (S_l = B_l - A_l G_(l-1)).
+template <int NF>
+__device__ __forceinline__ void small_inverse(double (&S)[NF][NF], double (&Z)[NF][NF]) {  // Gauss-Jordan, partial pivoting
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) Z[a][b] = a == b ? 1.0 : 0.0;
+#pragma unroll
+  for (int c = 0; c < NF; ++c) {
+    int pr = c;
+    double pv = fabs(S[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < NF; ++r)
+      if (fabs(S[r][c]) > pv) {
+        pv = fabs(S[r][c]);
+        pr = r;
+      }
+#pragma unroll
+    for (int r = c + 1; r < NF; ++r)
+      if (r == pr) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          double t = S[r][k];
+          S[r][k] = S[c][k];
+          S[c][k] = t;
+          t = Z[r][k];
+          Z[r][k] = Z[c][k];
+          Z[c][k] = t;
+        }
+      }
+    const double inv = 1.0 / S[c][c];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      S[c][k] *= inv;
+      Z[c][k] *= inv;
+    }
+#pragma unroll
+    for (int r = 0; r < NF; ++r)
+      if (r != c) {
+        const double fac = S[r][c];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          S[r][k] -= fac * S[c][k];
+          Z[r][k] -= fac * Z[c][k];
+        }
+      }
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(64) void row_factor_kernel(int nb, int n1, const double* __restrict__ D, int64_t stride,
+                                                        int nmat, double* __restrict__ fac) {
+  const int m = blockIdx.x * 64 + threadIdx.x;  // one thread per matrix: n1 dependent NF x NF steps
+  if (m >= nmat) return;
+  const double* De = D + (int64_t)m * stride;
+  double* F = fac + (int64_t)m * n1 * 3 * NF * NF;
+  double G[NF][NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) G[a][b] = 0.0;
+  for (int l = 0; l < n1; ++l) {
+    double S[NF][NF], A[NF][NF], Z[NF][NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        S[a][b] = De[(l * NF + a) + (int64_t)(l * NF + b) * nb];
+        A[a][b] = l > 0 ? De[(l * NF + a) + (int64_t)((l - 1) * NF + b) * nb] : 0.0;
+      }
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        double acc = S[a][b];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) acc -= A[a][k] * G[k][b];
+        S[a][b] = acc;
+      }
+    small_inverse<NF>(S, Z);
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        double acc = 0.0;
+        if (l + 1 < n1) {
+#pragma unroll
+          for (int k = 0; k < NF; ++k) acc += Z[a][k] * De[(l * NF + k) + (int64_t)((l + 1) * NF + b) * nb];
+        }
+        S[a][b] = acc;  // G_l
+      }
+    double* Fl = F + (int64_t)l * 3 * NF * NF;
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        Fl[a * NF + b] = Z[a][b];
+        Fl[NF * NF + a * NF + b] = S[a][b];
+        Fl[2 * NF * NF + a * NF + b] = A[a][b];
+        G[a][b] = S[a][b];
+      }
+  }
+}
+
+// one thread per (matrix, right-hand-side column): columns 0..nb-1 of L_e, nb..2nb-1 of U_e, 2nb = r_e; in place
+template <int NF>
+__global__ __launch_bounds__(256) void row_solve_kernel(int nb, int n1, const double* __restrict__ fac, double* Lm,
+                                                        double* Um, double* rv, int64_t stride_mat,
+                                                        int64_t stride_vec) {
+  const int j = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+  if (j > 2 * nb) return;
+  double* col = j < nb ? Lm + (int64_t)m * stride_mat + (int64_t)j * nb
+                       : (j < 2 * nb ? Um + (int64_t)m * stride_mat + (int64_t)(j - nb) * nb : rv + (int64_t)m * stride_vec);
+  const double* F = fac + (int64_t)m * n1 * 3 * NF * NF;
+  // a coupling column is zero above corner (its own corner - 1): the forward sweep starts there
+  const int l0 = j < 2 * nb ? max(0, (j % nb) / NF - 1) : 0;
+  double y[NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a) y[a] = 0.0;
+  for (int l = l0; l < n1; ++l) {
+    const double* Fl = F + (int64_t)l * 3 * NF * NF;
+    double t[NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      double acc = col[l * NF + a];
+#pragma unroll
+      for (int b = 0; b < NF; ++b) acc -= Fl[2 * NF * NF + a * NF + b] * y[b];
+      t[a] = acc;
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      double acc = 0.0;
+#pragma unroll
+      for (int b = 0; b < NF; ++b) acc += Fl[a * NF + b] * t[b];
+      y[a] = acc;
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a) col[l * NF + a] = y[a];
+  }
+  for (int l = n1 - 2; l >= 0; --l) {  // y holds x_(l+1)
+    const double* Fl = F + (int64_t)l * 3 * NF * NF;
+    double x[NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      double acc = col[l * NF + a];
+#pragma unroll
+      for (int b = 0; b < NF; ++b) acc -= Fl[NF * NF + a * NF + b] * y[b];
+      x[a] = acc;
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      col[l * NF + a] = x[a];
+      y[a] = x[a];
+    }
+  }
+}
+
+// C = beta C + alpha Lb X for a block-tridiagonal Lb (dense column-major storage, nonzeros of row r in columns
+// [(r / NF - 1) NF, (r / NF + 2) NF)); one thread per (row, strip of 8 columns), grid.z = matrix
+template <int NF>
+__global__ __launch_bounds__(256) void band_gemm_kernel(int nb, const double* __restrict__ Lb, int64_t strideL,
+                                                        const double* __restrict__ X, int64_t strideX, double* C,
+                                                        int64_t strideC, double alpha, double beta) {
+  const int r = blockIdx.x * 256 + threadIdx.x, m = blockIdx.z;
+  if (r >= nb) return;
+  const int c0 = (r / NF - 1) * NF;
+  const double* Lm = Lb + (int64_t)m * strideL;
+  double lv[3 * NF];
+#pragma unroll
+  for (int k = 0; k < 3 * NF; ++k) {
+    const int c = c0 + k;
+    lv[k] = (c >= 0 && c < nb) ? Lm[r + (int64_t)c * nb] : 0.0;
+  }
+  const double* Xm = X + (int64_t)m * strideX;
+  double* Cm = C + (int64_t)m * strideC;
+  for (int j = blockIdx.y * 8; j < min(nb, blockIdx.y * 8 + 8); ++j) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3 * NF; ++k) {
+      const int c = c0 + k;
+      if (c >= 0 && c < nb) acc += lv[k] * Xm[c + (int64_t)j * nb];
+    }
+    double* out = Cm + r + (int64_t)j * nb;
+    *out = beta == 0.0 ? alpha * acc : beta * *out + alpha * acc;
+  }
+}
+
 template <int NF>
 __global__ __launch_bounds__(256) void gen_update_kernel(const FemParams p, const double* __restrict__ sol, FieldPtrs u,
                                                          double scale) {
@@ -849,6 +1041,8 @@ struct FemBE {
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
+  bool band0 = false;                              // condensed generic path: first reduction level by the banded kernels
+  double* fac = nullptr;                           // its block-Thomas factors: (ng / 2) * n1 * 3 * nf^2
   int gen_nf = 0;                                  // Newton solve by the generic kernels with this many fields (0: the
                                                    // c / mu / phi kernels: BM6, or BM1 with PFHIP_FEM_CONDENSE=0)
   double* Aloc = nullptr;                          // condensed generic path: (5 nf)^2 local matrix per cell
@@ -1015,7 +1209,12 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     }
     fb->vec_len = condensed ? (size_t)p.nn * nf : (size_t)p.nb * p.ng;
     FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * fb->vec_len));
-    if (condensed) FB_HIP(hipMalloc(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
+    if (condensed) {
+      FB_HIP(hipMalloc(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
+      FB_HIP(hipMalloc(&fb->fac, sizeof(double) * (size_t)(p.ng / 2 + 1) * n1 * 3 * nf * nf));
+      const char* b0 = getenv("PFHIP_FEM_BAND0");  // "0": dense rocSOLVER / rocBLAS kernels on the first level too (A/B)
+      fb->band0 = !(b0 && b0[0] == '0');
+    }
     FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
     FB_HIP(hipMalloc(&fb->info, sizeof(rocblas_int) * p.ng));
     FB_HIP(hipMalloc(&fb->scal, sizeof(double) * 4));
@@ -1024,7 +1223,7 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_BLAS(rocblas_create_handle(&fb->bh));
     FB_BLAS(rocblas_set_stream(fb->bh, stream));
     FB_BLAS(rocblas_set_pointer_mode(fb->bh, rocblas_pointer_mode_host));
-    if (condensed && nf == 2 && rho != 0.0) {
+    if (condensed && nf == 2) {  // (fembe_create_model overwrites this description with its own)
       // BM1 (bench1.py:60-77): the same two residual blocks written in the generic form, so that the Newton solve runs
       // on the condensed kernels -- R_c = M (c - c0)/dt + Mob K mu,  R_mu = M mu - kappa K c - int f'(c) lambda
       GenModel& m = fb->gm;
@@ -1074,6 +1273,7 @@ void fembe_destroy(FemBE* fb) {
   if (fb->rhs0) (void)hipFree(fb->rhs0);
   if (fb->rhs1) (void)hipFree(fb->rhs1);
   if (fb->Aloc) (void)hipFree(fb->Aloc);
+  if (fb->fac) (void)hipFree(fb->fac);
   for (int f = 3; f < MAXF; ++f) {  // fields 0..2 alias c / mu / phi
     if (fb->u.u[f]) (void)hipFree(fb->u.u[f]);
     if (fb->u0.u[f]) (void)hipFree(fb->u0.u[f]);
@@ -1300,7 +1500,26 @@ static int block_solve_bcr(FemBE* fb) {
     double *Lc = Ls[set], *Uc = Us[set], *Ln = Ls[1 - set], *Un = Us[1 - set];
     double* De = fb->D + (int64_t)s * bs;
     rocblas_int* pe = fb->piv + (int64_t)s * nb;
-    if (fb->pivot) {
+    const bool banded = fb->band0 && s == 1;  // first level of the condensed system: block-tridiagonal blocks
+    if (banded) {
+      const int n1 = p.N + 1;
+      double* Le = Lc + (int64_t)s * bs;
+      double* Ue = Uc + (int64_t)s * bs;
+      double* re = fb->rhs + (int64_t)s * nb;
+      const dim3 gs((2 * nb + 1 + 255) / 256, ne);
+      if (fb->gen_nf == 6) {
+        hipLaunchKernelGGL(row_factor_kernel<6>, dim3((ne + 63) / 64), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
+                           ne, fb->fac);
+        hipLaunchKernelGGL(row_solve_kernel<6>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re, st,
+                           sv);
+      } else {
+        hipLaunchKernelGGL(row_factor_kernel<2>, dim3((ne + 63) / 64), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
+                           ne, fb->fac);
+        hipLaunchKernelGGL(row_solve_kernel<2>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re, st,
+                           sv);
+      }
+      FB_HIP(hipGetLastError());
+    } else if (fb->pivot) {
       FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
       FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
                                                Lc + (int64_t)s * bs, nb, st, ne));
@@ -1323,26 +1542,50 @@ static int block_solve_bcr(FemBE* fb) {
       }
     }
     const int nl = nk - 1;  // kept blocks k = 2, 4, .. have a left neighbour
+    auto band_gemm = [&](const double* Lb, const double* X, double* C, double beta, int count) {
+      const dim3 g((nb + 255) / 256, (nb + 7) / 8, count);
+      if (fb->gen_nf == 6)
+        hipLaunchKernelGGL(band_gemm_kernel<6>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+      else
+        hipLaunchKernelGGL(band_gemm_kernel<2>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+    };
     if (nl > 0) {
       const int64_t j0 = 2 * (int64_t)s;
-      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
-                                            Lc + j0 * bs, nb, st, Uc + (int64_t)s * bs, nb, st, &one, fb->D + j0 * bs,
-                                            nb, st, nl));
+      if (banded) {
+        band_gemm(Lc + j0 * bs, Uc + (int64_t)s * bs, fb->D + j0 * bs, 1.0, nl);
+      } else {
+        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
+                                              Lc + j0 * bs, nb, st, Uc + (int64_t)s * bs, nb, st, &one,
+                                              fb->D + j0 * bs, nb, st, nl));
+      }
       FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Lc + j0 * bs, nb, st,
                                             fb->rhs + (int64_t)s * nb, 1, sv, &one, fb->rhs + j0 * nb, 1, sv, nl));
-      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
-                                            Lc + j0 * bs, nb, st, Lc + (int64_t)s * bs, nb, st, &zero, Ln + j0 * bs, nb,
-                                            st, nl));
+      if (banded) {
+        band_gemm(Lc + j0 * bs, Lc + (int64_t)s * bs, Ln + j0 * bs, 0.0, nl);
+      } else {
+        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
+                                              Lc + j0 * bs, nb, st, Lc + (int64_t)s * bs, nb, st, &zero, Ln + j0 * bs,
+                                              nb, st, nl));
+      }
     }
     const int nr = ne;  // kept blocks k = 0, 2, .. with k + 1 <= m - 1 have a right neighbour
     if (nr > 0) {
-      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone, Uc,
-                                            nb, st, Lc + (int64_t)s * bs, nb, st, &one, fb->D, nb, st, nr));
+      if (banded) {
+        band_gemm(Uc, Lc + (int64_t)s * bs, fb->D, 1.0, nr);
+      } else {
+        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
+                                              Uc, nb, st, Lc + (int64_t)s * bs, nb, st, &one, fb->D, nb, st, nr));
+      }
       FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Uc, nb, st,
                                             fb->rhs + (int64_t)s * nb, 1, sv, &one, fb->rhs, 1, sv, nr));
-      FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone, Uc,
-                                            nb, st, Uc + (int64_t)s * bs, nb, st, &zero, Un, nb, st, nr));
+      if (banded) {
+        band_gemm(Uc, Uc + (int64_t)s * bs, Un, 0.0, nr);
+      } else {
+        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
+                                              Uc, nb, st, Uc + (int64_t)s * bs, nb, st, &zero, Un, nb, st, nr));
+      }
     }
+    if (banded) FB_HIP(hipGetLastError());
     // couplings that do not exist at the next level
     FB_HIP(hipMemsetAsync(Ln, 0, sizeof(double) * bs, fb->stream));
     if (nk > nr) FB_HIP(hipMemsetAsync(Un + 2 * (int64_t)s * (nk - 1) * bs, 0, sizeof(double) * bs, fb->stream));
