@@ -1037,6 +1037,9 @@ struct FemBE {
   double *D = nullptr, *Lo = nullptr, *Up = nullptr, *rhs = nullptr;
   double *Lo2 = nullptr, *Up2 = nullptr;  // second coupling set (block cyclic reduction ping-pongs between the two)
   int solver = 0;                          // 0: block cyclic reduction (batched), 1: block Thomas (sequential)
+  rocblas_handle bh2 = nullptr;            // second handle on stream2: the U side of the dense reduction levels
+  hipStream_t stream2 = nullptr;           // (PFHIP_FEM_STREAMS=1 keeps everything on one stream)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pivot = true;                       // PFHIP_FEM_PIVOT=0: LU without row exchanges in the cyclic reduction (experiment)
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
@@ -1223,6 +1226,17 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_BLAS(rocblas_create_handle(&fb->bh));
     FB_BLAS(rocblas_set_stream(fb->bh, stream));
     FB_BLAS(rocblas_set_pointer_mode(fb->bh, rocblas_pointer_mode_host));
+    {
+      const char* ns = getenv("PFHIP_FEM_STREAMS");
+      if (!(ns && ns[0] == '1')) {
+        FB_HIP(hipStreamCreateWithFlags(&fb->stream2, hipStreamNonBlocking));
+        FB_HIP(hipEventCreateWithFlags(&fb->ev_fork, hipEventDisableTiming));
+        FB_HIP(hipEventCreateWithFlags(&fb->ev_join, hipEventDisableTiming));
+        FB_BLAS(rocblas_create_handle(&fb->bh2));
+        FB_BLAS(rocblas_set_stream(fb->bh2, fb->stream2));
+        FB_BLAS(rocblas_set_pointer_mode(fb->bh2, rocblas_pointer_mode_host));
+      }
+    }
     if (condensed && nf == 2) {  // (fembe_create_model overwrites this description with its own)
       // BM1 (bench1.py:60-77): the same two residual blocks written in the generic form, so that the Newton solve runs
       // on the condensed kernels -- R_c = M (c - c0)/dt + Mob K mu,  R_mu = M mu - kappa K c - int f'(c) lambda
@@ -1263,6 +1277,10 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
 void fembe_destroy(FemBE* fb) {
   if (!fb) return;
   if (fb->bh) (void)rocblas_destroy_handle(fb->bh);
+  if (fb->bh2) (void)rocblas_destroy_handle(fb->bh2);
+  if (fb->ev_fork) (void)hipEventDestroy(fb->ev_fork);
+  if (fb->ev_join) (void)hipEventDestroy(fb->ev_join);
+  if (fb->stream2) (void)hipStreamDestroy(fb->stream2);
   for (void* q : {(void*)fb->tri, (void*)fb->Ke, (void*)fb->ell_col, (void*)fb->ell_K, (void*)fb->ell_M,
                   (void*)fb->nt_ptr, (void*)fb->nt_tri, (void*)fb->nt_loc, (void*)fb->c, (void*)fb->mu, (void*)fb->phi,
                   (void*)fb->c0, (void*)fb->mu0, (void*)fb->phi0, (void*)fb->D, (void*)fb->Lo, (void*)fb->Up,
@@ -1519,21 +1537,29 @@ static int block_solve_bcr(FemBE* fb) {
                            sv);
       }
       FB_HIP(hipGetLastError());
-    } else if (fb->pivot) {
+    }
+    // D_e^-1 [L_e | U_e | r_e] of the dense levels.  The U-side work (the solves for U_e and r_e, U_next, the right-hand
+    // side updates) is independent of the L-side work until the last product: with a second rocBLAS handle on its own
+    // stream the two halves run side by side -- these levels are batches of <= 25 launch-latency-bound kernels.
+    const bool two = !banded && fb->pivot && fb->bh2;
+    rocblas_handle hU = two ? fb->bh2 : fb->bh;
+    double *Xl = Lc + (int64_t)s * bs, *Xu = Uc + (int64_t)s * bs, *xr = fb->rhs + (int64_t)s * nb;
+    if (!banded && fb->pivot) {
       FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
-      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
-                                               Lc + (int64_t)s * bs, nb, st, ne));
-      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv,
-                                               Uc + (int64_t)s * bs, nb, st, ne));
-      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, 1, De, nb, st, pe, sv,
-                                               fb->rhs + (int64_t)s * nb, nb, sv, ne));
-    } else {
+      if (two) {
+        FB_HIP(hipEventRecord(fb->ev_fork, fb->stream));
+        FB_HIP(hipStreamWaitEvent(fb->stream2, fb->ev_fork, 0));
+      }
+      FB_BLAS(rocsolver_dgetrs_strided_batched(hU, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xu, nb, st, ne));
+      FB_BLAS(rocsolver_dgetrs_strided_batched(hU, rocblas_operation_none, nb, 1, De, nb, st, pe, sv, xr, nb, sv, ne));
+      FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xl, nb, st, ne));
+    } else if (!banded) {
       FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, De, nb, st, fb->info, ne));
       struct Rhs {
         double* b;
         int n;
         int64_t stride;
-      } rr[3] = {{Lc + (int64_t)s * bs, nb, st}, {Uc + (int64_t)s * bs, nb, st}, {fb->rhs + (int64_t)s * nb, 1, sv}};
+      } rr[3] = {{Xl, nb, st}, {Xu, nb, st}, {xr, 1, sv}};
       for (const Rhs& r : rr) {
         FB_BLAS(rocblas_dtrsm_strided_batched(fb->bh, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none,
                                               rocblas_diagonal_unit, nb, r.n, &one, De, nb, st, r.b, nb, r.stride, ne));
@@ -1541,51 +1567,48 @@ static int block_solve_bcr(FemBE* fb) {
                                               rocblas_diagonal_non_unit, nb, r.n, &one, De, nb, st, r.b, nb, r.stride, ne));
       }
     }
-    const int nl = nk - 1;  // kept blocks k = 2, 4, .. have a left neighbour
-    auto band_gemm = [&](const double* Lb, const double* X, double* C, double beta, int count) {
-      const dim3 g((nb + 255) / 256, (nb + 7) / 8, count);
-      if (fb->gen_nf == 6)
-        hipLaunchKernelGGL(band_gemm_kernel<6>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
-      else
-        hipLaunchKernelGGL(band_gemm_kernel<2>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+    const int nl = nk - 1;  // kept blocks k = 2, 4, .. have a left neighbour (L_k at Lc + j0 bs)
+    const int nr = ne;      // kept blocks k = 0, 2, .. with k + 1 <= m - 1 have a right neighbour (U_k at Uc)
+    const int64_t j0 = 2 * (int64_t)s;
+    auto gemm = [&](rocblas_handle hh, const double* Ab, const double* X, const double* beta, double* C, int count) {
+      return rocblas_dgemm_strided_batched(hh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone, Ab, nb, st,
+                                           X, nb, st, beta, C, nb, st, count);
     };
-    if (nl > 0) {
-      const int64_t j0 = 2 * (int64_t)s;
-      if (banded) {
-        band_gemm(Lc + j0 * bs, Uc + (int64_t)s * bs, fb->D + j0 * bs, 1.0, nl);
-      } else {
-        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
-                                              Lc + j0 * bs, nb, st, Uc + (int64_t)s * bs, nb, st, &one,
-                                              fb->D + j0 * bs, nb, st, nl));
+    auto gemv = [&](rocblas_handle hh, const double* Ab, double* y, int count) {
+      return rocblas_dgemv_strided_batched(hh, rocblas_operation_none, nb, nb, &mone, Ab, nb, st, xr, 1, sv, &one, y, 1, sv,
+                                           count);
+    };
+    if (banded) {
+      auto band_gemm = [&](const double* Lb, const double* X, double* C, double beta, int count) {
+        const dim3 g((nb + 255) / 256, (nb + 7) / 8, count);
+        if (fb->gen_nf == 6)
+          hipLaunchKernelGGL(band_gemm_kernel<6>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+        else
+          hipLaunchKernelGGL(band_gemm_kernel<2>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+      };
+      if (nl > 0) {
+        band_gemm(Lc + j0 * bs, Xu, fb->D + j0 * bs, 1.0, nl);
+        FB_BLAS(gemv(fb->bh, Lc + j0 * bs, fb->rhs + j0 * nb, nl));
+        band_gemm(Lc + j0 * bs, Xl, Ln + j0 * bs, 0.0, nl);
       }
-      FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Lc + j0 * bs, nb, st,
-                                            fb->rhs + (int64_t)s * nb, 1, sv, &one, fb->rhs + j0 * nb, 1, sv, nl));
-      if (banded) {
-        band_gemm(Lc + j0 * bs, Lc + (int64_t)s * bs, Ln + j0 * bs, 0.0, nl);
-      } else {
-        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
-                                              Lc + j0 * bs, nb, st, Lc + (int64_t)s * bs, nb, st, &zero, Ln + j0 * bs,
-                                              nb, st, nl));
+      if (nr > 0) {
+        band_gemm(Uc, Xl, fb->D, 1.0, nr);
+        FB_BLAS(gemv(fb->bh, Uc, fb->rhs, nr));
+        band_gemm(Uc, Xu, Un, 0.0, nr);
       }
+      FB_HIP(hipGetLastError());
+    } else {
+      if (nr > 0) FB_BLAS(gemm(hU, Uc, Xu, &zero, Un, nr));                  // U side: U_next = -U_k X_U
+      if (nl > 0) FB_BLAS(gemv(hU, Lc + j0 * bs, fb->rhs + j0 * nb, nl));    //         r_k -= L_k x_r
+      if (nr > 0) FB_BLAS(gemv(hU, Uc, fb->rhs, nr));                        //         r_k -= U_k x_r
+      if (nl > 0) FB_BLAS(gemm(fb->bh, Lc + j0 * bs, Xl, &zero, Ln + j0 * bs, nl));  // L side: L_next = -L_k X_L
+      if (nr > 0) FB_BLAS(gemm(fb->bh, Uc, Xl, &one, fb->D, nr));                    //         D_k -= U_k X_L
+      if (two) {
+        FB_HIP(hipEventRecord(fb->ev_join, fb->stream2));
+        FB_HIP(hipStreamWaitEvent(fb->stream, fb->ev_join, 0));
+      }
+      if (nl > 0) FB_BLAS(gemm(fb->bh, Lc + j0 * bs, Xu, &one, fb->D + j0 * bs, nl));  // D_k -= L_k X_U (needs the U side)
     }
-    const int nr = ne;  // kept blocks k = 0, 2, .. with k + 1 <= m - 1 have a right neighbour
-    if (nr > 0) {
-      if (banded) {
-        band_gemm(Uc, Lc + (int64_t)s * bs, fb->D, 1.0, nr);
-      } else {
-        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
-                                              Uc, nb, st, Lc + (int64_t)s * bs, nb, st, &one, fb->D, nb, st, nr));
-      }
-      FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Uc, nb, st,
-                                            fb->rhs + (int64_t)s * nb, 1, sv, &one, fb->rhs, 1, sv, nr));
-      if (banded) {
-        band_gemm(Uc, Uc + (int64_t)s * bs, Un, 0.0, nr);
-      } else {
-        FB_BLAS(rocblas_dgemm_strided_batched(fb->bh, rocblas_operation_none, rocblas_operation_none, nb, nb, nb, &mone,
-                                              Uc, nb, st, Uc + (int64_t)s * bs, nb, st, &zero, Un, nb, st, nr));
-      }
-    }
-    if (banded) FB_HIP(hipGetLastError());
     // couplings that do not exist at the next level
     FB_HIP(hipMemsetAsync(Ln, 0, sizeof(double) * bs, fb->stream));
     if (nk > nr) FB_HIP(hipMemsetAsync(Un + 2 * (int64_t)s * (nk - 1) * bs, 0, sizeof(double) * bs, fb->stream));
