@@ -756,58 +756,74 @@ __device__ __forceinline__ void small_inverse(double (&S)[NF][NF], double (&Z)[N
   }
 }
 
+// One wave per matrix: n1 dependent steps  S_l = B_l - A_l G_(l-1),  Z_l = S_l^-1,  G_l = Z_l C_l.  The lanes fetch the
+// three NF x NF blocks of step l + 1 while step l is computed (the scattered loads of D_e were the whole cost of the
+// one-thread-per-matrix form: 1.5 ms per call on BM2), the products are spread over NF^2 lanes, lane 0 inverts S_l.
 template <int NF>
 __global__ __launch_bounds__(64) void row_factor_kernel(int nb, int n1, const double* __restrict__ D, int64_t stride,
                                                         int nmat, double* __restrict__ fac) {
-  const int m = blockIdx.x * 64 + threadIdx.x;  // one thread per matrix: n1 dependent NF x NF steps
+  constexpr int Q = NF * NF, PER = (3 * Q + 63) / 64;
+  __shared__ double sh[5 * Q];  // B (then S), A, C, G of the previous corner, Z
+  const int m = blockIdx.x, lane = threadIdx.x;
   if (m >= nmat) return;
   const double* De = D + (int64_t)m * stride;
-  double* F = fac + (int64_t)m * n1 * 3 * NF * NF;
-  double G[NF][NF];
+  double* F = fac + (int64_t)m * n1 * 3 * Q;
+  auto ld = [&](int l, int k) -> double {  // k in [0, 3 Q): block 0 diagonal, 1 sub-diagonal, 2 super-diagonal
+    const int blk = k / Q, a = (k % Q) / NF, b = k % NF;
+    const int lc = blk == 0 ? l : (blk == 1 ? l - 1 : l + 1);
+    if (lc < 0 || lc >= n1) return 0.0;
+    return De[(l * NF + a) + (int64_t)(lc * NF + b) * nb];
+  };
+  double nxt[PER];
 #pragma unroll
-  for (int a = 0; a < NF; ++a)
-#pragma unroll
-    for (int b = 0; b < NF; ++b) G[a][b] = 0.0;
+  for (int i = 0; i < PER; ++i) nxt[i] = lane + 64 * i < 3 * Q ? ld(0, lane + 64 * i) : 0.0;
+  if (lane < Q) sh[3 * Q + lane] = 0.0;
+  const int a = lane / NF, b = lane % NF;
   for (int l = 0; l < n1; ++l) {
-    double S[NF][NF], A[NF][NF], Z[NF][NF];
 #pragma unroll
-    for (int a = 0; a < NF; ++a)
+    for (int i = 0; i < PER; ++i)
+      if (lane + 64 * i < 3 * Q) sh[lane + 64 * i] = nxt[i];
+    __syncthreads();
+    if (l + 1 < n1) {
 #pragma unroll
-      for (int b = 0; b < NF; ++b) {
-        S[a][b] = De[(l * NF + a) + (int64_t)(l * NF + b) * nb];
-        A[a][b] = l > 0 ? De[(l * NF + a) + (int64_t)((l - 1) * NF + b) * nb] : 0.0;
-      }
+      for (int i = 0; i < PER; ++i) nxt[i] = lane + 64 * i < 3 * Q ? ld(l + 1, lane + 64 * i) : 0.0;
+    }
+    double sv = 0.0;
+    if (lane < Q) {
+      sv = sh[lane];
 #pragma unroll
-    for (int a = 0; a < NF; ++a)
+      for (int k = 0; k < NF; ++k) sv -= sh[Q + a * NF + k] * sh[3 * Q + k * NF + b];
+    }
+    __syncthreads();
+    if (lane < Q) sh[lane] = sv;
+    __syncthreads();
+    if (lane == 0) {
+      double S[NF][NF], Z[NF][NF];
 #pragma unroll
-      for (int b = 0; b < NF; ++b) {
-        double acc = S[a][b];
+      for (int x = 0; x < NF; ++x)
 #pragma unroll
-        for (int k = 0; k < NF; ++k) acc -= A[a][k] * G[k][b];
-        S[a][b] = acc;
-      }
-    small_inverse<NF>(S, Z);
+        for (int y = 0; y < NF; ++y) S[x][y] = sh[x * NF + y];
+      small_inverse<NF>(S, Z);
 #pragma unroll
-    for (int a = 0; a < NF; ++a)
+      for (int x = 0; x < NF; ++x)
 #pragma unroll
-      for (int b = 0; b < NF; ++b) {
-        double acc = 0.0;
-        if (l + 1 < n1) {
+        for (int y = 0; y < NF; ++y) sh[4 * Q + x * NF + y] = Z[x][y];
+    }
+    __syncthreads();
+    double gv = 0.0;
+    if (lane < Q) {
 #pragma unroll
-          for (int k = 0; k < NF; ++k) acc += Z[a][k] * De[(l * NF + k) + (int64_t)((l + 1) * NF + b) * nb];
-        }
-        S[a][b] = acc;  // G_l
-      }
-    double* Fl = F + (int64_t)l * 3 * NF * NF;
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-#pragma unroll
-      for (int b = 0; b < NF; ++b) {
-        Fl[a * NF + b] = Z[a][b];
-        Fl[NF * NF + a * NF + b] = S[a][b];
-        Fl[2 * NF * NF + a * NF + b] = A[a][b];
-        G[a][b] = S[a][b];
-      }
+      for (int k = 0; k < NF; ++k) gv += sh[4 * Q + a * NF + k] * sh[2 * Q + k * NF + b];
+    }
+    __syncthreads();
+    if (lane < Q) {
+      double* Fl = F + (int64_t)l * 3 * Q;
+      Fl[lane] = sh[4 * Q + lane];
+      Fl[Q + lane] = gv;
+      Fl[2 * Q + lane] = sh[Q + lane];
+      sh[3 * Q + lane] = gv;
+    }
+    __syncthreads();
   }
 }
 
@@ -1526,12 +1542,12 @@ static int block_solve_bcr(FemBE* fb) {
       double* re = fb->rhs + (int64_t)s * nb;
       const dim3 gs((2 * nb + 1 + 255) / 256, ne);
       if (fb->gen_nf == 6) {
-        hipLaunchKernelGGL(row_factor_kernel<6>, dim3((ne + 63) / 64), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
+        hipLaunchKernelGGL(row_factor_kernel<6>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
                            ne, fb->fac);
         hipLaunchKernelGGL(row_solve_kernel<6>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re, st,
                            sv);
       } else {
-        hipLaunchKernelGGL(row_factor_kernel<2>, dim3((ne + 63) / 64), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
+        hipLaunchKernelGGL(row_factor_kernel<2>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
                            ne, fb->fac);
         hipLaunchKernelGGL(row_solve_kernel<2>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re, st,
                            sv);
