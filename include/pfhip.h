@@ -57,7 +57,7 @@ typedef enum pf_status {
 enum { PF_BC_PERIODIC = 0, PF_BC_MIRROR = 1 };           /* mirror = natural no-flux BC (bench1.py:69) */
 enum {
   PF_SCHEME_FD_EXPLICIT = 0, /* explicit finite differences, fused stencil kernel (the throughput path) */
-  PF_SCHEME_SPECTRAL_SI = 1, /* semi-implicit Fourier spectral (hand-written LDS FFTs at 512-point axes, else rocFFT);
+  PF_SCHEME_SPECTRAL_SI = 1, /* semi-implicit Fourier spectral (hand-written LDS FFTs on power-of-two axes 128..1024, else rocFFT);
                                 BM6: periodic box on one GPU, phi eliminated in Fourier space (implicit term) */
   PF_SCHEME_FEM_BE = 2       /* BE-parity mode: the reference's own P1 'crossed'-mesh backward-Euler Newton solve
                                 (bench1.py:21-110) -- 2-D, PF_BC_MIRROR, n[0] == n[1] = corner nodes per side;
