@@ -12,6 +12,10 @@
 // transform, twiddles from an LDS table.  Same layout / scaling as rocFFT's D2Z output ([ny][nx/2+1], unnormalised
 // forward), so diagnostics and the resident spectrum are shared with spectral.hip.
 //   c^+_k = (c_k - dt M k^2 N_k) / (1 + dt M kappa k^4),  N = f'(c)       dolfin/pfbase.py:361-383, bench1.py:63-65
+//
+// The same transforms serve 3-D boxes whose axes are powers of two in 128..1024 (four passes per step: z, y, x, y;
+// 512-point axes by the one-wave radix-8 kernels, the others by the radix-2^2 kernels), the 3-D periodic Poisson solve of
+// BM6, and the slab-decomposed transforms of the multi-GPU modes (fusedslab_*, used by slabfft.hip).
 #include <cmath>
 #include <cstdlib>
 #include <string>
