@@ -143,25 +143,27 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
   po->nh = (int64_t)a.nxh * ny * a.nz;
   a.inv_n = 1.0 / (double)po->n;
   auto body = [&]() -> int {
-    if (dim == 2) {
+    const bool fast = npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz);
+    if (fast) {  // the hand-written passes need no library plans
+    } else if (dim == 2) {
       PO_FFT(hipfftPlan2d(&po->fwd, ny, nx, HIPFFT_D2Z));
       PO_FFT(hipfftPlan2d(&po->inv, ny, nx, HIPFFT_Z2D));
     } else {
       PO_FFT(hipfftPlan3d(&po->fwd, a.nz, ny, nx, HIPFFT_D2Z));
       PO_FFT(hipfftPlan3d(&po->inv, a.nz, ny, nx, HIPFFT_Z2D));
     }
-    po->have_plans = true;
-    PO_FFT(hipfftSetStream(po->fwd, stream));
-    PO_FFT(hipfftSetStream(po->inv, stream));
-    {  // the hand-written 512^3 passes use a padded row pitch (fused_spectrum_pitch); the rocFFT path the natural one
-      const bool fast = npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz);
+    if (!fast) {
+      po->have_plans = true;
+      PO_FFT(hipfftSetStream(po->fwd, stream));
+      PO_FFT(hipfftSetStream(po->inv, stream));
+    }
+    {  // the hand-written passes use a padded row pitch (fused_spectrum_pitch); the rocFFT path the natural one
       const int64_t nh_alloc = fast ? (int64_t)fused_spectrum_pitch(3, nx, ny, a.nz) * ny * a.nz : po->nh;
       PO_HIP(hipMalloc(&po->ph, sizeof(double2) * nh_alloc));
       if (nh_alloc != po->nh) PO_HIP(hipMemsetAsync(po->ph, 0, sizeof(double2) * nh_alloc, stream));
     }
     if (npx > 0) PO_HIP(hipMalloc(&po->rhs, sizeof(double) * po->n));
-    if (npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz) &&
-        fused2d_create(&po->fast, nx, ny, a.nz, h, stream) != 0) {
+    if (fast && fused2d_create(&po->fast, nx, ny, a.nz, h, stream) != 0) {
       po->err = "fused2d_create failed";
       return -3;
     }

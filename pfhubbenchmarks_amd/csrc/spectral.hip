@@ -214,16 +214,18 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     return rc;
   };
   auto body = [&]() -> int {
-    if (dim == 2) {
-      SP_FFT(hipfftPlan2d(&sp->fwd, ny, nx, HIPFFT_D2Z));
-      SP_FFT(hipfftPlan2d(&sp->inv, ny, nx, HIPFFT_Z2D));
-    } else {
-      SP_FFT(hipfftPlan3d(&sp->fwd, sp->nz, ny, nx, HIPFFT_D2Z));
-      SP_FFT(hipfftPlan3d(&sp->inv, sp->nz, ny, nx, HIPFFT_Z2D));
+    if (!want_fast) {  // the hand-written passes need neither the library plans (and their work buffers) nor sp->g
+      if (dim == 2) {
+        SP_FFT(hipfftPlan2d(&sp->fwd, ny, nx, HIPFFT_D2Z));
+        SP_FFT(hipfftPlan2d(&sp->inv, ny, nx, HIPFFT_Z2D));
+      } else {
+        SP_FFT(hipfftPlan3d(&sp->fwd, sp->nz, ny, nx, HIPFFT_D2Z));
+        SP_FFT(hipfftPlan3d(&sp->inv, sp->nz, ny, nx, HIPFFT_Z2D));
+      }
+      sp->have_plans = true;
+      SP_FFT(hipfftSetStream(sp->fwd, stream));
+      SP_FFT(hipfftSetStream(sp->inv, stream));
     }
-    sp->have_plans = true;
-    SP_FFT(hipfftSetStream(sp->fwd, stream));
-    SP_FFT(hipfftSetStream(sp->inv, stream));
     SP_HIP(hipMalloc(&sp->chat, sizeof(double2) * nh_alloc));
     SP_HIP(hipMalloc(&sp->ghat, sizeof(double2) * nh_alloc));
     SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * nh_alloc));
@@ -232,7 +234,7 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
       SP_HIP(hipMemsetAsync(sp->ghat, 0, sizeof(double2) * nh_alloc, stream));
       SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
     }
-    SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
+    if (!want_fast) SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
     SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 4096));
     if (want_fast) {  // PFHIP_SPECTRAL_2D / _3D = rocfft force the library path (A/B comparison)
       if (fused2d_create(&sp->fast, nx, ny, sp->nz, h, stream) != 0) {
