@@ -126,8 +126,8 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "bm1_fem_be", "mesh": "100x100 crossed, 20201 nodes, 40402 dofs",
                       "time_grid": "rows %d..%d of results/bench1_out.csv" % (warmup, warmup + steps - 1),
-                      "newton_iterations": its, "linear_solver": "block cyclic reduction, strided-batched rocSOLVER/rocBLAS "
-                                       "(PFHIP_FEM_SOLVER=thomas: sequential block Thomas)"},
+                      "newton_iterations": its, "linear_solver": "cell-centre unknowns condensed out, banded first reduction level, "
+                                       "then block cyclic reduction on strided-batched rocSOLVER/rocBLAS"},
            "roofline": None,
            "check": {"t": float(tprev), "F": F, "C": C},
            # (this repo has its own dolfin/ directory of command-line shims, so probe FEniCS's dependencies instead)
