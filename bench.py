@@ -453,6 +453,11 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
                      "bytes_per_cell_update": bytes_per_cell},
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
+    if scheme == "spectral" and not slab:
+        # one pf_step call advances `steps` steps; the state is the resident spectrum, the real-space field is written by
+        # the last two steps of the call (PFHIP_SPECTRAL_STORE_EVERY_STEP=1 writes it every step)
+        out["config"]["field_store"] = ("every step" if os.environ.get("PFHIP_SPECTRAL_STORE_EVERY_STEP", "") == "1"
+                                        else "last two steps of each pf_step call")
     if copy_ceiling and rank == 0 and world == 1 and dim == 3 and scheme == "fd":
         # the same 8 B read + 8 B write per cell as a plain device copy (pfk_stream_copy): what the memory system
         # delivers for this traffic pattern, measured in the same process and the same (pre-heated, busy) state:

@@ -113,6 +113,7 @@ struct pf_handle {
   FemBE* fb = nullptr;     // PF_SCHEME_FEM_BE
   MultiFD* mf = nullptr;   // PF_SCHEME_FD_EXPLICIT with PF_MODEL_BM2 / BM3
   SlabFFT* sf = nullptr;   // slab FFT modes (nranks > 1 spectral / BM6)
+  bool sp_store = true;    // spectral scheme: does the next launch_step write the real-space field (pf_step decides)
   bool own_phi = false;
   bool chat_valid = false; // slab spectral: resident spectrum consistent with c[cur]
   int d_op = 0, d_phase = 0;
@@ -242,6 +243,10 @@ int ensure_phi(pf_handle* h) {
   return PF_OK;
 }
 
+bool g_spectral_store_all = [] {  // PFHIP_SPECTRAL_STORE_EVERY_STEP=1 (read once)
+  const char* e = getenv("PFHIP_SPECTRAL_STORE_EVERY_STEP");
+  return e && e[0] == '1';
+}();
 int g_max_k2d = 4;  // pfk_set_tuning key 3: largest number of 2-D steps fused into one launch (1, 2 or 4)
 
 // One FD step on planes [zlo, zhi) (and optionally [zlo2, zhi2): the second boundary strip of a slab, same launch) of the
@@ -268,7 +273,7 @@ int launch_step(pf_handle* h, double dt, int zlo, int zhi, int K = 1, int zlo2 =
     }
     const pf_config& c = h->cfg;
     if (spectral_step(h->sp, h->c[h->cur], h->c[1 - h->cur], dt, c.M, c.kappa, c.c_alpha, c.c_beta, 2.0 * c.rho_s,
-                      h->stream) != 0)
+                      h->stream, h->sp_store) != 0)
       return fail(h, PF_ERR_HIP, spectral_error(h->sp));
     if (e) PF_HIP(h, hipEventRecord(e->second, h->stream));
     return PF_OK;
@@ -948,6 +953,10 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   }
   for (int s = 0; s < nsteps;) {
     const int left = nsteps - s;
+    // spectral scheme: the state is the resident spectrum; the real-space field is written by the last two steps of the
+    // call only -- what the caller can observe afterwards and what pf_rollback returns to (the same rule as the 2-D FD
+    // multi-step launches below).  PFHIP_SPECTRAL_STORE_EVERY_STEP=1 writes it every step (A/B).
+    h->sp_store = left <= 2 || g_spectral_store_all;
     int K = 1;
     if (multi && left > 4 && g_max_k2d >= 4)
       K = 4;
@@ -958,6 +967,7 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
     s += K;
     swap_buffers(h);
   }
+  h->sp_store = true;
   if (info) {
     double raw[6];
     int rc = run_diag(h, raw);

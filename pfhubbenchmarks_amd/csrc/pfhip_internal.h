@@ -77,7 +77,7 @@ void spectral_destroy(Spectral* sp);
 void spectral_invalidate(Spectral* sp);
 void spectral_set_screening(Spectral* sp, double gq);  // BM6: gq = k^2 / eps; the step then treats -M gq (c - mean) implicitly  // call whenever the real-space field changed behind the scheme's back
 int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
-                  double cb, double two_rho, hipStream_t stream);
+                  double cb, double two_rho, hipStream_t stream, bool store_field = true);
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
 

@@ -285,12 +285,14 @@ static int ensure_chat(Spectral* sp, const double* c) {
 }
 
 // one semi-implicit step: reads c_in (real space), writes c_out (real space); c_k stays resident
+// store_field = false (an intermediate step of a multi-step pf_step call): the hand-written passes do not write the
+// real-space field -- the state lives in the resident spectrum and in G, c_out stays untouched; the library path ignores it
 int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
-                  double cb, double two_rho, hipStream_t stream) {
+                  double cb, double two_rho, hipStream_t stream, bool store_field) {
   int rc = ensure_chat(sp, c_in);
   if (rc) return rc;
   if (sp->fast) {
-    if (fused2d_step(sp->fast, c_in, c_out, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho,
+    if (fused2d_step(sp->fast, c_in, store_field ? c_out : nullptr, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho,
                      dt * M * sp->gq) != 0) {
       sp->err = "fused2d_step launch failed";
       return -3;

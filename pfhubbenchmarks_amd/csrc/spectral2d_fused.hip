@@ -195,8 +195,10 @@ __global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double
       const int x = lane + RT * i;
       if (x < N) {
         z[i] = X[px(x)];
-        c_out[(int64_t)y0 * N + x] = z[i].x;
-        c_out[(int64_t)y1 * N + x] = z[i].y;
+        if (c_out) {  // null: an intermediate step of a multi-step call, the field is not materialised
+          c_out[(int64_t)y0 * N + x] = z[i].x;
+          c_out[(int64_t)y1 * N + x] = z[i].y;
+        }
       }
     }
     if (from_spectrum == 2) return;  // inverse only (Poisson solve)
@@ -476,8 +478,10 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
       fft512_wave<+1>(v, L, lane, twN, twB, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
-      c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
+      if (c_out) {  // null: an intermediate step of a multi-step call, the field is not materialised
+        c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
+        c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
+      }
     }
     if (from_spectrum == 2) return;  // inverse only (Poisson solve): no forward transform of the result
     m = T;
