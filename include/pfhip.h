@@ -230,7 +230,9 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n);
 
 /* ---- time stepping ---------------------------------------------------------------------------------- */
 /* nranks == 1: advance nsteps steps of size dt.  Asynchronous on the handle's stream unless info != NULL
- * (then the guard reduction is read back).  The state before the LAST step stays available to pf_rollback. */
+ * (then the guard reduction is read back).  The state before the LAST step stays available to pf_rollback.
+ * Intermediate states of a multi-step call are not observable and need not be materialised in HBM: the 2-D FD path
+ * fuses up to 4 steps per launch, the spectral scheme writes the real-space field in the last two steps only. */
 int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info);
 int pf_rollback(pf_handle* h);
 /* PF_FLAG_BM6_ELIMINATE_PHI: the lattice mean of c (a conserved quantity).  nranks == 1: computed by the library when
