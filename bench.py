@@ -502,7 +502,7 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
 def side_measurements(a, ctx):
     """Same run, same process, rank 0 of an N = 1 default run: the other configurations BASELINE.json's metric and
     north_star name -- the two 512^2 workloads (wall clock incl. launches), the 1024^3 stencil (north_star's roofline
-    target; own pre-heat, timed blocks, per-launch events) and config 1 = the reference's own algorithm on the GPU with
+    target; own pre-heat, timed blocks, per-launch events), the 512^3 spectral step, and config 1 = the reference's own algorithm on the GPU with
     its CPU restatement (oracle/fem_be.py) timed beside it and whether FEniCS itself is on the host."""
     from pfhubbenchmarks_amd.solver import PhaseFieldSolver
     also = {}
@@ -527,6 +527,11 @@ def side_measurements(a, ctx):
                                                 "block_ms_per_step", "steady", "roofline", "check")}
     also["bm1_fd_1024c"]["config"] = {"workload": "bm1_fd_1024c", "grid": big["config"]["grid"],
                                       "note": "BASELINE.json config 4 on ONE GPU (16 GiB of state); north_star roofline target"}
+    sp3 = bench_grid(a, "bm1_spectral_512c", ctx, max(10, min(a.steps, 50)), min(a.warmup, 10), cpu=False)
+    also["bm1_spectral_512c"] = {k: sp3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "preheat_ms", "repeats",
+                                                     "block_ms_per_step", "steady", "roofline", "check")}
+    also["bm1_spectral_512c"]["config"] = dict(sp3["config"], note="semi-implicit spectral scheme on the 512^3 box: four "
+                                               "hand-written LDS-FFT passes per step; roofline at the 72 B/cell-update idealisation")
     if not a.no_cpu_baseline:
         fb = bench_fem_be(a, 1, steps=8, warmup=2, ncpu_max=3)
         also["bm1_fem_be"] = {k: fb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "check",

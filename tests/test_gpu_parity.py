@@ -1380,6 +1380,10 @@ def test_bench_contract_json_line():
     assert big["config"]["grid"] == [1024, 1024, 1024] and 0.2 < big["roofline"]["frac"] < 1.0
     assert abs(big["value"] - 1024 ** 3 / (big["ms_per_step"] * 1e-3)) < 1e-6 * big["value"]
     assert big["check"]["C_rel_drift"] < 1e-12 and big["check"]["F_after"] < big["check"]["F_before"]
+    sp3 = d["also"]["bm1_spectral_512c"]
+    assert sp3["config"]["grid"] == [512, 512, 512] and sp3["roofline"]["bytes_per_cell_update"] == 72.0
+    assert 0.1 < sp3["roofline"]["frac"] < 1.0 and sp3["check"]["C_rel_drift"] < 1e-12
+    assert sp3["config"]["field_store"] == "last two steps of each pf_step call"
     fb = d["also"]["bm1_fem_be"]
     assert fb["unit"] == "node-updates/s" and fb["cpu_baseline"]["kind"] == "port" and fb["fenics_on_host"] in (True, False)
     assert abs(fb["check"]["F"] - 190.1699) < 1e-3      # row t = 11.1 of the reference's bench1_out.csv
