@@ -1053,9 +1053,9 @@ struct FemBE {
   double *D = nullptr, *Lo = nullptr, *Up = nullptr, *rhs = nullptr;
   double *Lo2 = nullptr, *Up2 = nullptr;  // second coupling set (block cyclic reduction ping-pongs between the two)
   int solver = 0;                          // 0: block cyclic reduction (batched), 1: block Thomas (sequential)
-  rocblas_handle bh2 = nullptr;            // second handle on stream2: the U side of the dense reduction levels
-  hipStream_t stream2 = nullptr;           // (PFHIP_FEM_STREAMS=1 keeps everything on one stream)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  rocblas_handle bh2 = nullptr, bh3 = nullptr;  // handles on stream2 / stream3: the U side and the right-hand side of the
+  hipStream_t stream2 = nullptr, stream3 = nullptr;  // dense reduction levels (PFHIP_FEM_STREAMS=1: everything on one stream)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
   bool pivot = true;                       // PFHIP_FEM_PIVOT=0: LU without row exchanges in the cyclic reduction (experiment)
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
@@ -1251,6 +1251,11 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
         FB_BLAS(rocblas_create_handle(&fb->bh2));
         FB_BLAS(rocblas_set_stream(fb->bh2, fb->stream2));
         FB_BLAS(rocblas_set_pointer_mode(fb->bh2, rocblas_pointer_mode_host));
+        FB_HIP(hipStreamCreateWithFlags(&fb->stream3, hipStreamNonBlocking));
+        FB_HIP(hipEventCreateWithFlags(&fb->ev_join3, hipEventDisableTiming));
+        FB_BLAS(rocblas_create_handle(&fb->bh3));
+        FB_BLAS(rocblas_set_stream(fb->bh3, fb->stream3));
+        FB_BLAS(rocblas_set_pointer_mode(fb->bh3, rocblas_pointer_mode_host));
       }
     }
     if (condensed && nf == 2) {  // (fembe_create_model overwrites this description with its own)
@@ -1294,6 +1299,9 @@ void fembe_destroy(FemBE* fb) {
   if (!fb) return;
   if (fb->bh) (void)rocblas_destroy_handle(fb->bh);
   if (fb->bh2) (void)rocblas_destroy_handle(fb->bh2);
+  if (fb->bh3) (void)rocblas_destroy_handle(fb->bh3);
+  if (fb->ev_join3) (void)hipEventDestroy(fb->ev_join3);
+  if (fb->stream3) (void)hipStreamDestroy(fb->stream3);
   if (fb->ev_fork) (void)hipEventDestroy(fb->ev_fork);
   if (fb->ev_join) (void)hipEventDestroy(fb->ev_join);
   if (fb->stream2) (void)hipStreamDestroy(fb->stream2);
@@ -1558,16 +1566,18 @@ static int block_solve_bcr(FemBE* fb) {
     // side updates) is independent of the L-side work until the last product: with a second rocBLAS handle on its own
     // stream the two halves run side by side -- these levels are batches of <= 25 launch-latency-bound kernels.
     const bool two = !banded && fb->pivot && fb->bh2;
-    rocblas_handle hU = two ? fb->bh2 : fb->bh;
+    rocblas_handle hU = two ? fb->bh2 : fb->bh;  // U_e solve, U_next
+    rocblas_handle hR = two ? fb->bh3 : fb->bh;  // r_e solve, right-hand-side updates (third stream)
     double *Xl = Lc + (int64_t)s * bs, *Xu = Uc + (int64_t)s * bs, *xr = fb->rhs + (int64_t)s * nb;
     if (!banded && fb->pivot) {
       FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
       if (two) {
         FB_HIP(hipEventRecord(fb->ev_fork, fb->stream));
         FB_HIP(hipStreamWaitEvent(fb->stream2, fb->ev_fork, 0));
+        FB_HIP(hipStreamWaitEvent(fb->stream3, fb->ev_fork, 0));
       }
       FB_BLAS(rocsolver_dgetrs_strided_batched(hU, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xu, nb, st, ne));
-      FB_BLAS(rocsolver_dgetrs_strided_batched(hU, rocblas_operation_none, nb, 1, De, nb, st, pe, sv, xr, nb, sv, ne));
+      FB_BLAS(rocsolver_dgetrs_strided_batched(hR, rocblas_operation_none, nb, 1, De, nb, st, pe, sv, xr, nb, sv, ne));
       FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xl, nb, st, ne));
     } else if (!banded) {
       FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, De, nb, st, fb->info, ne));
@@ -1615,13 +1625,15 @@ static int block_solve_bcr(FemBE* fb) {
       FB_HIP(hipGetLastError());
     } else {
       if (nr > 0) FB_BLAS(gemm(hU, Uc, Xu, &zero, Un, nr));                  // U side: U_next = -U_k X_U
-      if (nl > 0) FB_BLAS(gemv(hU, Lc + j0 * bs, fb->rhs + j0 * nb, nl));    //         r_k -= L_k x_r
-      if (nr > 0) FB_BLAS(gemv(hU, Uc, fb->rhs, nr));                        //         r_k -= U_k x_r
+      if (nl > 0) FB_BLAS(gemv(hR, Lc + j0 * bs, fb->rhs + j0 * nb, nl));    // r side: r_k -= L_k x_r
+      if (nr > 0) FB_BLAS(gemv(hR, Uc, fb->rhs, nr));                        //         r_k -= U_k x_r
       if (nl > 0) FB_BLAS(gemm(fb->bh, Lc + j0 * bs, Xl, &zero, Ln + j0 * bs, nl));  // L side: L_next = -L_k X_L
       if (nr > 0) FB_BLAS(gemm(fb->bh, Uc, Xl, &one, fb->D, nr));                    //         D_k -= U_k X_L
       if (two) {
         FB_HIP(hipEventRecord(fb->ev_join, fb->stream2));
+        FB_HIP(hipEventRecord(fb->ev_join3, fb->stream3));
         FB_HIP(hipStreamWaitEvent(fb->stream, fb->ev_join, 0));
+        FB_HIP(hipStreamWaitEvent(fb->stream, fb->ev_join3, 0));
       }
       if (nl > 0) FB_BLAS(gemm(fb->bh, Lc + j0 * bs, Xu, &one, fb->D + j0 * bs, nl));  // D_k -= L_k X_U (needs the U side)
     }
