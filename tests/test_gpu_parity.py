@@ -998,10 +998,14 @@ def test_fem_be_static_condensation_equals_the_full_block_solve(lib, model, n, h
     """The generic BE-parity path eliminates the cell-centre unknowns cell by cell before the block-tridiagonal solve
     (gen_cell_jacobian_kernel / gen_condense_kernel / gen_backsub_kernel).  PFHIP_FEM_CONDENSE=0 keeps them in the blocks
     (the first implementation, pinned to the reference CSVs in round 2): same Newton iterates up to rounding -- same
-    iteration counts, fields to 1e-10, incl. the cp line search (BM2)."""
+    iteration counts, fields to 1e-10, incl. the cp line search (BM2).  Also against the other solver variants kept behind
+    switches: the sequential block Thomas solve, dense kernels on the first reduction level, one stream."""
     out = {}
-    for cond in ("1", "0"):
-        monkeypatch.setenv("PFHIP_FEM_CONDENSE", cond)
+    for cond in ("1", "0", "thomas", "dense0", "onestream"):
+        monkeypatch.setenv("PFHIP_FEM_CONDENSE", "0" if cond == "0" else "1")
+        monkeypatch.setenv("PFHIP_FEM_SOLVER", "thomas" if cond == "thomas" else "bcr")     # sequential block solve
+        monkeypatch.setenv("PFHIP_FEM_BAND0", "0" if cond == "dense0" else "1")             # dense kernels on level 0
+        monkeypatch.setenv("PFHIP_FEM_STREAMS", "1" if cond == "onestream" else "0")        # no side streams
         with PhaseFieldSolver(dim=2, n=n, h=h, bc="mirror", scheme="fem_be", model=model, max_newton=100) as s:
             s.set_ic_bm2() if model == "bm2" else s.set_ic_bm3()
             its = []
@@ -1011,10 +1015,12 @@ def test_fem_be_static_condensation_equals_the_full_block_solve(lib, model, n, h
                 its.append(s.last_iters)
             names = ("c", "mu", "eta1", "eta4") if model == "bm2" else ("U", "phi")
             out[cond] = (its, [s.get_field(k) for k in names], s.diagnostics())
-    assert out["1"][0] == out["0"][0] and max(out["1"][0]) >= 3, out["1"][0]
-    for a, b in zip(out["1"][1], out["0"][1]):
-        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
-    assert abs(out["1"][2][0] - out["0"][2][0]) <= 1e-11 * abs(out["0"][2][0])
+    assert max(out["1"][0]) >= 3, out["1"][0]
+    for other in ("0", "thomas", "dense0", "onestream"):      # every solver variant lands on the same Newton iterates
+        assert out["1"][0] == out[other][0], (other, out["1"][0], out[other][0])
+        for a, b in zip(out["1"][1], out[other][1]):
+            assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), other
+        assert abs(out["1"][2][0] - out[other][2][0]) <= 1e-11 * abs(out[other][2][0]), other
 
 
 def test_fem_be_bm3_against_reference_rows(lib, golden_dir):
