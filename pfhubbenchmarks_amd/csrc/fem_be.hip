@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void fem_ic_kernel(const FemParams p, double c
 constexpr int MAXF = 6;
 struct GenModel {
   int id = 0;  // 2: BM2 (c, mu, eta1..4), 3: BM3 (U, phi); 0: BM1 / BM6 (the c, mu[, phi] interface of fembe_create)
-  int kind = 0;  // source terms: 1 BM1 (q = {c_alpha, c_beta, 2 rho}), 2 BM2, 3 BM3
+  int kind = 0;  // source terms: 1 BM1 (q = {c_alpha, c_beta, 2 rho}), 2 BM2, 3 BM3, 6 BM6 (as BM1; field 2 = phi with
+                 // Dirichlet rows at the x = 0 / x = L corners, bench6.py:77-90)
   int nf = 0;
   double T[MAXF][MAXF], A[MAXF][MAXF], Kc[MAXF][MAXF];
   unsigned char nl[MAXF][MAXF];  // 1: dS_e/du_f is not identically zero
@@ -348,7 +349,7 @@ __device__ __forceinline__ void gen_source(const GenModel& m, const double (&v)[
       const double well = (2.0 * ei * ((1.0 - ei) * (1.0 - ei)) - 2.0 * (ei * ei) * (1.0 - ei)) + 2.0 * al * ei * (e2 - ei * ei);
       S[2 + i] = L * ((fb - fa) * bm2_hp(ei) + w * well);
     }
-  } else if (m.kind == 1) {  // BM1: mu row carries - int f'(c) lambda (bench1.py:60-66, d_fp)
+  } else if (m.kind == 1 || m.kind == 6) {  // BM1 / BM6: mu row carries - int f'(c) lambda (bench1.py:60-66, d_fp)
     const double a = v[0] - m.q[0], b = m.q[1] - v[0];
     S[1] = -(m.q[2] * ((a * b) * (b - a)));
   } else {
@@ -385,7 +386,7 @@ __device__ __forceinline__ void gen_dsource_row(const GenModel& m, int e, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[2 + j] = j == i ? L * ((fb - fa) * bm2_hpp(ei) + w * well2) : L * w * 4.0 * al * ei * v[2 + j];
     }
-  } else if (m.kind == 1) {
+  } else if (m.kind == 1 || m.kind == 6) {
     if (e == 1) {
       const double a = v[0] - m.q[0], b = m.q[1] - v[0];
       d[0] = -(m.q[2] * ((b * b - 4.0 * (a * b)) + a * a));  // - f''(c), d_fpp
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(256) void gen_residual_kernel(const FemParams p, co
     double R = acc[e];
 #pragma unroll
     for (int f = 0; f < NF; ++f) R += (m.T[e][f] * inv_dt) * md[f] + m.A[e][f] * mk[f] + m.Kc[e][f] * kk[f];
+    if (NF == 3 && e == 2 && m.kind == 6 && is_dirichlet(p, n)) R = u.u[2][n] - phi_bc(p, n);
     r[e] = -R;
   }
 }
@@ -587,6 +589,17 @@ __global__ __launch_bounds__(256) void gen_cell_jacobian_kernel(const FemParams 
           const double val = (cm * Mij + ck * Ke[9 * t + 3 * i + j]) + G[f][sym[i][j]];
           A[(la4[k][i] * NF + e) * W + la4[k][j] * NF + f] += val;
         }
+    }
+  }
+  if (NF == 3 && e == 2 && m.kind == 6) {
+    // Dirichlet phi rows (corners on x = 0 / x = L): identity.  A boundary corner belongs to two cells (one at the
+    // domain's corners): each contributes its share of the 1 on the diagonal.
+    const int ci = cell % p.N, cj = cell / p.N;
+    for (int a = 0; a < 4; ++a) {
+      const int i = ci + (a & 1), j = cj + (a >> 1);
+      if (i != 0 && i != p.N) continue;
+      for (int c = 0; c < W; ++c) A[(a * NF + 2) * W + c] = 0.0;
+      A[(a * NF + 2) * W + a * NF + 2] = (j == 0 || j == p.N) ? 1.0 : 0.5;
     }
   }
 }
@@ -1040,6 +1053,17 @@ __global__ __launch_bounds__(256) void gen_identity_kernel(const FemParams p, do
 
 }  // namespace
 
+// generic kernels are instantiated for 2 (BM1, BM3), 3 (BM6) and 6 (BM2) fields per node
+template <class F>
+static void with_nf(int nf, F&& f) {
+  if (nf == 6)
+    f(std::integral_constant<int, 6>{});
+  else if (nf == 3)
+    f(std::integral_constant<int, 3>{});
+  else
+    f(std::integral_constant<int, 2>{});
+}
+
 struct FemBE {
   FemParams p;
   hipStream_t stream = nullptr;
@@ -1258,13 +1282,13 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
         FB_BLAS(rocblas_set_pointer_mode(fb->bh3, rocblas_pointer_mode_host));
       }
     }
-    if (condensed && nf == 2) {  // (fembe_create_model overwrites this description with its own)
-      // BM1 (bench1.py:60-77): the same two residual blocks written in the generic form, so that the Newton solve runs
+    if (condensed && (nf == 2 || nf == 3)) {  // (fembe_create_model overwrites this description with its own)
+      // BM1 (bench1.py:60-77) / BM6: the same residual blocks written in the generic form, so that the Newton solve runs
       // on the condensed kernels -- R_c = M (c - c0)/dt + Mob K mu,  R_mu = M mu - kappa K c - int f'(c) lambda
       GenModel& m = fb->gm;
       m.id = 0;
-      m.kind = 1;
-      m.nf = 2;
+      m.kind = nf == 3 ? 6 : 1;
+      m.nf = nf;
       for (int e = 0; e < MAXF; ++e) {
         m.gradc[e] = 0.0;
         for (int f = 0; f < MAXF; ++f) {
@@ -1282,11 +1306,18 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       m.A[1][1] = 1.0;
       m.Kc[1][0] = -kappa;
       m.nl[1][0] = 1;
+      if (nf == 3) {  // BM6 (pfbase.py:410-421, bench6.py:60-75): R_mu -= k M phi;  R_phi = -K phi + (k / eps) M c
+        m.A[1][2] = -k;
+        m.A[2][0] = k / eps;
+        m.Kc[2][2] = -1.0;
+      }
       fb->u.u[0] = fb->c;
       fb->u.u[1] = fb->mu;
+      fb->u.u[2] = fb->phi;
       fb->u0.u[0] = fb->c0;
       fb->u0.u[1] = fb->mu0;
-      fb->gen_nf = 2;
+      fb->u0.u[2] = fb->phi0;
+      fb->gen_nf = nf;
     }
     return 0;
   };
@@ -1473,12 +1504,13 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
     ~Restore() { f->rhs = r; }
   } restore{fb, rhs_saved};
   FB_HIP(hipMemsetAsync(fb->rhs, 0, sizeof(double) * fb->vec_len, fb->stream));
-  if (fb->gen_nf == 6)
-    hipLaunchKernelGGL(gen_residual_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
-                       fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
-  else if (fb->gen_nf == 2)
-    hipLaunchKernelGGL(gen_residual_kernel<2>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm, fb->ell_col,
-                       fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0, inv_dt, fb->rhs);
+  if (fb->gen_nf)
+    with_nf(fb->gen_nf, [&](auto nfc) {
+      constexpr int NF = decltype(nfc)::value;
+      hipLaunchKernelGGL(gen_residual_kernel<NF>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
+                         fb->ell_col, fb->ell_K, fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->u, fb->u0,
+                         inv_dt, fb->rhs);
+    });
   else
   hipLaunchKernelGGL(fem_residual_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->ell_col, fb->ell_K,
                      fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
@@ -1549,17 +1581,13 @@ static int block_solve_bcr(FemBE* fb) {
       double* Ue = Uc + (int64_t)s * bs;
       double* re = fb->rhs + (int64_t)s * nb;
       const dim3 gs((2 * nb + 1 + 255) / 256, ne);
-      if (fb->gen_nf == 6) {
-        hipLaunchKernelGGL(row_factor_kernel<6>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
-                           ne, fb->fac);
-        hipLaunchKernelGGL(row_solve_kernel<6>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re, st,
-                           sv);
-      } else {
-        hipLaunchKernelGGL(row_factor_kernel<2>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st,
-                           ne, fb->fac);
-        hipLaunchKernelGGL(row_solve_kernel<2>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re, st,
-                           sv);
-      }
+      with_nf(fb->gen_nf, [&](auto nfc) {
+        constexpr int NF = decltype(nfc)::value;
+        hipLaunchKernelGGL(row_factor_kernel<NF>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st, ne,
+                           fb->fac);
+        hipLaunchKernelGGL(row_solve_kernel<NF>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re,
+                           st, sv);
+      });
       FB_HIP(hipGetLastError());
     }
     // D_e^-1 [L_e | U_e | r_e] of the dense levels.  The U-side work (the solves for U_e and r_e, U_next, the right-hand
@@ -1607,10 +1635,10 @@ static int block_solve_bcr(FemBE* fb) {
     if (banded) {
       auto band_gemm = [&](const double* Lb, const double* X, double* C, double beta, int count) {
         const dim3 g((nb + 255) / 256, (nb + 7) / 8, count);
-        if (fb->gen_nf == 6)
-          hipLaunchKernelGGL(band_gemm_kernel<6>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
-        else
-          hipLaunchKernelGGL(band_gemm_kernel<2>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+        with_nf(fb->gen_nf, [&](auto nfc) {
+          constexpr int NF = decltype(nfc)::value;
+          hipLaunchKernelGGL(band_gemm_kernel<NF>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+        });
       };
       if (nl > 0) {
         band_gemm(Lc + j0 * bs, Xu, fb->D + j0 * bs, 1.0, nl);
@@ -1702,23 +1730,20 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     if (cp)  // keep -R(u): condensation and the solve overwrite rhs (with the Newton direction d in the end)
       FB_HIP(hipMemcpyAsync(fb->rhs0, fb->rhs, sizeof(double) * fb->vec_len, hipMemcpyDeviceToDevice, fb->stream));
     const int ncell = p.N * p.N;
-    if (fb->gen_nf == 6 && p.cond) {
-      hipLaunchKernelGGL(gen_cell_jacobian_kernel<6>, dim3((ncell * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
-                         fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
-      hipLaunchKernelGGL(gen_condense_kernel<6>, dim3((ncell * 24 + 255) / 256), dim3(256), 0, fb->stream, p,
-                         (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
-    } else if (fb->gen_nf == 2 && p.cond) {
-      hipLaunchKernelGGL(gen_cell_jacobian_kernel<2>, dim3((ncell * 2 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
-                         fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
-      hipLaunchKernelGGL(gen_condense_kernel<2>, dim3((ncell * 8 + 255) / 256), dim3(256), 0, fb->stream, p,
-                         (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
-    } else if (fb->gen_nf == 6) {
-      hipLaunchKernelGGL(gen_jacobian_kernel<6>, dim3((p.ntri * 6 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
-                         fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
-      hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
-    } else if (fb->gen_nf == 2) {
-      hipLaunchKernelGGL(gen_jacobian_kernel<2>, dim3((p.ntri * 2 + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
-                         fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
+    if (fb->gen_nf && p.cond) {
+      with_nf(fb->gen_nf, [&](auto nfc) {
+        constexpr int NF = decltype(nfc)::value;
+        hipLaunchKernelGGL(gen_cell_jacobian_kernel<NF>, dim3((ncell * NF + 255) / 256), dim3(256), 0, fb->stream, p,
+                           fb->gm, fb->tri, fb->Ke, fb->u, inv_dt, fb->Aloc);
+        hipLaunchKernelGGL(gen_condense_kernel<NF>, dim3((ncell * 4 * NF + 255) / 256), dim3(256), 0, fb->stream, p,
+                           (const double*)fb->Aloc, fb->rhs, fb->D, fb->Lo, fb->Up);
+      });
+    } else if (fb->gen_nf) {  // PFHIP_FEM_CONDENSE=0: cell centres stay in the blocks (BM2, BM3)
+      with_nf(fb->gen_nf, [&](auto nfc) {
+        constexpr int NF = decltype(nfc)::value;
+        hipLaunchKernelGGL(gen_jacobian_kernel<NF>, dim3((p.ntri * NF + 255) / 256), dim3(256), 0, fb->stream, p, fb->gm,
+                           fb->tri, fb->Ke, fb->u, inv_dt, fb->D, fb->Lo, fb->Up);
+      });
       hipLaunchKernelGGL(gen_identity_kernel, dim3((p.N * p.nf + 255) / 256), dim3(256), 0, fb->stream, p, fb->D);
     } else {
     hipLaunchKernelGGL(fem_jacobian_kernel, dim3((p.ntri + 255) / 256), dim3(256), 0, fb->stream, p, fb->tri, fb->Ke,
@@ -1729,19 +1754,18 @@ int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
     FB_HIP(hipGetLastError());
     rc = fb->solver == 1 ? block_solve(fb) : block_solve_bcr(fb);
     if (rc) return rc;
-    if (fb->gen_nf == 6 && p.cond)
-      hipLaunchKernelGGL(gen_backsub_kernel<6>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
-                         (const double*)fb->Aloc, fb->rhs);
-    else if (fb->gen_nf == 2 && p.cond)
-      hipLaunchKernelGGL(gen_backsub_kernel<2>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
-                         (const double*)fb->Aloc, fb->rhs);
+    if (fb->gen_nf && p.cond)
+      with_nf(fb->gen_nf, [&](auto nfc) {
+        constexpr int NF = decltype(nfc)::value;
+        hipLaunchKernelGGL(gen_backsub_kernel<NF>, dim3((ncell + 255) / 256), dim3(256), 0, fb->stream, p,
+                           (const double*)fb->Aloc, fb->rhs);
+      });
     auto gen_update = [&](double scale) {
-      if (fb->gen_nf == 6)
-        hipLaunchKernelGGL(gen_update_kernel<6>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
+      with_nf(fb->gen_nf, [&](auto nfc) {
+        constexpr int NF = decltype(nfc)::value;
+        hipLaunchKernelGGL(gen_update_kernel<NF>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
                            (const double*)fb->rhs, fb->u, scale);
-      else
-        hipLaunchKernelGGL(gen_update_kernel<2>, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p,
-                           (const double*)fb->rhs, fb->u, scale);
+      });
     };
     if (fb->gen_nf) {
       gen_update(1.0);

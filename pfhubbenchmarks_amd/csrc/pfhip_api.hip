@@ -584,10 +584,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     } else if (cfg->model == PF_MODEL_BM3) {
       frc = fembe_create_model(&h->fb, 3, cfg->n[0], cfg->h, cfg->model_params, h->stream, &h->err);
     } else {
-      // BM1: cell-centre unknowns condensed out before the block solve (PFHIP_FEM_CONDENSE=0: the full blocks); BM6 keeps
-      // the c / mu / phi kernels with their Dirichlet rows
+      // cell-centre unknowns condensed out before the block solve (PFHIP_FEM_CONDENSE=0: the full blocks, assembled by
+      // the c / mu / phi kernels)
       const char* ce = getenv("PFHIP_FEM_CONDENSE");
-      const bool cond = cfg->model != PF_MODEL_BM6 && !(ce && ce[0] == '0');
+      const bool cond = !(ce && ce[0] == '0');
       frc = fembe_create(&h->fb, cfg->n[0], cfg->h, cfg->model == PF_MODEL_BM6 ? 3 : 2, cfg->rho_s, cfg->c_alpha,
                          cfg->c_beta, cfg->kappa, cfg->M, cfg->k, cfg->eps_r, h->stream, &h->err, cond);
     }
