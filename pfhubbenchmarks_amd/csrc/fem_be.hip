@@ -855,6 +855,8 @@ __global__ __launch_bounds__(256) void row_solve_kernel(int nb, int n1, const do
   double y[NF];
 #pragma unroll
   for (int a = 0; a < NF; ++a) y[a] = 0.0;
+  // (unrolled so that the column loads of the next corners are in flight while this one's recurrence is evaluated)
+#pragma unroll 4
   for (int l = l0; l < n1; ++l) {
     const double* Fl = F + (int64_t)l * 3 * NF * NF;
     double t[NF];
@@ -875,6 +877,7 @@ __global__ __launch_bounds__(256) void row_solve_kernel(int nb, int n1, const do
 #pragma unroll
     for (int a = 0; a < NF; ++a) col[l * NF + a] = y[a];
   }
+#pragma unroll 4
   for (int l = n1 - 2; l >= 0; --l) {  // y holds x_(l+1)
     const double* Fl = F + (int64_t)l * 3 * NF * NF;
     double x[NF];
@@ -911,7 +914,10 @@ __global__ __launch_bounds__(256) void band_gemm_kernel(int nb, const double* __
   }
   const double* Xm = X + (int64_t)m * strideX;
   double* Cm = C + (int64_t)m * strideC;
-  for (int j = blockIdx.y * 8; j < min(nb, blockIdx.y * 8 + 8); ++j) {
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {  // fixed trip count: the 8 x 3 NF loads of a strip are issued together
+    const int j = blockIdx.y * 8 + jj;
+    if (j >= nb) break;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 3 * NF; ++k) {
