@@ -1000,13 +1000,15 @@ def test_fem_be_static_condensation_equals_the_full_block_solve(lib, model, n, h
     (the first implementation, pinned to the reference CSVs in round 2; for BM1 / BM6 that is the c / mu / phi kernels with
     BM6's Dirichlet rows): same Newton iterates up to rounding -- same
     iteration counts, fields to 1e-10, incl. the cp line search (BM2).  Also against the other solver variants kept behind
-    switches: the sequential block Thomas solve, dense kernels on the first reduction level, one stream."""
+    switches: the sequential block Thomas solve, dense kernels on the first reduction level, one stream, row exchanges in
+    every factorisation (the default factors the small batches of the dense levels without them)."""
     out = {}
-    for cond in ("1", "0", "thomas", "dense0", "onestream"):
+    for cond in ("1", "0", "thomas", "dense0", "onestream", "allpivot"):
         monkeypatch.setenv("PFHIP_FEM_CONDENSE", "0" if cond == "0" else "1")
         monkeypatch.setenv("PFHIP_FEM_SOLVER", "thomas" if cond == "thomas" else "bcr")     # sequential block solve
         monkeypatch.setenv("PFHIP_FEM_BAND0", "0" if cond == "dense0" else "1")             # dense kernels on level 0
         monkeypatch.setenv("PFHIP_FEM_STREAMS", "1" if cond == "onestream" else "0")        # no side streams
+        monkeypatch.setenv("PFHIP_FEM_PIVOT", "1" if cond == "allpivot" else "auto")        # row exchanges in every LU
         with PhaseFieldSolver(dim=2, n=n, h=h, bc="mirror", scheme="fem_be", model=model, max_newton=100) as s:
             {"bm1": s.set_ic_bm1, "bm2": s.set_ic_bm2, "bm3": s.set_ic_bm3, "bm6": s.set_ic_bm6}[model]()
             its = []
@@ -1018,7 +1020,7 @@ def test_fem_be_static_condensation_equals_the_full_block_solve(lib, model, n, h
                      "bm6": ("c", "mu", "phi")}[model]
             out[cond] = (its, [s.get_field(k) for k in names], s.diagnostics())
     assert max(out["1"][0]) >= 2, out["1"][0]
-    for other in ("0", "thomas", "dense0", "onestream"):      # every solver variant lands on the same Newton iterates
+    for other in ("0", "thomas", "dense0", "onestream", "allpivot"):      # every variant lands on the same Newton iterates
         assert out["1"][0] == out[other][0], (other, out["1"][0], out[other][0])
         for a, b in zip(out["1"][1], out[other][1]):
             assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), other
