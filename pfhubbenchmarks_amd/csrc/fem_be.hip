@@ -1603,7 +1603,8 @@ static int block_solve_bcr(FemBE* fb) {
     // stream the two halves run side by side -- these levels are batches of <= 25 launch-latency-bound kernels.
     const bool two = !banded && fb->bh2;
     // row exchanges: only in batches of more than 32 matrices (default; see fembe_step), always (PFHIP_FEM_PIVOT=1), never (=0)
-    const bool lvl_pivot = fb->pivot_mode == 1 || fb->force_pivot || (fb->pivot_mode == 2 && ne > 32);
+    // (blocks below ~400 unknowns -- BM1's 202, BM6's 303 -- are faster through rocSOLVER's getrs: bench1.py 4.2 vs 5.7 s)
+    const bool lvl_pivot = fb->pivot_mode == 1 || fb->force_pivot || (fb->pivot_mode == 2 && (ne > 32 || nb < 400));
     rocblas_handle hU = two ? fb->bh2 : fb->bh;  // U_e solve, U_next
     rocblas_handle hR = two ? fb->bh3 : fb->bh;  // r_e solve, right-hand-side updates (third stream)
     double *Xl = Lc + (int64_t)s * bs, *Xu = Uc + (int64_t)s * bs, *xr = fb->rhs + (int64_t)s * nb;
@@ -1835,7 +1836,7 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
   return 0;
 }
 
-// The small batches of the dense reduction levels are factored WITHOUT row exchanges by default (no pivot search, no
+// The small batches of the dense reduction levels (blocks of 400+ unknowns: BM2, BM3) are factored WITHOUT row exchanges by default (no pivot search, no
 // row-swap kernels, rocBLAS triangular solves that spread over the three streams): BM2 23.4 -> 17.0 s, BM3 18.6 -> 16.4 s
 // on the same box, results identical to the last digit of the CSV comparison.  An LU without pivoting of these
 // Schur-complement blocks carries no stability guarantee, so the Newton iteration is the judge: a step that does not
