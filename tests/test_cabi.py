@@ -124,3 +124,18 @@ def test_ext_buffer_offsets_follow_the_placement_rule():
         assert (o1 * 8) % (512 * 1024) == 64 * 1024 and (o2 * 8) % (512 * 1024) == 448 * 1024
         assert o1 * 8 < elems * 8 + 576 * 1024 + 64 * 1024          # no more than one period of padding
     assert lib.pf_ext_buffer_offset(C.byref(cfg), 3) < 0
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """The A/B switches read by the library (getenv("PFHIP_...") in csrc/) are all named in DESIGN.md."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "pfhubbenchmarks_amd", "csrc", "*.hip")):
+        names |= set(re.findall(r'getenv\("(PFHIP_[A-Z0-9_]+)"\)', open(f).read()))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    assert len(names) >= 10
+    missing = sorted(n for n in names if n not in design)
+    assert not missing, missing
