@@ -93,7 +93,7 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
     """config 1 (reference's own discretisation): accepted backward-Euler steps on the committed time grid.
     Returns the JSON dict (the caller prints it, or nests it under `also`)."""
     steps = a.steps if steps is None else steps
-    warmup = warmup if warmup is None else warmup
+    warmup = a.warmup if warmup is None else warmup
     import importlib.util
     import numpy as np
     import torch
@@ -154,6 +154,62 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
     return out
 
 
+def bench_fem_multi(a, model, steps=6, warmup=2, cpu=True):
+    """BM2 / BM3 in the BE-parity mode: accepted backward-Euler steps of the reference's own
+    discretisation (dolfin/bench2.py:76-113 on the 100 x 100 crossed mesh, 6 fields; bench3.py:63-97 on 350 x 350, 2
+    fields) on the committed time grid; node-updates/s.  CPU leg: ONE Newton iteration of oracle/fem_multi.py (scipy
+    SuperLU; a whole step costs it 100-200 s here), extrapolated to the iterations the timed steps took -- for BM3 on a
+    120 x 120 mesh, scaled by nodes."""
+    import numpy as np
+    import torch
+    from pfhubbenchmarks_amd.drivers import report_times
+    from pfhubbenchmarks_amd.solver import PhaseFieldSolver
+    bench = "bench2" if model == "bm2" else "bench3"
+    N, L_dom = (100, 200.0) if model == "bm2" else (350, 960.0)
+    times = report_times(bench)
+    nodes = (N + 1) ** 2 + N * N
+    nf = 6 if model == "bm2" else 2
+    with PhaseFieldSolver(dim=2, n=N + 1, h=L_dom / N, bc="mirror", scheme="fem_be", model=model, max_newton=100) as s:
+        (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+        tprev, its = 0.0, 0
+        for i in range(warmup):
+            s.step(times[i] - tprev, 1, check=True)
+            tprev = times[i]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            ok, _, _ = s.step(times[i] - tprev, 1, check=True)
+            assert ok
+            its += s.last_iters
+            tprev = times[i]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        F, C, _ = s.diagnostics()
+    ref_wall = {"bm2": "22 s on 32 cores for the whole 120-row run (dolfin/bench2.py:140 comment)",
+                "bm3": "27 s on 128 cores for the whole 46-row run (dolfin/bench3.py:125 comment)"}[model]
+    out = {"metric": "node-updates/sec on PFHub %s, reference algorithm (P1 crossed mesh, backward Euler, Newton)" % model.upper(),
+           "value": nodes * steps / el, "unit": "node-updates/s", "ms_per_step": el / steps * 1e3, "steps": steps,
+           "warmup": warmup, "dtype": "f64",
+           "config": {"workload": "%s_fem_be" % model, "mesh": "%dx%d crossed, %d nodes x %d fields = %d dofs" % (N, N, nodes, nf, nodes * nf),
+                      "time_grid": "rows %d..%d of results/%s_out.csv" % (warmup, warmup + steps - 1, bench),
+                      "newton_iterations": its, "reference_wall_time": ref_wall},
+           "check": {"t": float(tprev), "F": F, "second_column": C}}
+    if cpu:
+        from oracle import ch_fd, fem_multi
+        Ns = N if model == "bm2" else 120
+        o = fem_multi.MultiFieldBE(model, N=Ns, newton_max=1)
+        t0 = time.perf_counter()
+        o.step(times[0])                       # exactly one Newton iteration: residual, Jacobian, sparse LU, solve
+        t_it = time.perf_counter() - t0
+        nodes_s = (Ns + 1) ** 2 + Ns * Ns
+        out["cpu_baseline"] = {"value": nodes_s * steps / (t_it * its), "unit": "node-updates/s", "cores": ch_fd.host_cores(),
+                               "kind": "port",
+                               "sample": "1 Newton iteration (%.1f s) of oracle/fem_multi.py (scipy SuperLU) on the %dx%d "
+                                         "crossed mesh, extrapolated to the %d iterations of the %d timed steps" % (
+                                             t_it, Ns, Ns, its, steps)}
+    return out
+
+
 def measured_traffic(workload, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
     separate runs, FETCH_SIZE x2 per MI355X_MICROARCH.md) of THIS workload with the default kernel variant;
@@ -186,8 +242,13 @@ def main():
                     help="FD slab path (N > 1 or --slab): 'wide' = PF_FLAG_WIDE_HALO, 4 ghost planes exchanged every second "
                          "step (half the hand-offs, 8 instead of 12 redundant plane reads per step); 'narrow' = 2 ghost "
                          "planes every step.  Bit-identical results.")
+    ap.add_argument("--strips", default="inline", choices=["side", "inline"],
+                    help="FD slab path over RCCL: 'side' = the boundary strips of a step run on a stream of their own "
+                         "(pf_set_strip_stream: interior launch || exchange -> strips; the exchange wait leaves the critical "
+                         "path); 'inline' = behind the interior launch on the compute stream (round-2 form).  Bit-identical.")
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c", "bm1_spectral_1024c",
-                             "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be"])
+                             "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be", "bm2_fem_be", "bm3_fem_be",
+                             "bm2_fd_512c", "bm3_fd_512c"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
     ap.add_argument("--target-wgs", type=int, default=0, help="pfk_set_tuning key 1")
@@ -204,9 +265,9 @@ def main():
                          "written by a side-stream kernel (pfhubbenchmarks_amd.solver.IpcHaloTransport; one node)")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 100 if a.workload == "bm1_fem_be" else 200
+        a.steps = 100 if a.workload == "bm1_fem_be" else (20 if a.workload.endswith("_fem_be") else 200)
     if a.warmup is None:
-        a.warmup = 10 if a.workload == "bm1_fem_be" else 20
+        a.warmup = 10 if a.workload == "bm1_fem_be" else (2 if a.workload.endswith("_fem_be") else 20)
 
     import torch
     from pfhubbenchmarks_amd import lib as L
@@ -221,9 +282,11 @@ def main():
     if rehearsal:
         local_rank = 0
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (a.gpus, a.gpus))
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # one command, like the reference's `mpirun -np N python dolfin/bench1.py` (README.md:22): start the one-process-
+            # per-GPU job ourselves -- as a CHILD process, before this process touches the GPU -- relay its output (rank 0
+            # prints the JSON line) and exit with its return code
+            sys.exit(spawn_ranks(a.gpus))
         sys.exit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     lib = L.load()                      # raises if the HIP extension is missing: no fallback
     if not torch.cuda.is_available():
@@ -240,6 +303,13 @@ def main():
 
     if a.workload == "bm1_fem_be":
         print(json.dumps(bench_fem_be(a, world)), flush=True)
+        return
+    if a.workload in ("bm2_fem_be", "bm3_fem_be"):
+        if world != 1:
+            sys.exit("%s is a single-GPU workload" % a.workload)
+        o = bench_fem_multi(a, a.workload[:3], steps=min(a.steps, 40), warmup=min(a.warmup, 4), cpu=not a.no_cpu_baseline)
+        o.update(n_gpus=1, higher_is_better=True, scaling="weak", vs_baseline=None, data="synthetic", roofline=None)
+        print(json.dumps(o), flush=True)
         return
 
     dist = None
@@ -261,6 +331,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench.py] --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
 
 
 def workload_table(workload, world):
@@ -292,6 +376,17 @@ def workload_table(workload, world):
         w.update(dim=2, gn=(512, 512, 1)) if workload.endswith("512s") else w.update(gn=(256, 256, 256))
         if world > 1:
             sys.exit("this 2-D / small spectral workload is single-GPU; use bm1_spectral_512c for N > 1")
+    elif workload in ("bm2_fd_512c", "bm3_fd_512c"):
+        # SURVEY 8f next-4 on the stencil design: explicit FD for the multi-field models (dolfin/bench2.py:76-113,
+        # bench3.py:63-97), streaming LDS-tiled kernels (csrc/multi_fd.hip).  Algorithmic bytes per cell-update = every field
+        # read once and written once: BM2 5 fields = 80 B, BM3 2 fields = 32 B (BM2's separate mu pass moves 136 B: the
+        # roofline figure is still quoted against 80)
+        if world > 1:
+            sys.exit("%s is single-GPU" % workload)
+        if workload.startswith("bm2"):
+            w.update(model="bm2", bytes_per_cell=80.0, gn=(512, 512, 512), dt=2e-4)
+        else:
+            w.update(model="bm3", bytes_per_cell=32.0, gn=(512, 512, 512), dt=2e-3)
     elif workload == "bm1_fd_512s":
         w.update(dim=2, gn=(512, 512, 1), dt=1e-3)
     elif workload == "bm1_fd_512c":
@@ -334,9 +429,11 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
             solver = FFTSlabSolver(eng)
         else:
-            wide = a.halo == "wide" and not a.fused_slab and eng_planes(gn[2], world, rank) >= 4
+            wide = a.halo == "wide" and not a.fused_slab and gn[2] // world >= 4     # the smallest slab: same answer on every rank
             eng = HipSlabEngine(gn, h, world, rank, local_rank, wide=wide)
             eng.set_ic_bm1(0.5, 0.05)
+            if a.strips == "side" and a.transport == "rccl":
+                eng.use_strip_stream()
             solver = SlabSolver(eng, transport=a.transport, fused=a.fused_slab)
         timer = eng
         local_cells = gn[0] * gn[1] * eng.nz
@@ -352,7 +449,7 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
         n = gn[:dim]
         s = PhaseFieldSolver(dim=dim, n=n, h=h, kernel=a.kernel, device=local_rank, scheme=scheme, model=model,
                              eliminate_phi=elim)
-        (s.set_ic_bm6 if model == "bm6" else s.set_ic_bm1)()
+        {"bm6": s.set_ic_bm6, "bm1": s.set_ic_bm1, "bm2": s.set_ic_bm2, "bm3": s.set_ic_bm3}[model]()
         solver = timer = s
         local_cells = gn[0] * gn[1] * gn[2]
 
@@ -413,7 +510,7 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
     els = max_over_ranks([b[0] for b in blocks])
     mi = _median_index(els)
     el, (_, k_ms, k_launches) = els[mi], blocks[mi]
-    if not per_launch_events:
+    if not per_launch_events or k_launches == 0:      # (the multi-field FD path records no per-launch events)
         k_ms, k_launches = el / steps * 1e3, steps
     F1, C1, _ = solver.diagnostics()
     if getattr(solver, "transport", None) is not None:
@@ -421,14 +518,29 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
 
     total_cells = gn[0] * gn[1] * gn[2]
     value = total_cells * steps / el
+    # who took part: world size of the process group and the device every rank ran on (checkable evidence of an N-rank job)
+    dev_name = torch.cuda.get_device_name(local_rank)
+    if dist is not None:
+        mine = [{"rank": rank, "device": local_rank, "pid": os.getpid()}]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine[0])
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered,
+                      "device_name": dev_name}
+    else:
+        ranks_info = {"world_size": 1, "backend": None, "ranks": [{"rank": 0, "device": local_rank, "pid": os.getpid()}],
+                      "device_name": dev_name}
     # dominant kernel: all step launches of this rank (1 per step on one GPU; interior + 2 boundary launches per
     # step in slab mode, summed)
     kernel_s_per_step = k_ms * 1e-3 * k_launches / max(steps, 1)
-    achieved = bytes_per_cell * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+    achieved_events = bytes_per_cell * local_cells / kernel_s_per_step / 1e9 if kernel_s_per_step > 0 else 0.0
+    # the headline roofline figure comes from the WALL clock of the timed block (the same clock as `value`); the HIP-event
+    # average of the step launches sits beside it (it excludes the few us between launches, so it reads 1-2 % higher)
+    achieved = bytes_per_cell * local_cells * steps / el / 1e9
     block_ms = [e / steps * 1e3 for e in els]
     out = {
         "metric": "cell-updates/sec on PFHub %s (%s)" % (
-            "BM1 Cahn-Hilliard" if model == "bm1" else "BM6 Cahn-Hilliard + Poisson",
+            {"bm1": "BM1 Cahn-Hilliard", "bm6": "BM6 Cahn-Hilliard + Poisson", "bm2": "BM2 Ostwald ripening (c + 4 order parameters)",
+             "bm3": "BM3 dendritic growth (U, phi)"}[model],
             ("explicit FD, fused HIP stencil" + (" + FFT Poisson" if model == "bm6" else "")) if scheme == "fd"
             else "semi-implicit spectral; hand-written LDS-FFT passes on power-of-two grids 128..1024, rocFFT + HIP k-space kernels otherwise"),
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -439,7 +551,8 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
                    "parallelism": "slab%d%s%s%s%s" % (world, "-forced" if a.slab else "", "-REHEARSAL-one-device-gloo" if rehearsal else "",
                                                     ("-ipc-fused" if a.fused_slab else "-ipc")
                                                     if (dist is not None and a.transport == "ipc") else "",
-                                                    "-widehalo" if (slab and getattr(timer, "wide", False)) else "")},
+                                                    ("-widehalo" if (slab and getattr(timer, "wide", False)) else "") +
+                                                    ("-sidestrips" if (slab and getattr(timer, "strip_stream", None) is not None) else ""))},
         # timed-region bookkeeping: what ran before the clock started, and every timed block (the reported one is the median)
         "preheat_ms": preheat_ms, "preheat_steps": preheat_steps, "repeats": len(blocks),
         "block_ms_per_step": block_ms,
@@ -449,8 +562,12 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
                      "traffic": measured_traffic(workload, a.variant) if world == 1 else None,
                      "traffic_source": "profiles/r*/summary_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
                                        "bytes per launch)" % workload,
+                     "timing": "wall clock of the timed block (ms_per_step); achieved_hip_events = the same bytes over the "
+                               "HIP-event average of the step launches",
+                     "achieved_hip_events": achieved_events, "frac_hip_events": achieved_events / HBM_PEAK_GBS,
                      "kernel_ms_per_step": kernel_s_per_step * 1e3, "launches_per_step": k_launches / max(steps, 1),
                      "bytes_per_cell_update": bytes_per_cell},
+        "ranks": ranks_info,
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
     if scheme == "spectral" and not slab:
@@ -484,7 +601,7 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
                                           "kernel": "pfk_stream_copy (one 16-byte element per thread), %d doubles, 20 launches"
                                                     % local_cells}
         out["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
-    if model == "bm6" or not cpu:
+    if model in ("bm6", "bm2", "bm3") or not cpu:
         pass          # no CPU leg for the BM6 box (the BM6 oracle is a test checker, minutes per step at this size)
     elif rank == 0 and world == 1 and scheme == "spectral":
         out["cpu_baseline"] = cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8)
@@ -532,6 +649,17 @@ def side_measurements(a, ctx):
                                                      "block_ms_per_step", "steady", "roofline", "check")}
     also["bm1_spectral_512c"]["config"] = dict(sp3["config"], note="semi-implicit spectral scheme on the 512^3 box: four "
                                                "hand-written LDS-FFT passes per step; roofline at the 72 B/cell-update idealisation")
+    keys = ("value", "unit", "ms_per_step", "steps", "warmup", "preheat_ms", "repeats", "block_ms_per_step", "steady",
+            "roofline", "check")
+    for name, note in (("bm6_fd_512c", "BASELINE.json config 5 on ONE GPU, periodic box: FFT Poisson solve (hand-written passes) + "
+                                       "coupled fused FD step per step; roofline at 72 B/cell-update (CH 16 + phi 8 + Poisson 48)"),
+                       ("bm6_fd_512c_elim", "the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c)): the "
+                                            "fused kernel alone, 16 B/cell-update")):
+        b6 = bench_grid(a, name, ctx, max(10, min(a.steps, 40)), min(a.warmup, 10), cpu=False)
+        also[name] = {k: b6[k] for k in keys}
+        also[name]["config"] = dict(b6["config"], note=note)
+    for model in ("bm2", "bm3"):
+        also["%s_fem_be" % model] = bench_fem_multi(a, model, steps=6, warmup=2, cpu=not a.no_cpu_baseline)
     if not a.no_cpu_baseline:
         fb = bench_fem_be(a, 1, steps=8, warmup=2, ncpu_max=3)
         also["bm1_fem_be"] = {k: fb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "check",

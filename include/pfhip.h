@@ -49,7 +49,7 @@ typedef enum pf_status {
   PF_OK = 0,
   PF_ERR_INVALID = -1,     /* bad argument / config (programmer error) */
   PF_ERR_UNSUPPORTED = -2, /* valid request this build cannot do */
-  PF_ERR_HIP = -3,         /* HIP runtime / hipFFT error (message in pf_last_error) */
+  PF_ERR_HIP = -3,         /* HIP runtime / rocFFT / rocSOLVER error (message in pf_last_error) */
   PF_ERR_STATE = -4,       /* call sequence error (e.g. rollback with nothing to roll back) */
   PF_ERR_NOMEM = -5
 } pf_status;
@@ -127,6 +127,11 @@ enum {
                                    Halves the hand-offs per step and cuts the strips' redundant reads from 12 to 8 planes
                                    per step for 4 / nz more arithmetic.  Needs >= 4 (periodic) / 5 (mirror walls) planes per
                                    rank.  Results are bit-identical to the 2-ghost path. */
+  PF_FLAG_FEM_ALWAYS_PIVOT = 4, /* PF_SCHEME_FEM_BE: row exchanges in EVERY dense factorisation of the Newton solve.  By default
+                                   the small batches of 400+-unknown blocks (BM2, BM3) are factored without them, and a Newton
+                                   solve that then fails is repeated once with them.  Same converged states either way; set this
+                                   when the step's ITERATION COUNT steers the run -- the reference's dt rule, bench1.py:180-183
+                                   -- so that the time grid never depends on that optimisation (drivers: controller="reference") */
   PF_FLAG_BM6_ELIMINATE_PHI = 1 /* BM6, periodic box, FD scheme: phi solves lap_h(phi) = -(k/eps)(c - mean c) with the SAME
                                    discrete Laplacian the Cahn-Hilliard step applies to mu, so lap_h(k phi) =
                                    -(k^2/eps)(c - mean c) exactly and the time step needs no Poisson solve:
@@ -246,6 +251,13 @@ int pf_sync(pf_handle* h);
 int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
 int pf_step_begin(pf_handle* h, double dt);
 int pf_step_finish(pf_handle* h);
+/* Launch the boundary strips of pf_step_finish on `stream` instead of the handle's stream (NULL = back to the handle's
+ * stream).  The strips only depend on the ghost planes and on the owned boundary planes of the CURRENT buffer, so on a
+ * stream of their own they run beside the interior launch as soon as the exchange has delivered -- the exchange wait
+ * leaves the critical path.  The caller orders the streams: the strip stream must wait for everything that last read the
+ * output buffer (an event recorded on the handle's stream before pf_step_begin) and for the exchange; the handle's stream
+ * must wait for the strips before the next exchange is posted / the next step begins.  SlabSolver does exactly that. */
+int pf_set_strip_stream(pf_handle* h, void* stream);
 
 /* slab mode, one step in ONE launch (peer-copy transport): the interior chunks are dispatched first; the workgroups
  * of the two boundary strips are dispatched last and poll flag_lo / flag_hi (device words the neighbours publish `seq`
@@ -264,6 +276,12 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req);
  * and sum the 3 doubles over ranks. */
 int pf_diagnostics(pf_handle* h, double out[3]);
 int pf_diagnostics_local(pf_handle* h, double out[3]);
+
+/* Counters of the last pf_step, for tests and logs (solver.solve() reports only (niters, converged), bench1.py:162).
+ * key PF_STAT_FEM_ATTEMPTS: Newton solves the step took (1; 2 = an optimistic solve without row exchanges failed and was
+ * repeated with them); PF_STAT_FEM_NPVT_LEVELS: reduction levels its last attempt factored without row exchanges. */
+enum { PF_STAT_FEM_ATTEMPTS = 0, PF_STAT_FEM_NPVT_LEVELS = 1 };
+int pf_get_stat(pf_handle* h, int key, int64_t* value);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------- */
 /* average device time (ms) of the dominant step kernel over the launches since the last call, measured with
@@ -336,6 +354,14 @@ int pfk_ipc_close(void* dev_ptr);
 /* Measures the cost of one grid-wide barrier (agent-scope release + atomic count-in + acquire) of a cooperative launch
  * with nblocks x nthreads: the price a persistent multi-phase kernel pays instead of a kernel boundary. */
 int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_barrier);
+
+/* The same question for a kernel whose workgroups all sit on ONE XCD (one L2: a hand-off needs no L2 write-back, only
+ * loads that bypass the per-CU L1): `nblocks` workgroups are launched chip-wide, those that landed on XCD 0 (HW_REG_XCC_ID)
+ * stay and run `iters` rounds of { write a 128-byte record, arrive, wait, read the next participant's record (handoff != 0),
+ * arrive, wait }.  us_per_round = two barriers + the hand-off; participants = workgroups that took part; stale = records
+ * read with an old value (must be 0). */
+int pfk_xcd_barrier_probe(int nblocks, int nthreads, int iters, int handoff, double* us_per_round, int* participants,
+                          int* stale);
 
 /* Shader clock actually held, measured inside a kernel: delta s_memtime / delta s_memrealtime x 100 MHz over ~spin_us
  * microseconds, by `nblocks` workgroups.  out_dev: 2 * nblocks DEVICE doubles {MHz, start of the probe in ms of the

@@ -32,8 +32,9 @@ def poisson_periodic(c, h, k=0.09, eps=90.0):
 
 def poisson_dirichlet_x(c_ext, npx, npy, h, k=0.09, eps=90.0):
     """c_ext: even extension (2(npy-1), 2(npx-1)) of the no-flux domain.  Returns the EVEN-in-x extension of phi with
-    phi = 0 on x = 0 and phi = sin(y/7) on x = Lx (same output as poisson_solve in csrc/poisson.hip).  2-D."""
-    ny, nx = c_ext.shape
+    phi = 0 on x = 0 and phi = sin(y/7) on x = Lx (same output as poisson_solve in csrc/poisson.hip).  2-D, or
+    3-D (nz_ext, ny_ext, nx_ext) with z a no-flux axis like y (the boundary data depends on y only)."""
+    ny, nx = c_ext.shape[-2:]
     N = npx - 1
     x = np.arange(nx)
     xr = np.where(x <= N, x, 2 * N - x)
@@ -41,17 +42,17 @@ def poisson_dirichlet_x(c_ext, npx, npy, h, k=0.09, eps=90.0):
     yr = np.where(y < npy, y, 2 * (npy - 1) - y)
     g = np.sin(yr * h / 7.0)
     r = -(k / eps) * c_ext.copy()
-    r[:, xr == N - 1] -= (g / (h * h))[:, None]
+    r[..., xr == N - 1] -= (g / (h * h))[:, None]
     sgn = np.where((xr == 0) | (xr == N), 0.0, np.where(x > N, -1.0, 1.0))
-    r = r * sgn[None, :]
+    r = r * sgn
     lam = _lam(r.shape, h)
     rh = np.fft.rfftn(r)
     with np.errstate(divide="ignore", invalid="ignore"):
         ph = np.where(lam != 0.0, rh / lam, 0.0)
-    phi = np.fft.irfftn(ph, s=r.shape, axes=(0, 1))
-    out = phi * np.where(x > N, -1.0, 1.0)[None, :]
-    out[:, x == 0] = 0.0
-    out[:, x == N] = g[:, None]
+    phi = np.fft.irfftn(ph, s=r.shape, axes=tuple(range(r.ndim)))
+    out = phi * np.where(x > N, -1.0, 1.0)
+    out[..., x == 0] = 0.0
+    out[..., x == N] = g[:, None]
     return out
 
 

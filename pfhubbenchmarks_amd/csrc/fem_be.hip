@@ -1089,6 +1089,11 @@ struct FemBE {
   int pivot_mode = 2;                      // 2 (default): row exchanges only in batches of more than 32 matrices, with a
                                            // pivoted retry of a failed Newton solve; PFHIP_FEM_PIVOT=1: always, =0: never
   bool force_pivot = false;                // set for the retry
+  bool used_npvt = false;                  // the current attempt factored at least one level without row exchanges
+  int npvt_levels = 0;                     // ... how many (statistics of the last attempt)
+  int attempts = 0;                        // Newton solves of the last fembe_step: 1, or 2 (optimistic solve + pivoted repeat)
+  bool test_poison = false;                // TEST ONLY (PFHIP_FEM_TEST_POISON_NPVT=1): spoil the first Newton direction of
+                                           // an attempt that used an un-pivoted factorisation, so that tests reach the repeat
   rocblas_int *piv = nullptr, *info = nullptr;
   double *scal = nullptr, *scal_host = nullptr, *partials = nullptr;
   double *rhs0 = nullptr, *rhs1 = nullptr;         // generic path, line search: -R(u) before the solve, -R(u + d)
@@ -1255,6 +1260,8 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
       const char* pv = getenv("PFHIP_FEM_PIVOT");
       fb->pivot_mode = !pv ? 2 : (pv[0] == '0' ? 0 : (pv[0] == '1' ? 1 : 2));
+      const char* tp = getenv("PFHIP_FEM_TEST_POISON_NPVT");
+      fb->test_poison = tp && tp[0] == '1';
       const char* v = getenv("PFHIP_FEM_VERBOSE");
       fb->verbose = v && v[0] == '1';
     }
@@ -1524,7 +1531,7 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
                      fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
                      fb->rhs);
   hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, (int)fb->vec_len, fb->scal);
-  FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, sizeof(double), hipMemcpyDeviceToHost, fb->stream));
+  FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));  // [3]: info flag
   FB_HIP(hipStreamSynchronize(fb->stream));
   *nrm = std::sqrt(fb->scal_host[0]);
   return 0;
@@ -1557,6 +1564,14 @@ static int block_solve(FemBE* fb) {
   return 0;
 }
 
+// scal[3] <- 1 if any of the n factorisations of a batch reported a zero pivot (rocSOLVER info > 0)
+__global__ void info_flag_kernel(const rocblas_int* __restrict__ info, int n, double* __restrict__ flag) {
+  bool bad = false;
+  for (int i = threadIdx.x; i < n; i += 64) bad = bad || info[i] != 0;
+  if (__any(bad) && threadIdx.x == 0) *flag = 1.0;
+}
+__global__ void poison_kernel(double* __restrict__ x) { x[0] = __longlong_as_double(0x7ff8000000000000LL); }
+
 // Block cyclic reduction: log2(ng) levels; every level eliminates the odd-numbered active blocks with STRIDED-BATCHED
 // rocSOLVER / rocBLAS calls (all blocks of a level factor concurrently -- the sequential block Thomas sweep above
 // is latency-bound: 101 dependent stages of small dense kernels).  Level with stride s, active blocks g = k s:
@@ -1582,7 +1597,9 @@ static int block_solve_bcr(FemBE* fb) {
     double *Lc = Ls[set], *Uc = Us[set], *Ln = Ls[1 - set], *Un = Us[1 - set];
     double* De = fb->D + (int64_t)s * bs;
     rocblas_int* pe = fb->piv + (int64_t)s * nb;
-    const bool banded = fb->band0 && s == 1;  // first level of the condensed system: block-tridiagonal blocks
+    // first level of the condensed system: block-tridiagonal blocks (block Thomas sweep along the row: pivoting inside the
+    // NF x NF blocks only, so the fully pivoted repeat of a failed solve takes the dense kernels here too)
+    const bool banded = fb->band0 && s == 1 && !fb->force_pivot;
     if (banded) {
       const int n1 = p.N + 1;
       double* Le = Lc + (int64_t)s * bs;
@@ -1623,7 +1640,11 @@ static int block_solve_bcr(FemBE* fb) {
       FB_BLAS(rocsolver_dgetrs_strided_batched(hR, rocblas_operation_none, nb, 1, De, nb, st, pe, sv, xr, nb, sv, ne));
       FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xl, nb, st, ne));
     } else if (!banded) {
+      fb->used_npvt = true;
+      ++fb->npvt_levels;
       FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, De, nb, st, fb->info, ne));
+      // an exactly singular leading minor: raise the flag the Newton loop reads with the next residual norm
+      hipLaunchKernelGGL(info_flag_kernel, dim3(1), dim3(64), 0, fb->stream, (const rocblas_int*)fb->info, ne, fb->scal + 3);
       if (fork()) return -3;
       struct Rhs {
         rocblas_handle hh;
@@ -1728,6 +1749,9 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
   const double inv_dt = 1.0 / dt;
   const size_t bsz = sizeof(double) * (size_t)p.nb * p.nb * p.ng;
   *converged = 0;
+  fb->used_npvt = false;
+  fb->npvt_levels = 0;
+  FB_HIP(hipMemsetAsync(fb->scal + 3, 0, sizeof(double), fb->stream));
   int it = 0;
   for (;; ++it) {
     double nrm = 0.0;
@@ -1735,6 +1759,7 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
     if (rc) return rc;
     if (fb->verbose) fprintf(stderr, "[fem_be] dt %.6g newton %d ||R|| %.6e\n", dt, it, nrm);
     if (!(nrm == nrm)) break;  // NaN
+    if (fb->scal_host[3] != 0.0) break;  // an un-pivoted factorisation met a zero pivot: the direction is garbage
     if (nrm < fb->atol) {
       *converged = 1;
       break;
@@ -1771,6 +1796,8 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
     FB_HIP(hipGetLastError());
     rc = fb->solver == 1 ? block_solve(fb) : block_solve_bcr(fb);
     if (rc) return rc;
+    if (fb->test_poison && fb->used_npvt && it == 0)
+      hipLaunchKernelGGL(poison_kernel, dim3(1), dim3(1), 0, fb->stream, fb->rhs);
     if (fb->gen_nf && p.cond)
       with_nf(fb->gen_nf, [&](auto nfc) {
         constexpr int NF = decltype(nfc)::value;
@@ -1842,13 +1869,33 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
 // Schur-complement blocks carries no stability guarantee, so the Newton iteration is the judge: a step that does not
 // converge (or produces NaN) is repeated from the restored state with row exchanges in every factorisation before the
 // failure is reported to the caller.  PFHIP_FEM_PIVOT=1 always pivots, =0 never does (no retry).
+// The repeat happens only when the failed attempt really contained an un-pivoted factorisation (BM1 / BM6 never do: a
+// step they reject was solved with row exchanges throughout, is reported at once and costs one Newton solve, like the
+// reference's, bench1.py:164-177).  The iteration count of a step feeds the reference's dt rule (bench1.py:180-183):
+// drivers that let that rule choose the time grid ask for row exchanges everywhere (PF_FLAG_FEM_ALWAYS_PIVOT), so that
+// their grid never depends on this optimisation.
 int fembe_step(FemBE* fb, double dt, int* converged, int* iters) {
+  fb->attempts = 1;
   int rc = fembe_step_once(fb, dt, converged, iters);
-  if (rc || *converged || fb->pivot_mode != 2 || fb->solver == 1) return rc;
+  if (rc || *converged || fb->pivot_mode != 2 || fb->solver == 1 || !fb->used_npvt) return rc;
   fb->force_pivot = true;
+  fb->attempts = 2;
   rc = fembe_step_once(fb, dt, converged, iters);
   fb->force_pivot = false;
   return rc;
+}
+
+void fembe_set_pivot_always(FemBE* fb) {
+  if (fb->pivot_mode == 2) fb->pivot_mode = 1;  // an explicit PFHIP_FEM_PIVOT=0 (A/B) stays
+}
+
+// key 0: Newton solves of the last step (1 or 2); 1: levels factored without row exchanges in its last attempt
+long long fembe_stat(const FemBE* fb, int key) {
+  switch (key) {
+    case 0: return fb->attempts;
+    case 1: return fb->npvt_levels;
+    default: return -1;
+  }
 }
 
 void fembe_set_max_newton(FemBE* fb, int n) {

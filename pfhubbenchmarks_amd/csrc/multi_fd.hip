@@ -13,6 +13,7 @@
 // The operation order below is restated by oracle/multi_fd.py (numpy, no fma: this file is compiled with
 // -ffp-contract=off) and compared bit for bit.
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -104,6 +105,419 @@ __global__ __launch_bounds__(256) void bm3_update_kernel(const MfdParams p, cons
   const double pt = it * ((W2 * p.inv_h2) * lap_raw(u + cells, x, y, z, p.nx, p.ny, p.nz) + dfdp);
   un[cells + i] = ph + dt * pt;
   un[i] = U + dt * ((D * p.inv_h2) * lap_raw(u, x, y, z, p.nx, p.ny, p.nz) + 0.5 * pt);
+}
+
+// =====================================================================================================================
+// Streaming ("2.5-D") forms of the three passes above for 3-D boxes whose x extent is a multiple of 128 (and y of the tile
+// height): the design of the BM1 stencil kernel (ch_fd_kernels.hip) applied to the multi-field models.  A workgroup of 4
+// waves owns a 128 x (4 RPT) column of cells and walks a z-chunk plane by plane:
+//   * a lane owns 2 x-adjacent cells (16-byte global loads / stores: full 128-byte lines per quarter wave) in RPT rows;
+//   * the z-neighbours of a cell are ITS OWN values in the planes before / after: three planes per stencilled field live
+//     in registers and rotate, so every input plane is read from HBM once per workgroup;
+//   * the x / y neighbours of plane z come from an LDS tile per stencilled field (own cells + a 1-cell halo: the halo
+//     rows are one extra 16-byte load for two of the waves, the halo columns 2 scalars per row for a third) -- a halo
+//     cell needs no z-pipeline of its own because every pass here is a single radius-1 stage (that is what keeps this
+//     kernel so much simpler than the fused two-stage BM1 kernel; the price is BM2's separate mu pass);
+//   * same arithmetic, same operation order as the one-thread-per-cell kernels above (bit-identical; they stay the path
+//     for 2-D problems and for extents that do not tile).
+// PASS 30: BM3 update (U, phi -> U, phi: 32 B/cell).  PASS 20: BM2 mu pass (c with stencil, 4 eta pointwise -> mu: 48 B).
+// PASS 21: BM2 update (mu and 4 eta with stencil, c pointwise -> 5 fields: 88 B).
+constexpr int SX = 128, SPITCH = 132;   // tile width; LDS row pitch (own cells at 2..129, halo at 1 and 130)
+
+template <int PASS>
+struct PassTraits;
+template <>
+struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 2; };   // stencilled fields, pointwise inputs, rows per thread
+template <>
+struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2; };
+template <>
+struct PassTraits<21> { static constexpr int NS = 5, NPW = 1, RPT = 1; };
+
+template <int PASS>
+__global__ __launch_bounds__(256) void mfd_stream_kernel(const MfdParams p, const double* __restrict__ u,
+                                                         const double* __restrict__ mu_in, double* __restrict__ out,
+                                                         double dt, int zchunk) {
+  using T = PassTraits<PASS>;
+  constexpr int NS = T::NS, NPW = T::NPW, RPT = T::RPT, TY = 4 * RPT;
+  __shared__ __attribute__((aligned(16))) double tile[NS][TY + 2][SPITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * SX, y0 = blockIdx.y * TY;
+  const int zb = blockIdx.z * zchunk, ze = zb + zchunk < p.nz ? zb + zchunk : p.nz;
+  const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
+  const int xo = x0 + 2 * lane;
+  // stencilled field s of this pass -> where it lives
+  auto sfield = [&](int s) -> const double* {
+    if (PASS == 30) return u + (int64_t)s * cells;            // U, phi
+    if (PASS == 20) return u;                                   // c
+    return s == 0 ? mu_in : u + (int64_t)s * cells;             // mu, eta1..eta4
+  };
+  auto pfield = [&](int k) -> const double* { return PASS == 20 ? u + (int64_t)(k + 1) * cells : u; };  // eta_k / c
+  double2 zm[NS][RPT], zc[NS][RPT], zp[NS][RPT];   // own cells in planes z-1, z, z+1
+  const int64_t own = (int64_t)(y0 + wave * RPT) * row + xo;
+#define MFD_LOAD_OWN(DST, Z)                                                                                     \
+  {                                                                                                              \
+    const int64_t zo_ = (int64_t)wrapm((Z), p.nz) * plane + own;                                                 \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) _Pragma("unroll") for (int r = 0; r < RPT; ++r)               \
+        DST[s][r] = *reinterpret_cast<const double2*>(sfield(s) + zo_ + (int64_t)r * row);                       \
+  }
+  MFD_LOAD_OWN(zm, zb - 1)
+  MFD_LOAD_OWN(zc, zb)
+  for (int z = zb; z < ze; ++z) {
+    MFD_LOAD_OWN(zp, z + 1)
+    // halo of plane z: rows y0 - 1 and y0 + TY (waves 0 and 1), columns x0 - 1 and x0 + 128 (wave 2), periodic wrap
+    // (every wave forms both addresses -- clamped to something valid -- and loads under a predicate: arrays that are
+    // written in one branch only end up in scratch memory)
+    const bool do_row = wave < 2, do_col = wave == 2 && lane < 2 * TY;
+    const int yh = wrapm(wave == 0 ? y0 - 1 : y0 + TY, p.ny);
+    const int yy = y0 + (do_col ? (lane >> 1) : 0), xh = wrapm((lane & 1) ? x0 + SX : x0 - 1, p.nx);
+    const int64_t arow = z * plane + (int64_t)yh * row + xo, acol = z * plane + (int64_t)yy * row + xh;
+    double2 hrow[NS];
+    double hcol[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      hrow[s] = do_row ? *reinterpret_cast<const double2*>(sfield(s) + arow) : make_double2(0.0, 0.0);
+      hcol[s] = do_col ? sfield(s)[acol] : 0.0;
+    }
+    double2 pw[NPW > 0 ? NPW : 1][RPT];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k)
+#pragma unroll
+      for (int r = 0; r < RPT; ++r)
+        pw[k][r] = *reinterpret_cast<const double2*>(pfield(k) + z * plane + (int64_t)(y0 + wave * RPT + r) * row + xo);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) *reinterpret_cast<double2*>(&tile[s][1 + wave * RPT + r][2 + 2 * lane]) = zc[s][r];
+      if (do_row) *reinterpret_cast<double2*>(&tile[s][wave == 0 ? 0 : TY + 1][2 + 2 * lane]) = hrow[s];
+      if (do_col) tile[s][1 + (lane >> 1)][(lane & 1) ? SX + 2 : 1] = hcol[s];
+    }
+    __syncthreads();
+    // raw 7-point Laplacians (times h^2) of the stencilled fields at the two own cells of each row
+    double2 lap[NS][RPT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int ty = 1 + wave * RPT + r, tx = 2 + 2 * lane;
+        const double xl = tile[s][ty][tx - 1], xr = tile[s][ty][tx + 2];
+        const double2 ym = *reinterpret_cast<const double2*>(&tile[s][ty - 1][tx]);
+        const double2 yp = *reinterpret_cast<const double2*>(&tile[s][ty + 1][tx]);
+        const double2 c = zc[s][r];
+        double2 l;
+        l.x = ((xl + c.y) + (ym.x + yp.x)) - 4.0 * c.x;
+        l.y = ((c.x + xr) + (ym.y + yp.y)) - 4.0 * c.y;
+        l.x = l.x + ((zm[s][r].x + zp[s][r].x) - 2.0 * c.x);
+        l.y = l.y + ((zm[s][r].y + zp[s][r].y) - 2.0 * c.y);
+        lap[s][r] = l;
+      }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int64_t o = z * plane + (int64_t)(y0 + wave * RPT + r) * row + xo;
+      if (PASS == 30) {
+        const double lam = p.q[0], it = p.q[1], W2 = p.q[2], D = p.q[3];
+        double2 nU, nP;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const double U = h2 ? zc[0][r].y : zc[0][r].x, ph = h2 ? zc[1][r].y : zc[1][r].x;
+          const double lU = h2 ? lap[0][r].y : lap[0][r].x, lP = h2 ? lap[1][r].y : lap[1][r].x;
+          const double P = 1.0 - ph * ph;
+          const double dfdp = (ph - (lam * U) * P) * P;
+          const double pt = it * ((W2 * p.inv_h2) * lP + dfdp);
+          const double np_ = ph + dt * pt, nu_ = U + dt * ((D * p.inv_h2) * lU + 0.5 * pt);
+          if (h2) {
+            nP.y = np_;
+            nU.y = nu_;
+          } else {
+            nP.x = np_;
+            nU.x = nu_;
+          }
+        }
+        *reinterpret_cast<double2*>(out + o) = nU;
+        *reinterpret_cast<double2*>(out + cells + o) = nP;
+      } else if (PASS == 20) {
+        const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3];
+        double2 m;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const double c = h2 ? zc[0][r].y : zc[0][r].x;
+          double h = 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) h = h + hs(h2 ? pw[k][r].y : pw[k][r].x);
+          const double fc = (2.0 * r2) * (c - ca) * (1.0 - h) + (2.0 * r2) * (c - cb) * h;
+          const double v = fc - (kc * p.inv_h2) * (h2 ? lap[0][r].y : lap[0][r].x);
+          if (h2)
+            m.y = v;
+          else
+            m.x = v;
+        }
+        *reinterpret_cast<double2*>(out + o) = m;
+      } else {
+        const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], Mob = p.q[4], ke = p.q[5], w = p.q[6], al = p.q[7], L = p.q[8];
+        double2 res[5];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const double c = h2 ? pw[0][r].y : pw[0][r].x;
+          const double nc = c + (dt * Mob * p.inv_h2) * (h2 ? lap[0][r].y : lap[0][r].x);
+          double e[4], e2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            e[k] = h2 ? zc[k + 1][r].y : zc[k + 1][r].x;
+            e2 = e2 + e[k] * e[k];
+          }
+          const double dfab = r2 * ((c - cb) * (c - cb)) - r2 * ((c - ca) * (c - ca));
+          if (h2)
+            res[0].y = nc;
+          else
+            res[0].x = nc;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double ek = e[k];
+            const double well = (2.0 * ek * ((1.0 - ek) * (1.0 - ek)) - 2.0 * (ek * ek) * (1.0 - ek)) + (2.0 * al) * ek * (e2 - ek * ek);
+            const double fe = dfab * hsp(ek) + w * well;
+            const double ne = ek - (dt * L) * (fe - (ke * p.inv_h2) * (h2 ? lap[k + 1][r].y : lap[k + 1][r].x));
+            if (h2)
+              res[k + 1].y = ne;
+            else
+              res[k + 1].x = ne;
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < 5; ++f) *reinterpret_cast<double2*>(out + (int64_t)f * cells + o) = res[f];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        zm[s][r] = zc[s][r];
+        zc[s][r] = zp[s][r];
+      }
+  }
+#undef MFD_LOAD_OWN
+}
+
+// =====================================================================================================================
+// BM2 in ONE pass: c and the four order parameters read once, written once -- 80 B per cell update, the algorithmic
+// minimum (the two streaming passes above move 136 B: mu goes through HBM).  c is a two-stage update (mu = f_c - kappa
+// lap c, then c += dt M lap mu), so mu of plane z is needed on the tile AND on a 1-cell ring around it; the ring cells get
+// no z-pipeline in registers -- instead the last three c planes stay in an LDS ring (own cells + a 2-cell halo), from which
+// any thread can form lap c at a ring cell, and mu lives in two LDS planes (z, z + 1).  The order parameters are single
+// radius-1 stages: own z-neighbours in registers, x / y neighbours from one LDS tile per field, as in mfd_stream_kernel.
+// Workgroup = 8 waves on a 128 x 8 tile (one row per wave, 2 x-adjacent cells per lane: 16-byte accesses), one workgroup
+// per CU (99 KB of LDS), walking its z-chunk with the inputs of plane z + 2 / z + 3 already in flight.  Per plane:
+//   P1  c(z+2) (own + halo, prefetched)            -> LDS ring                                            | barrier
+//   P2  mu(z+1) on tile + ring from the ring planes z, z+1, z+2 and h(eta(z+1))  -> LDS mu plane; prefetch c(z+3), eta(z+2) | barrier
+//   P3  c+(z) = c + dt M lap mu(z);  eta_k+(z) from the eta(z) tiles and the registers; 5 stores          | barrier
+//   P4  eta(z+1) (own + halo) -> LDS tiles; rotate registers
+// Halo work by role: waves 0-3 load one halo row of c each, wave 4 its 4 halo columns, waves 5 / 6 the eta halo rows (and
+// compute mu on the ring rows), wave 7 the eta halo columns (and mu on the ring columns).  Two warm-up iterations per
+// z-chunk fill the pipeline (outputs suppressed).  Same arithmetic and operation order as bm2_mu_kernel /
+// bm2_update_kernel: bit-identical results.
+constexpr int B2TY = 8, B2T = 512;
+struct Bm2Lds {
+  double cc[3][B2TY + 4][SPITCH];
+  double mu[2][B2TY + 2][SPITCH];
+  double et[4][B2TY + 2][SPITCH];
+};
+
+__global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const double* __restrict__ u,
+                                                       double* __restrict__ un, double dt, int zchunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Bm2Lds& S = *reinterpret_cast<Bm2Lds*>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); give every XCD a
+  // contiguous run of tiles (x fastest, then y, then z-chunk) so that the halo rows a tile reads are the own rows of a
+  // tile on the SAME L2 -- with the plain blockIdx order y-neighbours sit 4 apart, i.e. on different XCDs, and every halo
+  // row comes from HBM a second time (measured: 1.3x the algorithmic traffic)
+  const int ntx = p.nx / SX, nty = p.ny / B2TY;
+  const int nb = gridDim.x, per = (nb + 7) / 8, full = nb % 8;
+  const int xq = blockIdx.x % 8, rq = blockIdx.x / 8;
+  const int tile = full == 0 ? xq * per + rq : ((xq < full ? xq * per : full * per + (xq - full) * (per - 1)) + rq);
+  const int bx = tile % ntx, by = (tile / ntx) % nty, bz = tile / (ntx * nty);
+  const int x0 = bx * SX, y0 = by * B2TY;
+  const int zb = bz * zchunk, ze = zb + zchunk < p.nz ? zb + zchunk : p.nz;
+  const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
+  const int xo = x0 + 2 * lane, tx = 2 + 2 * lane;
+  const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3], Mob = p.q[4], ke = p.q[5], w = p.q[6], al = p.q[7], L = p.q[8];
+  auto zw = [&](int z) { return ((z % p.nz) + p.nz) % p.nz; };
+  // ---- roles (every wave forms every address, clamped to something valid, and loads under a predicate) ----
+  const bool c_row = wave < 4, c_col = wave == 4 && lane < 4 * (B2TY + 2), e_row = wave == 5 || wave == 6,
+             e_col = wave == 7 && lane < 2 * B2TY;
+  // c halo row of this wave: y0-2, y0-1, y0+TY, y0+TY+1 -> ring rows 0, 1, TY+2, TY+3
+  const int chr = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? B2TY + 2 : B2TY + 3));
+  const int64_t a_crow = (int64_t)wrapm(y0 - 2 + chr, p.ny) * row + xo;
+  // c halo columns: lane -> (ring row 1 .. TY+2, one of x0-2, x0-1, x0+128, x0+129)
+  const int ccr = 1 + (c_col ? lane >> 2 : 0), cck = lane & 3;
+  const int ccx = cck == 0 ? 0 : (cck == 1 ? 1 : (cck == 2 ? SX + 2 : SX + 3));   // column index in the ring row
+  const int64_t a_ccol = (int64_t)wrapm(y0 - 2 + ccr, p.ny) * row + wrapm(x0 - 2 + ccx, p.nx);
+  // eta halo row (wave 5: y0-1 -> tile row 0; wave 6: y0+TY -> tile row TY+1) and columns (wave 7)
+  const int ehr = wave == 5 ? 0 : B2TY + 1;
+  const int64_t a_erow = (int64_t)wrapm(y0 - 1 + ehr, p.ny) * row + xo;
+  const int ecr = 1 + (e_col ? lane >> 1 : 0), ecx = (lane & 1) ? SX + 2 : 1;
+  const int64_t a_ecol = (int64_t)wrapm(y0 - 1 + ecr, p.ny) * row + wrapm(x0 - 2 + ecx, p.nx);
+  const int64_t a_own = (int64_t)(y0 + wave) * row + xo;
+  const int oy = wave + 2;  // own row in the c ring; own row in the mu / eta tiles is wave + 1
+
+  double2 e[4][3], pe[4], eh[4], peh[4];   // eta own: planes z-1, z, z+1; prefetched z+2; halo of z+1 / z+2 (.x only for columns)
+  double2 mu3[3], pc, pch;                 // mu own z-1, z, z+1; c own + halo of the plane about to enter the ring
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) e[k][j] = make_double2(0.0, 0.0);
+  mu3[0] = mu3[1] = mu3[2] = make_double2(0.0, 0.0);
+
+#define B2_LOAD_C(Z)                                                                                            \
+  {                                                                                                             \
+    const double* cz_ = u + (int64_t)zw(Z) * plane;                                                             \
+    pc = *reinterpret_cast<const double2*>(cz_ + a_own);                                                        \
+    pch = c_row ? *reinterpret_cast<const double2*>(cz_ + a_crow) : make_double2(c_col ? cz_[a_ccol] : 0.0, 0.0); \
+  }
+#define B2_STORE_C(Z)                                                                                           \
+  {                                                                                                             \
+    const int sl_ = ((Z) + 3) % 3;                                                                              \
+    *reinterpret_cast<double2*>(&S.cc[sl_][oy][tx]) = pc;                                                       \
+    if (c_row) *reinterpret_cast<double2*>(&S.cc[sl_][chr][tx]) = pch;                                          \
+    if (c_col) S.cc[sl_][ccr][ccx] = pch.x;                                                                     \
+  }
+#define B2_LOAD_E(DST, DSTH, Z)                                                                                 \
+  {                                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                             \
+      const double* ez_ = u + (int64_t)(k + 1) * cells + (int64_t)zw(Z) * plane;                                \
+      DST[k] = *reinterpret_cast<const double2*>(ez_ + a_own);                                                  \
+      DSTH[k] = e_row ? *reinterpret_cast<const double2*>(ez_ + a_erow) : make_double2(e_col ? ez_[a_ecol] : 0.0, 0.0); \
+    }                                                                                                           \
+  }
+  // mu at one cell from the ring (planes P-1, P, P+1 in slots sm, sc, sp), the cell's neighbours and h = sum hs(eta_k(P))
+  auto mu_cell = [&](double c, double xl, double xr, double ym, double yp, double zm, double zp, double h) {
+    double l = ((xl + xr) + (ym + yp)) - 4.0 * c;
+    l = l + ((zm + zp) - 2.0 * c);
+    const double fc = (2.0 * r2) * (c - ca) * (1.0 - h) + (2.0 * r2) * (c - cb) * h;
+    return fc - (kc * p.inv_h2) * l;
+  };
+  auto mu_pair = [&](int sm, int sc, int sp, int ry, const double2 (&en)[4]) {
+    const double2 c = *reinterpret_cast<const double2*>(&S.cc[sc][ry][tx]);
+    const double xl = S.cc[sc][ry][tx - 1], xr = S.cc[sc][ry][tx + 2];
+    const double2 ym = *reinterpret_cast<const double2*>(&S.cc[sc][ry - 1][tx]);
+    const double2 yp = *reinterpret_cast<const double2*>(&S.cc[sc][ry + 1][tx]);
+    const double2 zm = *reinterpret_cast<const double2*>(&S.cc[sm][ry][tx]);
+    const double2 zp = *reinterpret_cast<const double2*>(&S.cc[sp][ry][tx]);
+    double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h0 = h0 + hs(en[k].x);
+      h1 = h1 + hs(en[k].y);
+    }
+    return make_double2(mu_cell(c.x, xl, c.y, ym.x, yp.x, zm.x, zp.x, h0), mu_cell(c.y, c.x, xr, ym.y, yp.y, zm.y, zp.y, h1));
+  };
+
+  // prologue: ring planes zb-2, zb-1; prefetch registers = c(zb), eta(zb-1)
+  B2_LOAD_C(zb - 2)
+  B2_STORE_C(zb - 2)
+  B2_LOAD_C(zb - 1)
+  B2_STORE_C(zb - 1)
+  B2_LOAD_C(zb)
+  {
+    double2 t0[4], t1[4];
+    B2_LOAD_E(t0, t1, zb - 1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k][2] = t0[k];
+      eh[k] = t1[k];
+    }
+  }
+  for (int z = zb - 2; z < ze; ++z) {
+    // ---- P1 ----
+    B2_STORE_C(z + 2)
+    __syncthreads();
+    // ---- P2: mu(z+1) ----
+    {
+      const int sm = (z + 3) % 3, sc = (z + 4) % 3, sp = (z + 5) % 3, ms = (z + 3) & 1;   // planes z, z+1, z+2; mu slot of z+1
+      double2 en[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) en[k] = e[k][2];
+      const double2 m = mu_pair(sm, sc, sp, oy, en);
+      mu3[2] = m;
+      *reinterpret_cast<double2*>(&S.mu[ms][wave + 1][tx]) = m;
+      if (e_row) {  // ring rows: eta halo values of this wave give h there
+        const int ry = ehr + 1;  // ring row 1 (y0-1) or TY+2 (y0+TY)
+        *reinterpret_cast<double2*>(&S.mu[ms][ehr][tx]) = mu_pair(sm, sc, sp, ry, eh);
+      }
+      if (e_col) {  // ring columns: one cell per lane
+        const int ry = ecr + 1, cx = ecx;
+        double h = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h = h + hs(eh[k].x);
+        S.mu[ms][ecr][cx] = mu_cell(S.cc[sc][ry][cx], S.cc[sc][ry][cx - 1], S.cc[sc][ry][cx + 1], S.cc[sc][ry - 1][cx],
+                                    S.cc[sc][ry + 1][cx], S.cc[sm][ry][cx], S.cc[sp][ry][cx], h);
+      }
+    }
+    B2_LOAD_C(z + 3)
+    B2_LOAD_E(pe, peh, z + 2)
+    __syncthreads();
+    // ---- P3: outputs of plane z ----
+    if (z >= zb) {
+      const int sc = (z + 3) % 3, ms = (z + 2) & 1, ty = wave + 1;
+      const double2 c = *reinterpret_cast<const double2*>(&S.cc[sc][oy][tx]);
+      const int64_t o = (int64_t)z * plane + a_own;
+      {
+        const double xl = S.mu[ms][ty][tx - 1], xr = S.mu[ms][ty][tx + 2];
+        const double2 ym = *reinterpret_cast<const double2*>(&S.mu[ms][ty - 1][tx]);
+        const double2 yp = *reinterpret_cast<const double2*>(&S.mu[ms][ty + 1][tx]);
+        const double2 m = mu3[1];
+        double lx = ((xl + m.y) + (ym.x + yp.x)) - 4.0 * m.x, ly = ((m.x + xr) + (ym.y + yp.y)) - 4.0 * m.y;
+        lx = lx + ((mu3[0].x + mu3[2].x) - 2.0 * m.x);
+        ly = ly + ((mu3[0].y + mu3[2].y) - 2.0 * m.y);
+        *reinterpret_cast<double2*>(un + o) = make_double2(c.x + (dt * Mob * p.inv_h2) * lx, c.y + (dt * Mob * p.inv_h2) * ly);
+      }
+      double2 res[4];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const double cv = h2 ? c.y : c.x;
+        double ev[4], e2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ev[k] = h2 ? e[k][1].y : e[k][1].x;
+          e2 = e2 + ev[k] * ev[k];
+        }
+        const double dfab = r2 * ((cv - cb) * (cv - cb)) - r2 * ((cv - ca) * (cv - ca));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double ek = ev[k];
+          const double xl = h2 ? e[k][1].x : S.et[k][ty][tx - 1], xr = h2 ? S.et[k][ty][tx + 2] : e[k][1].y;
+          const double ym = S.et[k][ty - 1][tx + h2], yp = S.et[k][ty + 1][tx + h2];
+          double l = ((xl + xr) + (ym + yp)) - 4.0 * ek;
+          l = l + (((h2 ? e[k][0].y : e[k][0].x) + (h2 ? e[k][2].y : e[k][2].x)) - 2.0 * ek);
+          const double well = (2.0 * ek * ((1.0 - ek) * (1.0 - ek)) - 2.0 * (ek * ek) * (1.0 - ek)) + (2.0 * al) * ek * (e2 - ek * ek);
+          const double fe = dfab * hsp(ek) + w * well;
+          const double ne = ek - (dt * L) * (fe - (ke * p.inv_h2) * l);
+          if (h2)
+            res[k].y = ne;
+          else
+            res[k].x = ne;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<double2*>(un + (int64_t)(k + 1) * cells + o) = res[k];
+    }
+    __syncthreads();
+    // ---- P4: eta(z+1) -> tiles; rotate ----
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      *reinterpret_cast<double2*>(&S.et[k][wave + 1][tx]) = e[k][2];
+      if (e_row) *reinterpret_cast<double2*>(&S.et[k][ehr][tx]) = eh[k];
+      if (e_col) S.et[k][ecr][ecx] = eh[k].x;
+      e[k][0] = e[k][1];
+      e[k][1] = e[k][2];
+      e[k][2] = pe[k];
+      eh[k] = peh[k];
+    }
+    mu3[0] = mu3[1];
+    mu3[1] = mu3[2];
+  }
+#undef B2_LOAD_C
+#undef B2_STORE_C
+#undef B2_LOAD_E
 }
 
 // diagnostics, raw sums per block: {sum second (BM2: c, BM3: (phi+1)/2), sum f_chem, sum of weighted squared forward
@@ -293,6 +707,9 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, c
     MF_HIP(hipMemsetAsync(mf->u[0], 0, bytes, stream));
     MF_HIP(hipMemsetAsync(mf->u[1], 0, bytes, stream));
     if (model == 2) MF_HIP(hipMalloc(&mf->mu, sizeof(double) * (size_t)mf->cells));
+    if (model == 2)
+      MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm2_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(Bm2Lds)));
     MF_HIP(hipMalloc(&mf->partials, sizeof(double) * 5 * 1024));
     MF_HIP(hipMalloc(&mf->out5, sizeof(double) * 8));
     MF_HIP(hipHostMalloc(&mf->out5_host, sizeof(double) * 8, hipHostMallocDefault));
@@ -325,13 +742,54 @@ int multifd_set_ic(MultiFD* mf, int mnx, int mny, const double* a) {
 double* multifd_field_ptr(MultiFD* mf, int f) { return mf->u[mf->cur] + (int64_t)f * mf->cells; }
 void multifd_touch(MultiFD* mf) { mf->have_prev = false; }
 
+namespace {
+int g_mfd_stream = 1;  // PFHIP_MFD_STREAM=0: one-thread-per-cell kernels everywhere (A/B)
+int g_bm2_fused = 1;   // PFHIP_BM2_FUSED=0: BM2 by the two streaming passes (mu through HBM) instead of the one-pass kernel
+// z-chunks so that the grid holds about 4 workgroups per CU
+template <int PASS>
+void launch_stream(const MultiFD* mf, const double* u, const double* mu, double* out, double dt) {
+  const MfdParams& p = mf->p;
+  constexpr int TY = 4 * PassTraits<PASS>::RPT;
+  const int tiles = (p.nx / SX) * (p.ny / TY);
+  int nchunk = (4 * 256 + tiles - 1) / tiles;
+  if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
+  const int zchunk = (p.nz + nchunk - 1) / nchunk;
+  nchunk = (p.nz + zchunk - 1) / zchunk;
+  hipLaunchKernelGGL(mfd_stream_kernel<PASS>, dim3(p.nx / SX, p.ny / TY, nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt,
+                     zchunk);
+}
+}  // namespace
+
+// which kernels multifd_step uses on this box: 1 = the streaming LDS-tiled forms, 0 = one thread per cell
+int multifd_streaming(const MultiFD* mf) {
+  const MfdParams& p = mf->p;
+  return g_mfd_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 8 == 0;
+}
+
 int multifd_step(MultiFD* mf, double dt, int nsteps) {
   const MfdParams& p = mf->p;
   const unsigned nb = (unsigned)((mf->cells + 255) / 256);
+  if (const char* e = getenv("PFHIP_MFD_STREAM")) g_mfd_stream = e[0] != '0';
+  if (const char* e = getenv("PFHIP_BM2_FUSED")) g_bm2_fused = e[0] != '0';
+  const bool stream = multifd_streaming(mf) != 0;
   for (int s = 0; s < nsteps; ++s) {
     const double* u = mf->u[mf->cur];
     double* un = mf->u[1 - mf->cur];
-    if (p.model == 2) {
+    if (stream) {
+      if (p.model == 2 && g_bm2_fused) {
+        const int tiles = (p.nx / SX) * (p.ny / B2TY);
+        int nchunk = (256 + tiles - 1) / tiles;   // one workgroup per CU
+        if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
+        const int zchunk = (p.nz + nchunk - 1) / nchunk;
+        nchunk = (p.nz + zchunk - 1) / zchunk;
+        hipLaunchKernelGGL(bm2_fused_kernel, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
+      } else if (p.model == 2) {
+        launch_stream<20>(mf, u, nullptr, mf->mu, dt);
+        launch_stream<21>(mf, u, mf->mu, un, dt);
+      } else {
+        launch_stream<30>(mf, u, nullptr, un, dt);
+      }
+    } else if (p.model == 2) {
       hipLaunchKernelGGL(bm2_mu_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, mf->mu);
       hipLaunchKernelGGL(bm2_update_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, (const double*)mf->mu, un, dt);
     } else {

@@ -5,6 +5,8 @@
 #include <utility>
 #include <vector>
 
+#include <roctracer/roctx.h>
+
 #include "pfhip_internal.h"
 
 using namespace pfhip;
@@ -127,6 +129,8 @@ struct pf_handle {
   bool own_stream = false;
   bool step_open = false;
   double open_dt = 0.0;
+  hipStream_t strip_stream = nullptr;  // pf_set_strip_stream: where pf_step_finish launches the boundary strips
+  bool have_strip_stream = false;
   bool wide = false;       // PF_FLAG_WIDE_HALO: 4 ghost planes; the kernels see them as (2 ghost + 2 extra owned) planes
   int wide_phase = 0;      // 0: next step is A (ghosts must be fresh), 1: next step is B (no exchange)
   bool timing = false;
@@ -389,6 +393,16 @@ void scale_diag(const pf_handle* h, const double raw[6], double out[3]) {
 
 }  // namespace
 
+// roctx ranges around the calls a time loop makes (the reference's only timing hook is the wall clock around
+// its loop, dolfin/bench1.py:143,200-203): they show up as named intervals in rocprofv3 --marker-trace / --sys-trace next to
+// the kernels, and cost two no-op calls when no tracer is attached.
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+  ~RoctxRange() { roctxRangePop(); }
+  RoctxRange(const RoctxRange&) = delete;
+  RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 extern "C" {
 
 int pf_version(void) { return PFHIP_VERSION; }
@@ -593,6 +607,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     }
     if (frc != 0) return bail(PF_ERR_HIP);
     fembe_set_max_newton(h->fb, cfg->max_newton);
+    if (cfg->flags & PF_FLAG_FEM_ALWAYS_PIVOT) fembe_set_pivot_always(h->fb);
   } else if (multi) {
     double mp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (cfg->model == PF_MODEL_BM2) {
@@ -643,7 +658,8 @@ const char* pf_status_string(const pf_handle* h) {
   pf_handle* m = const_cast<pf_handle*>(h);
   const pf_config& c = h->cfg;
   if (h->mf) {
-    m->status = "fd: explicit multi-field scheme (BM2 / BM3), one thread per cell";
+    m->status = multifd_streaming(h->mf) ? "fd: explicit multi-field scheme (BM2 / BM3), streaming LDS-tiled kernels"
+                                         : "fd: explicit multi-field scheme (BM2 / BM3), one thread per cell";
   } else if (h->fb) {
     m->status = "fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction";
   } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
@@ -811,6 +827,7 @@ int pf_set_ic_bm1(pf_handle* h, double c0, double eps) { return set_ic(h, c0, ep
 int pf_set_ic_bm6(pf_handle* h, double c0, double c1) { return set_ic(h, c0, c1, 0.2); }
 
 int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
+  RoctxRange roctx_("pf_set_field");
   if (!h || !host) return PF_ERR_INVALID;
   if (h->mf) {
     const int f = mfd_field_index(h, field);
@@ -862,6 +879,7 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
 }
 
 int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
+  RoctxRange roctx_("pf_get_field");
   if (!h || !host) return PF_ERR_INVALID;
   if (h->mf) {
     const int f = mfd_field_index(h, field);
@@ -911,6 +929,7 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
 }
 
 int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
+  RoctxRange roctx_("pf_step");
   if (!h) return PF_ERR_INVALID;
   if (nsteps < 0 || !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step: need dt > 0 and nsteps >= 0");
   if (h->g.ghost != 0) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
@@ -1034,6 +1053,7 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out) {
 }
 
 int pf_step_begin(pf_handle* h, double dt) {
+  RoctxRange roctx_("pf_step_begin (interior)");
   if (!h) return PF_ERR_INVALID;
   if (!(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step_begin: need dt > 0");
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_begin: not in slab mode");
@@ -1056,11 +1076,36 @@ int pf_step_begin(pf_handle* h, double dt) {
   return PF_OK;
 }
 
+int pf_set_strip_stream(pf_handle* h, void* stream) {
+  if (!h) return PF_ERR_INVALID;
+  if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_set_strip_stream: not in slab mode");
+  h->strip_stream = reinterpret_cast<hipStream_t>(stream);
+  h->have_strip_stream = stream != nullptr;
+  return PF_OK;
+}
+
 int pf_step_finish(pf_handle* h) {
+  RoctxRange roctx_("pf_step_finish (boundary strips)");
   if (!h) return PF_ERR_INVALID;
   if (!h->step_open) return fail(h, PF_ERR_STATE, "pf_step_finish without pf_step_begin");
   const int g = h->g.ghost, nz = h->g.nz;
   int rc;
+  // the strips go to the strip stream when one is set (pf_set_strip_stream); everything else stays on the handle's stream
+  struct StreamSwap {
+    pf_handle* h;
+    hipStream_t saved;
+    bool timing;
+    explicit StreamSwap(pf_handle* hh) : h(hh), saved(hh->stream), timing(hh->timing) {
+      if (h->have_strip_stream) {
+        h->stream = h->strip_stream;
+        h->timing = false;  // the per-launch events belong to the handle's stream
+      }
+    }
+    ~StreamSwap() {
+      h->stream = saved;
+      h->timing = timing;
+    }
+  } swap_guard(h);
   if (h->wide) {
     if (h->wide_phase == 0) {  // step A: real planes [-2, 2) and [nz-2, nz+2) = virtual [0, 4) and [nz, nz+4)
       rc = nz > 4 ? launch_step(h, h->open_dt, 0, 4, 1, nz, nz + 4) : launch_step(h, h->open_dt, 0, nz + 4);
@@ -1128,6 +1173,7 @@ int pf_dist_begin(pf_handle* h, int op, double dt) {
 }
 
 int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
+  RoctxRange roctx_("pf_dist_advance");
   if (!h || !req) return PF_ERR_INVALID;
   if (!h->d_op) return fail(h, PF_ERR_STATE, "pf_dist_advance without pf_dist_begin");
   std::memset(req, 0, sizeof(*req));
@@ -1252,6 +1298,7 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
 }
 
 int pf_diagnostics_local(pf_handle* h, double out[3]) {
+  RoctxRange roctx_("pf_diagnostics_local");
   if (!h || !out) return PF_ERR_INVALID;
   if (h->step_open) return fail(h, PF_ERR_STATE, "a slab step is open");
   if (h->mf) {
@@ -1285,10 +1332,20 @@ int pf_diagnostics_local(pf_handle* h, double out[3]) {
 }
 
 int pf_diagnostics(pf_handle* h, double out[3]) {
+  RoctxRange roctx_("pf_diagnostics");
   if (!h || !out) return PF_ERR_INVALID;
   if (h->g.ghost != 0)
     return fail(h, PF_ERR_STATE, "pf_diagnostics: slab mode uses pf_diagnostics_local + a sum over ranks");
   return pf_diagnostics_local(h, out);
+}
+
+int pf_get_stat(pf_handle* h, int key, int64_t* value) {
+  if (!h || !value) return PF_ERR_INVALID;
+  if (!h->fb) return fail(h, PF_ERR_UNSUPPORTED, "pf_get_stat: PF_SCHEME_FEM_BE handles only");
+  const long long v = fembe_stat(h->fb, key);
+  if (v < 0) return fail(h, PF_ERR_INVALID, "pf_get_stat: unknown key");
+  *value = v;
+  return PF_OK;
 }
 
 int pf_timing_enable(pf_handle* h, int on) {
@@ -1484,6 +1541,18 @@ int pfk_grid_barrier_probe(int nblocks, int nthreads, int iters, double* us_per_
   if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_grid_barrier_probe: ") + hipGetErrorString(e));
   if (!ok) return fail(nullptr, PF_ERR_STATE, "pfk_grid_barrier_probe: the bounded spin tripped (workgroups not co-resident?)");
   *us_per_barrier = ms * 1e3;
+  return PF_OK;
+}
+
+int pfk_xcd_barrier_probe(int nblocks, int nthreads, int iters, int handoff, double* us_per_round, int* participants,
+                          int* stale) {
+  if (nblocks < 8 || nblocks > 2048 || nthreads < 64 || nthreads > 256 || iters < 1 || iters > 1000000 || !us_per_round ||
+      !participants || !stale)
+    return fail(nullptr, PF_ERR_INVALID, "pfk_xcd_barrier_probe: bad arguments");
+  int ok = 0;
+  hipError_t e = run_xcd_barrier_probe(nblocks, nthreads, iters, handoff, us_per_round, participants, stale, &ok);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pfk_xcd_barrier_probe: ") + hipGetErrorString(e));
+  if (!ok) return fail(nullptr, PF_ERR_STATE, "pfk_xcd_barrier_probe: a bounded spin tripped (workgroups not co-resident?)");
   return PF_OK;
 }
 

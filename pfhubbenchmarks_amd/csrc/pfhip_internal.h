@@ -59,6 +59,8 @@ hipError_t launch_signal_flag(long long* flag, long long seq, hipStream_t stream
 hipError_t launch_wait_flag(const long long* flag, long long seq, int* timeout, hipStream_t stream);
 hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* ms_per_barrier, int* ok);
 hipError_t launch_clock_probe(double* out, int nblocks, int spin_us, int busy, hipStream_t stream);
+hipError_t run_xcd_barrier_probe(int nblocks, int nthreads, int iters, int handoff, double* us_per_round, int* participants,
+                                 int* stale, int* ok);
 hipError_t launch_stream_copy(const double* src, double* dst, int64_t n, hipStream_t stream);
 hipError_t launch_reflect_ghosts(double* buf, int64_t plane, int nz, int ghost, int ends, hipStream_t stream);
 
@@ -81,11 +83,29 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
 
+// rocFFT through its native API (fftplan.hip): the library fallback for sizes the hand-written passes do not cover
+struct FftPlan;
+int fftplan_real(FftPlan** out, int dim, const int* n, int batch, bool forward, hipStream_t stream, std::string* err);
+int fftplan_c2c_strided(FftPlan** out, int n, int64_t stride, int64_t dist, int batch, hipStream_t stream, bool forward,
+                        std::string* err);
+int fftplan_exec(FftPlan* p, void* in, void* out_buf, std::string* err);   // out_buf = nullptr: in place
+void fftplan_destroy(FftPlan* p);
+
 // fused LDS-FFT spectral step for 2-D power-of-two grids (spectral2d_fused.hip); same spectrum layout as rocFFT D2Z
 struct Fused2D;
 bool fused2d_supported(int dim, int nx, int ny, int nz);
+struct SpecLayout {  // where row (z, y) of a half-spectrum array of the hand-written passes lives (spectral2d_fused.hip spec_row)
+  int pitch, zb, nyp, bp;
+  int64_t rows;      // rows to allocate (pitch complex elements each)
+};
+SpecLayout fused_spectrum_layout(int dim, int nx, int ny, int nz);
 int fused_spectrum_pitch(int dim, int nx, int ny, int nz);  // complex elements per k_x row of the arrays handed to fused2d_* / fused3d_poisson  // 2-D power-of-two grids, or the 512^3 cube
-int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream);
+int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream, int want_mx = 0);  // want_mx: also the
+                                                     // tables of the mixed-radix kernels (fused_poisson_dirichlet)
+bool fused_dirichlet_supported(int dim, int nx, int ny, int nz);
+int64_t fused_dirichlet_work_doubles(int npx, int npy, int npz);
+int fused_poisson_dirichlet(Fused2D* f, const double* c, double* phi, double* S, int npx, int npy, int npz, double h,
+                            double k_over_eps);
 void fused2d_destroy(Fused2D* f);
 void fused2d_invalidate(Fused2D* f);
 // slab-decomposed transforms: local x / y passes with the all-to-all layout written / read directly, z pass on the
@@ -146,6 +166,8 @@ int fembe_set_c(FemBE* fb, const double* host);
 int fembe_get(FemBE* fb, int field, double* host);
 int fembe_step(FemBE* fb, double dt, int* converged, int* iters);
 int fembe_rollback(FemBE* fb);
+void fembe_set_pivot_always(FemBE* fb);      // PF_FLAG_FEM_ALWAYS_PIVOT
+long long fembe_stat(const FemBE* fb, int key);
 void fembe_set_max_newton(FemBE* fb, int n);  // n <= 0: keep the default (10, bench1.py:88)
 int fembe_diagnostics(FemBE* fb, double out[3]);
 const char* fembe_error(const FemBE* fb);
@@ -160,6 +182,7 @@ int multifd_set_ic(MultiFD* mf, int mnx, int mny, const double* a);
 double* multifd_field_ptr(MultiFD* mf, int f);  // device pointer of field f of the current time level (lattice, no ghosts)
 void multifd_touch(MultiFD* mf);                // a field was overwritten: no rollback state
 int multifd_step(MultiFD* mf, double dt, int nsteps);
+int multifd_streaming(const MultiFD* mf);  // 1: the box tiles and multifd_step uses the streaming LDS-tiled kernels
 int multifd_rollback(MultiFD* mf);
 int multifd_diag_raw(MultiFD* mf, double raw[5]);
 const char* multifd_error(const MultiFD* mf);

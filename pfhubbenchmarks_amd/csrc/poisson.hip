@@ -1,5 +1,6 @@
 // Poisson solve of PFHub BM6:  lap(phi) = -k c / eps      (dolfin/pfbase.py:410-421 poisson_weak_form, called at
-// dolfin/bench6.py:72 with f = -k*c/epsilon, M = 1).  Fast direct solver on rocFFT: the 5/7-point Laplacian is
+// dolfin/bench6.py:72 with f = -k*c/epsilon, M = 1).  Fast direct solver (hand-written passes, or rocFFT through its native
+// API, fftplan.hip, for sizes they do not cover): the 5/7-point Laplacian is
 // diagonal in the discrete Fourier basis of the periodic lattice the solver runs on.
 //
 // Two boundary modes:
@@ -11,8 +12,6 @@
 //             diagonalised by a sine transform in x and a cosine transform in y = the FFT of the ODD-in-x, EVEN-in-y
 //             extension on the same lattice.  The result is handed to the Cahn-Hilliard kernel as the EVEN-in-x
 //             extension of phi (mu must stay mirror symmetric), with the Dirichlet values written on x = 0, Lx.
-#include <hipfft/hipfft.h>
-
 #include "pfhip_internal.h"
 
 namespace pfhip {
@@ -97,11 +96,12 @@ int grid_for_p(int64_t n) {
 struct Poisson {
   PoArgs a;
   int64_t n, nh;
-  hipfftHandle fwd = 0, inv = 0;
-  bool have_plans = false;
+  FftPlan *fwd = nullptr, *inv = nullptr;  // library transforms (null on the hand-written path)
   double* rhs = nullptr;
   double2* ph = nullptr;
-  Fused2D* fast = nullptr;  // 512^3 periodic box: hand-written LDS-FFT passes (spectral2d_fused.hip) instead of rocFFT
+  Fused2D* fast = nullptr;  // hand-written LDS-FFT passes (spectral2d_fused.hip) instead of library transforms
+  bool dirichlet_fast = false;  // reference BCs by the sine / cosine passes on the physical nodes (fused_poisson_dirichlet)
+  double* S = nullptr;          // their work array
   std::string err;
 };
 
@@ -115,11 +115,7 @@ struct Poisson {
   } while (0)
 #define PO_FFT(expr)                                                       \
   do {                                                                     \
-    hipfftResult r_ = (expr);                                              \
-    if (r_ != HIPFFT_SUCCESS) {                                            \
-      po->err = std::string(#expr) + ": hipfft error " + std::to_string((int)r_); \
-      return -3;                                                           \
-    }                                                                      \
+    if ((expr) != 0) return -3; /* po->err was filled by the fftplan_* call */ \
   } while (0)
 
 const char* poisson_error(const Poisson* po) { return po->err.c_str(); }
@@ -143,27 +139,25 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
   po->nh = (int64_t)a.nxh * ny * a.nz;
   a.inv_n = 1.0 / (double)po->n;
   auto body = [&]() -> int {
-    const bool fast = npx == 0 && dim == 3 && fused2d_supported(3, nx, ny, a.nz);
-    if (fast) {  // the hand-written passes need no library plans
-    } else if (dim == 2) {
-      PO_FFT(hipfftPlan2d(&po->fwd, ny, nx, HIPFFT_D2Z));
-      PO_FFT(hipfftPlan2d(&po->inv, ny, nx, HIPFFT_Z2D));
-    } else {
-      PO_FFT(hipfftPlan3d(&po->fwd, a.nz, ny, nx, HIPFFT_D2Z));
-      PO_FFT(hipfftPlan3d(&po->inv, a.nz, ny, nx, HIPFFT_Z2D));
+    const bool fast_dir = npx > 0 && fused_dirichlet_supported(dim, nx, ny, a.nz);  // reference BCs: sine / cosine passes
+    const bool fast = fast_dir || (npx == 0 && fused2d_supported(dim, nx, ny, a.nz));  // periodic boxes: hand-written passes
+    po->dirichlet_fast = fast_dir;
+    if (!fast) {  // the hand-written passes need no library plans
+      const int nn[3] = {nx, ny, a.nz};
+      PO_FFT(fftplan_real(&po->fwd, dim, nn, 1, true, stream, &po->err));
+      PO_FFT(fftplan_real(&po->inv, dim, nn, 1, false, stream, &po->err));
     }
-    if (!fast) {
-      po->have_plans = true;
-      PO_FFT(hipfftSetStream(po->fwd, stream));
-      PO_FFT(hipfftSetStream(po->inv, stream));
-    }
-    {  // the hand-written passes use a padded row pitch (fused_spectrum_pitch); the rocFFT path the natural one
-      const int64_t nh_alloc = fast ? (int64_t)fused_spectrum_pitch(3, nx, ny, a.nz) * ny * a.nz : po->nh;
+    if (fast_dir) {
+      PO_HIP(hipMalloc(&po->S, sizeof(double) * fused_dirichlet_work_doubles(npx, a.npy, dim == 3 ? nz / 2 + 1 : 1)));
+      PO_HIP(hipMemsetAsync(po->S, 0, sizeof(double) * fused_dirichlet_work_doubles(npx, a.npy, dim == 3 ? nz / 2 + 1 : 1), stream));
+    } else {  // the hand-written passes use a padded row pitch (fused_spectrum_pitch); the rocFFT path the natural one
+      const SpecLayout lay = fused_spectrum_layout(dim, nx, ny, a.nz);
+      const int64_t nh_alloc = fast ? (int64_t)lay.pitch * lay.rows : po->nh;
       PO_HIP(hipMalloc(&po->ph, sizeof(double2) * nh_alloc));
       if (nh_alloc != po->nh) PO_HIP(hipMemsetAsync(po->ph, 0, sizeof(double2) * nh_alloc, stream));
     }
-    if (npx > 0) PO_HIP(hipMalloc(&po->rhs, sizeof(double) * po->n));
-    if (fast && fused2d_create(&po->fast, nx, ny, a.nz, h, stream) != 0) {
+    if (npx > 0 && !fast_dir) PO_HIP(hipMalloc(&po->rhs, sizeof(double) * po->n));
+    if (fast && fused2d_create(&po->fast, nx, ny, a.nz, h, stream, fast_dir ? 1 : 0) != 0) {
       po->err = "fused2d_create failed";
       return -3;
     }
@@ -176,11 +170,10 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
 
 void poisson_destroy(Poisson* po) {
   if (!po) return;
-  if (po->have_plans) {
-    (void)hipfftDestroy(po->fwd);
-    (void)hipfftDestroy(po->inv);
-  }
+  fftplan_destroy(po->fwd);
+  fftplan_destroy(po->inv);
   if (po->rhs) (void)hipFree(po->rhs);
+  if (po->S) (void)hipFree(po->S);
   if (po->ph) (void)hipFree(po->ph);
   if (po->fast) fused2d_destroy(po->fast);
   delete po;
@@ -189,11 +182,16 @@ void poisson_destroy(Poisson* po) {
 // phi <- solution for the given c (both on the lattice, no ghost planes)
 int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream) {
   const PoArgs& a = po->a;
-  if (a.npx > 0) {
+  if (po->dirichlet_fast) {
+    if (fused_poisson_dirichlet(po->fast, c, phi, po->S, a.npx, a.npy, a.nz > 1 ? a.nz / 2 + 1 : 1, a.h, a.k_over_eps) != 0) {
+      po->err = "fused_poisson_dirichlet launch failed";
+      return -3;
+    }
+  } else if (a.npx > 0) {
     hipLaunchKernelGGL(rhs_dirichlet_kernel, dim3(grid_for_p(po->n)), dim3(256), 0, stream, c, po->rhs, a);
-    PO_FFT(hipfftExecD2Z(po->fwd, po->rhs, reinterpret_cast<hipfftDoubleComplex*>(po->ph)));
+    PO_FFT(fftplan_exec(po->fwd, po->rhs, po->ph, &po->err));
     hipLaunchKernelGGL(invert_laplacian_kernel, dim3(grid_for_p(po->nh)), dim3(256), 0, stream, po->ph, po->nh, a, 0);
-    PO_FFT(hipfftExecZ2D(po->inv, reinterpret_cast<hipfftDoubleComplex*>(po->ph), phi));
+    PO_FFT(fftplan_exec(po->inv, po->ph, phi, &po->err));
     hipLaunchKernelGGL(fixup_dirichlet_kernel, dim3(grid_for_p(po->n)), dim3(256), 0, stream, phi, a);
   } else if (po->fast) {
     if (fused3d_poisson(po->fast, c, phi, po->ph, a.k_over_eps, a.inv_h2) != 0) {
@@ -201,9 +199,9 @@ int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream)
       return -3;
     }
   } else {
-    PO_FFT(hipfftExecD2Z(po->fwd, const_cast<double*>(c), reinterpret_cast<hipfftDoubleComplex*>(po->ph)));
+    PO_FFT(fftplan_exec(po->fwd, const_cast<double*>(c), po->ph, &po->err));
     hipLaunchKernelGGL(invert_laplacian_kernel, dim3(grid_for_p(po->nh)), dim3(256), 0, stream, po->ph, po->nh, a, 1);
-    PO_FFT(hipfftExecZ2D(po->inv, reinterpret_cast<hipfftDoubleComplex*>(po->ph), phi));
+    PO_FFT(fftplan_exec(po->inv, po->ph, phi, &po->err));
   }
   PO_HIP(hipGetLastError());
   return 0;

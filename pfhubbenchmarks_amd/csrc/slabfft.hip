@@ -9,8 +9,6 @@
 // and the mirror image back.  k-space kernels work on T: global indices kz = z, ky = rank*nyl + yq, kx.
 // The library never communicates: pf_dist_advance() runs up to the next exchange and tells the caller which
 // buffers to all-to-all (include/pfhip.h: pf_dist_request).
-#include <hipfft/hipfft.h>
-
 #include "pfhip_internal.h"
 
 namespace pfhip {
@@ -153,8 +151,7 @@ int sf_grid(int64_t n) {
 struct SlabFFT {
   SfGeom g;
   int64_t blk;  // complex elements per peer block
-  hipfftHandle p2f = 0, p2i = 0, pz = 0;
-  bool have_plans = false;
+  FftPlan *p2f = nullptr, *p2i = nullptr, *pzf = nullptr, *pzi = nullptr;  // library transforms (rocFFT, native API)
   Fused2D* fast = nullptr;  // power-of-two boxes: the hand-written LDS-FFT passes instead of rocFFT + pack / unpack
   double2 *tmp = nullptr, *A = nullptr, *B = nullptr, *chat = nullptr;
   bool own_ab = false;
@@ -173,11 +170,7 @@ struct SlabFFT {
   } while (0)
 #define SF_FFT(expr)                                                       \
   do {                                                                     \
-    hipfftResult r_ = (expr);                                              \
-    if (r_ != HIPFFT_SUCCESS) {                                            \
-      sf->err = std::string(#expr) + ": hipfft error " + std::to_string((int)r_); \
-      return -3;                                                           \
-    }                                                                      \
+    if ((expr) != 0) return -3; /* sf->err was filled by the fftplan_* call */ \
   } while (0)
 
 const char* slabfft_error(const SlabFFT* sf) { return sf->err.c_str(); }
@@ -220,17 +213,12 @@ int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, doubl
         return -3;
       }
     } else {
-      int n2[2] = {ny, nx};
-      SF_FFT(hipfftPlanMany(&sf->p2f, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, g.nzl));
-      SF_FFT(hipfftPlanMany(&sf->p2i, 2, n2, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, g.nzl));
-      int n1[1] = {nz};
-      int emb[1] = {nz};
-      const int stride = g.nyl * g.nxh;
-      SF_FFT(hipfftPlanMany(&sf->pz, 1, n1, emb, stride, 1, emb, stride, 1, HIPFFT_Z2Z, stride));
-      sf->have_plans = true;
-      SF_FFT(hipfftSetStream(sf->p2f, stream));
-      SF_FFT(hipfftSetStream(sf->p2i, stream));
-      SF_FFT(hipfftSetStream(sf->pz, stream));
+      const int n2[2] = {nx, ny};   // batched 2-D r2c / c2r over the local planes
+      SF_FFT(fftplan_real(&sf->p2f, 2, n2, g.nzl, true, stream, &sf->err));
+      SF_FFT(fftplan_real(&sf->p2i, 2, n2, g.nzl, false, stream, &sf->err));
+      const int stride = g.nyl * g.nxh;   // 1-D c2c along z on the transposed layout T[z][yq][kx], in place
+      SF_FFT(fftplan_c2c_strided(&sf->pzf, nz, stride, 1, stride, stream, true, &sf->err));
+      SF_FFT(fftplan_c2c_strided(&sf->pzi, nz, stride, 1, stride, stream, false, &sf->err));
     }
     const size_t loc = sizeof(double2) * (size_t)g.nzl * ny * g.pitch;
     SF_HIP(hipMalloc(&sf->tmp, loc));
@@ -262,11 +250,10 @@ int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, doubl
 
 void slabfft_destroy(SlabFFT* sf) {
   if (!sf) return;
-  if (sf->have_plans) {
-    (void)hipfftDestroy(sf->p2f);
-    (void)hipfftDestroy(sf->p2i);
-    (void)hipfftDestroy(sf->pz);
-  }
+  fftplan_destroy(sf->p2f);
+  fftplan_destroy(sf->p2i);
+  fftplan_destroy(sf->pzf);
+  fftplan_destroy(sf->pzi);
   if (sf->fast) fused2d_destroy(sf->fast);
   if (sf->tmp) (void)hipFree(sf->tmp);
   if (sf->own_ab) {
@@ -289,7 +276,7 @@ int slabfft_forward_local(SlabFFT* sf, const double* real_in) {
     return 0;
   }
   const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nxh;
-  SF_FFT(hipfftExecD2Z(sf->p2f, const_cast<double*>(real_in), reinterpret_cast<hipfftDoubleComplex*>(sf->tmp)));
+  SF_FFT(fftplan_exec(sf->p2f, const_cast<double*>(real_in), sf->tmp, &sf->err));
   hipLaunchKernelGGL(sf_pack_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, (const double2*)sf->tmp, sf->A, sf->g);
   SF_HIP(hipGetLastError());
   return 0;
@@ -315,8 +302,7 @@ int slabfft_z(SlabFFT* sf, int inverse) {
     }
     return 0;
   }
-  SF_FFT(hipfftExecZ2Z(sf->pz, reinterpret_cast<hipfftDoubleComplex*>(sf->B),
-                       reinterpret_cast<hipfftDoubleComplex*>(sf->B), inverse ? HIPFFT_BACKWARD : HIPFFT_FORWARD));
+  SF_FFT(fftplan_exec(inverse ? sf->pzi : sf->pzf, sf->B, nullptr, &sf->err));
   return 0;
 }
 // A (after the all-to-all B -> A) -> real slab
@@ -330,7 +316,7 @@ int slabfft_inverse_local(SlabFFT* sf, double* real_out) {
   }
   const int64_t n = (int64_t)sf->g.nzl * sf->g.ny * sf->g.nxh;
   hipLaunchKernelGGL(sf_unpack_kernel, dim3(sf_grid(n)), dim3(256), 0, sf->stream, (const double2*)sf->A, sf->tmp, sf->g);
-  SF_FFT(hipfftExecZ2D(sf->p2i, reinterpret_cast<hipfftDoubleComplex*>(sf->tmp), real_out));
+  SF_FFT(fftplan_exec(sf->p2i, sf->tmp, real_out, &sf->err));
   SF_HIP(hipGetLastError());
   return 0;
 }

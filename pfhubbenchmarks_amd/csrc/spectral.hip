@@ -1,4 +1,6 @@
-// Semi-implicit Fourier-spectral Cahn-Hilliard step (BASELINE.json config 2: 512^2, fp64) on rocFFT (hipFFT API).
+// Semi-implicit Fourier-spectral Cahn-Hilliard step (BASELINE.json config 2: 512^2, fp64): HIP k-space kernels around
+// library transforms -- rocFFT through its native API (fftplan.hip) -- for the sizes the hand-written passes of
+// spectral2d_fused.hip do not cover.
 //
 //   c_t = M lap( f'(c) - kappa lap c )        dolfin/pfbase.py:361-383, f' from dolfin/bench1.py:63-65
 //   (c^+_k - c_k)/dt = -M k^2 N_k - M kappa k^4 c^+_k,   N = f'(c^n)   (stiff term implicit, nonlinearity explicit)
@@ -7,8 +9,8 @@
 // Per step: [HIP] g = f'(c)  ->  rocFFT r2c(g)  ->  [HIP] k-space update (c_k stays resident; also emits c_k/N for
 // the inverse)  ->  rocFFT c2r.  The inverse transform's input is a scratch copy because multi-dimensional c2r
 // may overwrite its input.  The same pointwise f' as the FD kernel: a = c-ca; b = cb-c; 2 rho ((a b)(b-a)).
-#include <hipfft/hipfft.h>
-
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "pfhip_internal.h"
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void dfdc_kernel(const double* __restrict__ c,
 struct KsArgs {
   int nxh, ny, nz;   // half-spectrum extents (x fastest)
   int pitch;         // complex elements per k_x row in memory (nxh, or 264 on the hand-written 512^3 path)
+  int zb = 0, nyp = 0, bp = 1;  // hand-written 3-D path: row (z, y) = ((z >> zb) nyp + y) bp + (z & (2^zb - 1)), SpecLayout
   int nx;            // full x extent
   double kx0, ky0, kz0;  // 2 pi / (n h) per axis
   double dtM, dtMkappa, inv_n;
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(256) void kspace_grad_energy_kernel(const double2* 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nh; i += (int64_t)gridDim.x * 256) {
     const int mx = (int)(i % a.nxh);
     const double w = (mx == 0 || 2 * mx == a.nx) ? 1.0 : 2.0;
-    const double2 ch = chat[(i / a.nxh) * a.pitch + mx];   // i runs over the logical half spectrum
+    const int64_t row = i / a.nxh;                         // i runs over the logical half spectrum: row = z ny + y
+    const int z = (int)(row / a.ny), y = (int)(row % a.ny);
+    const double2 ch = chat[((((int64_t)(z >> a.zb) * a.nyp + y) * a.bp) + (z & ((1 << a.zb) - 1))) * a.pitch + mx];
     const double k2 = ksq(a, i), m2 = ch.x * ch.x + ch.y * ch.y;
     acc += w * k2 * m2;
     if (k2 > 0.0) acc2 += w * m2 / k2;
@@ -137,27 +142,13 @@ int grid_for(int64_t n) {
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
-const char* fft_err(hipfftResult r) {
-  switch (r) {
-    case HIPFFT_SUCCESS: return "HIPFFT_SUCCESS";
-    case HIPFFT_INVALID_PLAN: return "HIPFFT_INVALID_PLAN";
-    case HIPFFT_ALLOC_FAILED: return "HIPFFT_ALLOC_FAILED";
-    case HIPFFT_INVALID_VALUE: return "HIPFFT_INVALID_VALUE";
-    case HIPFFT_INTERNAL_ERROR: return "HIPFFT_INTERNAL_ERROR";
-    case HIPFFT_EXEC_FAILED: return "HIPFFT_EXEC_FAILED";
-    case HIPFFT_SETUP_FAILED: return "HIPFFT_SETUP_FAILED";
-    case HIPFFT_INVALID_SIZE: return "HIPFFT_INVALID_SIZE";
-    default: return "HIPFFT error";
-  }
-}
-
 }  // namespace
 
 struct Spectral {
   int dim, nx, ny, nz;
   int64_t n, nh;
-  hipfftHandle fwd = 0, inv = 0;
-  bool have_plans = false;
+  FftPlan *fwd = nullptr, *inv = nullptr;  // library transforms (null on the hand-written path)
+  unsigned char* block = nullptr;  // one allocation: chat | ghat | scratch
   double2 *chat = nullptr, *ghat = nullptr, *scratch = nullptr;
   double* g = nullptr;
   double* partials = nullptr;  // 2 x 2048 doubles
@@ -178,11 +169,7 @@ struct Spectral {
   } while (0)
 #define SP_FFT(expr)                                                       \
   do {                                                                     \
-    hipfftResult r_ = (expr);                                              \
-    if (r_ != HIPFFT_SUCCESS) {                                            \
-      sp->err = std::string(#expr) + ": " + fft_err(r_);                   \
-      return -3;                                                           \
-    }                                                                      \
+    if ((expr) != 0) return -3; /* sp->err was filled by the fftplan_* call */ \
   } while (0)
 
 const char* spectral_error(const Spectral* sp) { return sp->err.c_str(); }
@@ -199,8 +186,13 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
   sp->nh = (int64_t)nxh * ny * sp->nz;
   const char* e3 = getenv("PFHIP_SPECTRAL_2D");
   const bool want_fast = fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e3 && std::string(e3) == "rocfft");
-  sp->ks.pitch = want_fast ? fused_spectrum_pitch(dim, nx, ny, sp->nz) : nxh;
-  const int64_t nh_alloc = (int64_t)sp->ks.pitch * ny * sp->nz;
+  SpecLayout lay{nxh, 0, ny, 1, (int64_t)ny * sp->nz};
+  if (want_fast) lay = fused_spectrum_layout(dim, nx, ny, sp->nz);
+  sp->ks.pitch = lay.pitch;
+  sp->ks.zb = lay.zb;
+  sp->ks.nyp = lay.nyp;
+  sp->ks.bp = lay.bp;
+  const int64_t nh_alloc = (int64_t)lay.pitch * lay.rows;
   sp->ks.nxh = nxh;
   sp->ks.ny = ny;
   sp->ks.nz = sp->nz;
@@ -215,20 +207,39 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
   };
   auto body = [&]() -> int {
     if (!want_fast) {  // the hand-written passes need neither the library plans (and their work buffers) nor sp->g
-      if (dim == 2) {
-        SP_FFT(hipfftPlan2d(&sp->fwd, ny, nx, HIPFFT_D2Z));
-        SP_FFT(hipfftPlan2d(&sp->inv, ny, nx, HIPFFT_Z2D));
-      } else {
-        SP_FFT(hipfftPlan3d(&sp->fwd, sp->nz, ny, nx, HIPFFT_D2Z));
-        SP_FFT(hipfftPlan3d(&sp->inv, sp->nz, ny, nx, HIPFFT_Z2D));
-      }
-      sp->have_plans = true;
-      SP_FFT(hipfftSetStream(sp->fwd, stream));
-      SP_FFT(hipfftSetStream(sp->inv, stream));
+      const int nn[3] = {nx, ny, sp->nz};
+      SP_FFT(fftplan_real(&sp->fwd, dim, nn, 1, true, stream, &sp->err));
+      SP_FFT(fftplan_real(&sp->inv, dim, nn, 1, false, stream, &sp->err));
     }
-    SP_HIP(hipMalloc(&sp->chat, sizeof(double2) * nh_alloc));
-    SP_HIP(hipMalloc(&sp->ghat, sizeof(double2) * nh_alloc));
-    SP_HIP(hipMalloc(&sp->scratch, sizeof(double2) * nh_alloc));
+    {
+      // The three half-spectrum arrays come from ONE allocation at chosen distances (like the FD path's time levels,
+      // pfhip_api.hip placed_offset_bytes): three separate hipMallocs land wherever the allocator puts them, and the
+      // column passes' time depends on where their read and write streams sit relative to each other in the HBM
+      // channel map (same binary: z pass 1.00 or 1.19 ms from process to process, profiles/r03).
+      // PFHIP_SPEC_PLACE="g_kb,h_kb": extra distance of ghat / scratch behind the array before it, in KB (A/B).
+      size_t off_g = 0, off_h = 0;
+      if (const char* e = getenv("PFHIP_SPEC_PLACE")) {
+        long a = 0, b = 0;
+        if (sscanf(e, "%ld,%ld", &a, &b) == 2 && a >= 0 && b >= 0 && a <= 4096 && b <= 4096) {
+          off_g = (size_t)a * 1024;
+          off_h = (size_t)b * 1024;
+        }
+      }
+      const size_t bytes = sizeof(double2) * nh_alloc, slot = (bytes + 255) / 256 * 256;
+      size_t align = 0, shift = 0;  // PFHIP_SPEC_ALIGN_MB: start the block on a multiple of this many MiB, PFHIP_SPEC_BASE_MB: plus this
+      if (const char* e = getenv("PFHIP_SPEC_ALIGN_MB")) align = (size_t)std::atol(e) << 20;
+      if (const char* e = getenv("PFHIP_SPEC_BASE_MB")) shift = (size_t)std::atol(e) << 20;
+      SP_HIP(hipMalloc(&sp->block, 3 * slot + off_g + off_h + align + shift));
+      unsigned char* base = sp->block;
+      if (align) base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(base) + align - 1) / align * align);
+      base += shift;
+      sp->chat = reinterpret_cast<double2*>(base);
+      sp->ghat = reinterpret_cast<double2*>(base + slot + off_g);
+      sp->scratch = reinterpret_cast<double2*>(base + 2 * slot + off_g + off_h);
+      if (getenv("PFHIP_SPECTRAL_VERBOSE"))
+        fprintf(stderr, "[spectral] block %p chat %p ghat %p scratch %p (%zu bytes each)\n", (void*)sp->block, (void*)sp->chat,
+                (void*)sp->ghat, (void*)sp->scratch, bytes);
+    }
     if (nh_alloc != sp->nh) {  // padded rows: the pad columns are never written by the passes; keep them defined
       SP_HIP(hipMemsetAsync(sp->chat, 0, sizeof(double2) * nh_alloc, stream));
       SP_HIP(hipMemsetAsync(sp->ghat, 0, sizeof(double2) * nh_alloc, stream));
@@ -249,13 +260,9 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
 
 void spectral_destroy(Spectral* sp) {
   if (!sp) return;
-  if (sp->have_plans) {
-    (void)hipfftDestroy(sp->fwd);
-    (void)hipfftDestroy(sp->inv);
-  }
-  if (sp->chat) (void)hipFree(sp->chat);
-  if (sp->ghat) (void)hipFree(sp->ghat);
-  if (sp->scratch) (void)hipFree(sp->scratch);
+  fftplan_destroy(sp->fwd);
+  fftplan_destroy(sp->inv);
+  if (sp->block) (void)hipFree(sp->block);
   if (sp->g) (void)hipFree(sp->g);
   if (sp->partials) (void)hipFree(sp->partials);
   if (sp->fast) fused2d_destroy(sp->fast);
@@ -279,7 +286,7 @@ static int ensure_chat(Spectral* sp, const double* c) {
     sp->chat_valid = true;
     return 0;
   }
-  SP_FFT(hipfftExecD2Z(sp->fwd, const_cast<double*>(c), reinterpret_cast<hipfftDoubleComplex*>(sp->chat)));
+  SP_FFT(fftplan_exec(sp->fwd, const_cast<double*>(c), sp->chat, &sp->err));
   sp->chat_valid = true;
   return 0;
 }
@@ -300,14 +307,14 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
     return 0;
   }
   hipLaunchKernelGGL(dfdc_kernel, dim3(grid_for(sp->n / 2)), dim3(256), 0, stream, c_in, sp->g, sp->n, ca, cb, two_rho);
-  SP_FFT(hipfftExecD2Z(sp->fwd, sp->g, reinterpret_cast<hipfftDoubleComplex*>(sp->ghat)));
+  SP_FFT(fftplan_exec(sp->fwd, sp->g, sp->ghat, &sp->err));
   KsArgs ks = sp->ks;
   ks.dtM = dt * M;
   ks.dtMkappa = dt * M * kappa;
   ks.gam = dt * M * sp->gq;
   hipLaunchKernelGGL(kspace_update_kernel, dim3(grid_for(sp->nh)), dim3(256), 0, stream, sp->chat,
                      (const double2*)sp->ghat, sp->scratch, sp->nh, ks);
-  SP_FFT(hipfftExecZ2D(sp->inv, reinterpret_cast<hipfftDoubleComplex*>(sp->scratch), c_out));
+  SP_FFT(fftplan_exec(sp->inv, sp->scratch, c_out, &sp->err));
   SP_HIP(hipGetLastError());
   return 0;
 }

@@ -43,18 +43,45 @@ struct F2Args {
   double kz0 = 0.0;
   double gam = 0.0;  // BM6: dt M k_c^2 / eps added to the implicit denominator for k != 0
   int yoff = 0;      // slab-decomposed z pass: global k_y index of the first local y-row
+  // single-GPU 3-D boxes: row (z, y) of a half-spectrum array, see spec_row() / SpecLayout
+  int zb = 0;        // log2 of the z-block (0: planes are not blocked)
+  int nyp = 0;       // rows reserved per plane (ny + pad rows; 0 = ny)
+  int bp = 1;        // rows reserved per (y, z-block) group (2^zb + pad rows)
 };
 
-// Column passes of the slab-decomposed transforms (csrc/slabfft.hip) move their columns between the natural layout
-// [batch][row][kx] and the all-to-all layout [row / split][batch][row % split][kx] on the fly: element r of the column of
-// batch b sits at (r >> lg) * chunk + b * bstride + (r & (2^lg - 1)) * col_stride + kx.  on = 1: the store side of a
-// MODE 0 pass (written to H instead of in place); on = 2: the load side of a MODE 1 pass (read from A, written to H).
-struct ColSplit {
-  int on = 0, lg = 0;
-  int64_t chunk = 0, bstride = 0;
+// Row (z, y) of a half-spectrum array starts at spec_row() complex elements:
+//   row = ((z >> zb) nyp + y) bp + (z & (2^zb - 1)),   element = row pitch + kx.
+// Default: zb = 0, bp = 1, nyp = ny: the plain [z][y][kx] order.  The other forms exist for A/B and are OFF because they
+// measured no better (profiles/r03/spectral_512c_layouts.md).  The question they answer: the same column kernel runs
+// 30-45 % slower per byte along z (stride one plane = 2.06 MB) than along y (stride one row = 4224 B).  Not the TLB and
+// not the stride's length: a z-BLOCKED layout (PFHIP_FFT3D_ZBLOCK=4: [z / 16][y][z % 16][kx], z stride 4224 B inside a
+// block) took the z pass from 1050 to 1008 us but the y passes, now at stride 16 rows, from 446 to 557 us (460 with one
+// pad row per 16-row group) -- no net gain; pad rows per plane (PFHIP_FFT3D_PLANEPAD = 1, 2, 3, 5, 9, 33: plane strides
+// of every residue) changed nothing within +-0.5 % in one process.
+__host__ __device__ __forceinline__ int64_t spec_row(const F2Args& a, int z, int y) {
+  return ((((int64_t)(z >> a.zb) * a.nyp + y) * a.bp) + (z & ((1 << a.zb) - 1))) * a.pitch;
+}
+// the same from the flattened row index z ny + y (2-D: z = 0)
+__host__ __device__ __forceinline__ int64_t spec_row_flat(const F2Args& a, int row) {
+  if (!(a.zb || a.nyp != a.ny)) return (int64_t)row * a.pitch;
+  const int z = a.lgy >= 0 ? row >> a.lgy : row / a.ny;  // ny a power of two except on the mixed-radix path
+  return spec_row(a, z, row - z * a.ny);
+}
+
+// Where element r of the column of batch b lives (complex elements, k_x added by the caller):
+//   (r >> lr) rchunk + (r & (2^lr - 1)) rstride + (b >> lb) bchunk + (b & (2^lb - 1)) bstride        (lr / lb = 31: no split)
+// covers the plain layout, the z-blocked layout of spec_row() for both column directions, and the all-to-all layout
+// [row / split][batch][row % split][kx] that the column passes of the slab-decomposed transforms (csrc/slabfft.hip) read /
+// write on the fly.  A pass gets two maps: `mn` for its natural side and `ms` for the other side when spon != 0
+// (spon = 1: the store side of a MODE 0 pass goes to H through ms; spon = 2: the load side of a MODE 1 pass comes from A
+// through ms and the result goes to H through mn).
+struct ColMap {
+  int lr = 31, lb = 31;
+  int64_t rchunk = 0, rstride = 0, bchunk = 0, bstride = 0;
 };
-__device__ __forceinline__ int64_t split_addr(const ColSplit& sp, int b, int kx, int r, int64_t col_stride) {
-  return (int64_t)(r >> sp.lg) * sp.chunk + (int64_t)b * sp.bstride + (int64_t)(r & ((1 << sp.lg) - 1)) * col_stride + kx;
+__device__ __forceinline__ int64_t col_addr(const ColMap& m, int b, int r) {
+  return (int64_t)(r >> m.lr) * m.rchunk + (int64_t)(r & (int)((1u << m.lr) - 1u)) * m.rstride +
+         (int64_t)(b >> m.lb) * m.bchunk + (int64_t)(b & (int)((1u << m.lb) - 1u)) * m.bstride;
 }
 
 __device__ __forceinline__ int brev(int i, int lg) { return (int)(__brev((unsigned)i) >> (32 - lg)); }
@@ -184,7 +211,7 @@ __global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double
   double2 z[MAXP];
   if (from_spectrum) {
     for (int k = lane; k <= N / 2; k += RT) {
-      const double2 p = H[(int64_t)y0 * a.pitch + k], q = H[(int64_t)y1 * a.pitch + k];
+      const double2 p = H[spec_row_flat(a, y0) + k], q = H[spec_row_flat(a, y1) + k];
       X[px(brev(k, lg))] = make_double2(p.x - q.y, p.y + q.x);  // p + i q
       if (k > 0 && k < N / 2) X[px(brev(N - k, lg))] = make_double2(p.x + q.y, q.x - p.y);  // conj(p) + i conj(q)
     }
@@ -219,8 +246,8 @@ __global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double
   fft_inplace<-1, RT>(X, TW, N, lg, lane);
   for (int k = lane; k <= N / 2; k += RT) {
     const double2 w = X[px(k)], m = X[px((N - k) & (N - 1))];
-    G[(int64_t)y0 * a.pitch + k] = make_double2(0.5 * (w.x + m.x), 0.5 * (w.y - m.y));
-    G[(int64_t)y1 * a.pitch + k] = make_double2(0.5 * (w.y + m.y), -0.5 * (w.x - m.x));
+    G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + m.x), 0.5 * (w.y - m.y));
+    G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + m.y), -0.5 * (w.x - m.x));
   }
 }
 
@@ -297,8 +324,11 @@ __global__ __launch_bounds__(CT * CW) void f2_col_kernel(const F2Args a, const d
 // Physical lane p = 8 q + s ends up holding X[T(p) + 64 t] with T(p) = q + 8 s (the two octal digits of p swapped).
 // The input side accepts any lane -> l map m(p) (the twiddles W_512^(m q) come from a table row), so a second transform
 // can consume the first one's output in place with m = T: forward and inverse chain without touching LDS in between.
-// LDS layout of the exchanges: 8 blocks of 72 slots (64 + 8 pad); exchange 1 at [q*72 + l], exchange 2 at
-// [q*72 + 9*l0 + s]: both directions of both exchanges are bank-conflict free per quarter-wave of 16-byte accesses.
+// LDS layout of the exchanges: 8 blocks of 72 slots (64 + 8 pad); exchange 1 at [q*72 + l + l/8] (input index l skewed by
+// one slot per 8: conflict-free for BOTH lane -> l maps in use, m = lane and the chained m = T(lane) -- the unskewed form
+// put the 8 lanes of a 16-byte write group of the chained map on two bank groups, a 4-way conflict on every store of the
+// row pass's forward transform: round 3, SQ_LDS_BANK_CONFLICT = 50 % of its LDS cycles), exchange 2 at [q*72 + 9*l0 + s]:
+// both directions of both exchanges are bank-conflict free per group of 16-byte accesses.
 constexpr int W8 = 576;  // double2 slots of LDS per wave (8 * 72)
 constexpr double RSQRT2 = 0.70710678118654752440084436210485;
 
@@ -366,10 +396,10 @@ __device__ __forceinline__ void fft512_wave(double2 (&v)[8], double2* L, int m, 
     v[q] = cmul2(w, v[q]);
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) L[q * 72 + m] = v[q];
+  for (int q = 0; q < 8; ++q) L[q * 72 + m + (m >> 3)] = v[q];
   wave_lds_sync();
 #pragma unroll
-  for (int l1 = 0; l1 < 8; ++l1) v[l1] = L[hi * 72 + lo + 8 * l1];
+  for (int l1 = 0; l1 < 8; ++l1) v[l1] = L[hi * 72 + lo + 9 * l1];
   radix8<SIGN>(v);
 #pragma unroll
   for (int s = 1; s < 8; ++s) {
@@ -406,10 +436,10 @@ __device__ __forceinline__ void fft512_wave_tw(double2 (&v)[8], double2* L, int 
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) L[q * 72 + m] = v[q];
+  for (int q = 0; q < 8; ++q) L[q * 72 + m + (m >> 3)] = v[q];
   wave_lds_sync();
 #pragma unroll
-  for (int l1 = 0; l1 < 8; ++l1) v[l1] = L[hi * 72 + lo + 8 * l1];
+  for (int l1 = 0; l1 < 8; ++l1) v[l1] = L[hi * 72 + lo + 9 * l1];
   {
     double2 tw[7];
 #pragma unroll
@@ -468,7 +498,7 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
       const int k = lane + 64 * j;
       const bool upper = k > N / 2;
       const int kk = upper ? N - k : k;
-      const double2 p = H[(int64_t)y0 * a.pitch + kk], q = H[(int64_t)y1 * a.pitch + kk];
+      const double2 p = H[spec_row_flat(a, y0) + kk], q = H[spec_row_flat(a, y1) + kk];
       // X[k] = p + i q for k <= N/2, conj(p) + i conj(q) beyond (Hermitian rows)
       v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
     }
@@ -517,8 +547,8 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
     if (k <= N / 2) {
       const int km = (N - k) & (N - 1);
       const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-      G[(int64_t)y0 * a.pitch + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
-      G[(int64_t)y1 * a.pitch + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+      G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+      G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
     }
   }
 }
@@ -587,6 +617,227 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
   }
 }
 
+
+// ---- per-XCD work queues for the 3-D column passes ---------------------------------------------------------------------
+// A 4-column workgroup moves 64-byte half lines; the two workgroups that share a 128-byte line only save the second HBM
+// fetch if they run on the same XCD (same L2) at about the same time.  A static blockIdx -> item map cannot promise
+// that once the dispatcher refills the XCDs out of order (round 2: the z pass fetched 1.57x its bytes).  Instead every
+// workgroup is persistent, reads the id of the XCD it landed on and pulls items from THAT XCD's queue: an XCD owns a
+// contiguous run of items and hands them out in order, so neighbouring items are taken by the same L2 within a fraction
+// of a microsecond of each other, wherever the dispatcher put the workgroups.  An XCD whose queue is empty steals from
+// the others (tail balance).  Placement only affects speed, never results: every item is processed exactly once.
+// Counters: two sets of 8 heads (one 128-byte line each); launch n uses set n & 1 and block 0 zeroes the other set for
+// launch n + 1 (launches of one Fused2D are ordered on one stream).
+constexpr int QSTRIDE = 32;  // ints per head: one 128-byte line
+struct XcdQueue {
+  int* head;
+  int per, nitems, xcc, k0;
+  __device__ __forceinline__ void init(int* set, int* other, int n) {
+    head = set;
+    nitems = n;
+    per = ((n + 7) / 8 + 1) & ~1;  // even: a line-sharing pair never straddles two XCDs' runs
+    int id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    xcc = id & 7;
+    k0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 8) other[threadIdx.x * QSTRIDE] = 0;
+  }
+  // the same for ONE wave (workgroups whose waves work independently): lane 0 pops, the value is broadcast
+  __device__ __forceinline__ int pop_wave() {
+    int it = nitems;
+    if ((threadIdx.x & 63) == 0) {
+      for (; k0 < 8; ++k0) {
+        const int x = (xcc + k0) & 7;
+        const int lo = x * per, hi = lo + per < nitems ? lo + per : nitems;
+        if (lo >= hi) continue;
+        const int t = __hip_atomic_fetch_add(head + x * QSTRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo + t < hi) {
+          it = lo + t;
+          break;
+        }
+      }
+    }
+    return __builtin_amdgcn_readfirstlane(it);
+  }
+  // next item for this workgroup, or nitems when every queue is empty (called by all threads; two barriers)
+  __device__ __forceinline__ int pop(int* s_item) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int it = nitems;
+      for (; k0 < 8; ++k0) {  // queues only ever run dry, so the scan never goes back
+        const int x = (xcc + k0) & 7;
+        const int lo = x * per, hi = lo + per < nitems ? lo + per : nitems;
+        if (lo >= hi) continue;
+        const int t = __hip_atomic_fetch_add(head + x * QSTRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo + t < hi) {
+          it = lo + t;
+          break;
+        }
+      }
+      *s_item = it;
+    }
+    __syncthreads();
+    return *s_item;
+  }
+};
+
+// Row pass of the 3-D boxes (nx == 512), experimental forms of f2_row512_kernel<true>: RWT row pairs (waves) per
+// workgroup, MINW waves per SIMD asked of the register allocator, PERSIST: persistent waves fed by the per-XCD queues
+// (each wave pops its own row pairs; no workgroup barrier anywhere: every LDS region is private to its wave).
+template <int RWT, int MINW, bool PERSIST>
+__global__ __launch_bounds__(64 * RWT, MINW) void f3_row512_kernel(const F2Args a, const double2* __restrict__ H,
+                                                                   const double* __restrict__ c_in,
+                                                                   double* __restrict__ c_out, double2* __restrict__ G,
+                                                                   const double2* __restrict__ twA_g,
+                                                                   const double2* __restrict__ twB_g, int from_spectrum,
+                                                                   int use_fprime, int npairs, int* __restrict__ qset,
+                                                                   int* __restrict__ qother) {
+  __shared__ __attribute__((aligned(16))) double2 Lall[RWT * W8];
+  constexpr int N = 512;
+  int pair = blockIdx.x * RWT + (threadIdx.x >> 6);
+  XcdQueue xq;
+  if (PERSIST) {
+    xq.init(qset, qother, npairs);
+    pair = xq.pop_wave();
+  }
+  while (pair < npairs) {
+    asm volatile("" : "+s"(twA_g), "+s"(twB_g));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    double2* L = Lall + (tid >> 6) * W8;
+    const int y0 = 2 * pair, y1 = y0 + 1;
+    const int T = (lane >> 3) + 8 * (lane & 7);
+    double2 v[8];
+    int m = lane;
+    bool done = false;
+    if (from_spectrum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = lane + 64 * j;
+        const bool upper = k > N / 2;
+        const int kk = upper ? N - k : k;
+        const double2 p = H[spec_row_flat(a, y0) + kk], q = H[spec_row_flat(a, y1) + kk];
+        v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
+      }
+      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+      if (c_out) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
+          c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
+        }
+      }
+      done = from_spectrum == 2;  // inverse only (Poisson solve)
+      m = T;
+      wave_lds_sync();
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = make_double2(c_in[(int64_t)y0 * N + lane + 64 * j], c_in[(int64_t)y1 * N + lane + 64 * j]);
+    }
+    if (!done) {
+      if (use_fprime) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
+      }
+      fft512_wave_tw<-1>(v, L, m, twA_g, twB_g, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = T + 64 * t;
+        L[k + (k >> 3)] = v[t];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int k = lane + 64 * t;
+        if (k <= N / 2) {
+          const int km = (N - k) & (N - 1);
+          const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
+          G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+          G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+        }
+      }
+    }
+    if (!PERSIST) break;
+    wave_lds_sync();
+    pair = xq.pop_wave();
+  }
+}
+
+// Row pass of a time step (inverse x -> c -> f'(c) -> forward x) with the NEXT row pair's half-spectrum rows already in
+// flight: one persistent wave per workgroup walks row pairs pair, pair + W, pair + 2 W, ...; right after a pair's 16 loads
+// have been combined into the transform's input, the loads of the wave's next pair are issued into the same registers and
+// stay in flight during the two transforms (16 KB per wave at all times; 3 waves per SIMD at <= 168 VGPRs).
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, const double2* __restrict__ H,
+                                                              double* __restrict__ c_out, double2* __restrict__ G,
+                                                              const double2* __restrict__ twA_g,
+                                                              const double2* __restrict__ twB_g, int npairs) {
+  __shared__ __attribute__((aligned(16))) double2 L[W8];
+  constexpr int N = 512;
+  const int lane = threadIdx.x;
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  double2 p[8], q[8];
+  int pair = blockIdx.x;
+  auto issue = [&](int pr) {
+    const int64_t r0 = spec_row_flat(a, 2 * pr), r1 = spec_row_flat(a, 2 * pr + 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lane + 64 * j;
+      const int kk = k > N / 2 ? N - k : k;
+      p[j] = H[r0 + kk];
+      q[j] = H[r1 + kk];
+    }
+  };
+  if (pair < npairs) issue(pair);
+  while (pair < npairs) {
+    asm volatile("" : "+s"(twA_g), "+s"(twB_g));
+    double2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool upper = lane + 64 * j > N / 2;
+      v[j] = upper ? make_double2(p[j].x + q[j].y, q[j].x - p[j].y) : make_double2(p[j].x - q[j].y, p[j].y + q[j].x);
+    }
+    const int y0 = 2 * pair, y1 = y0 + 1;
+    const int next = pair + gridDim.x;
+    if (next < npairs) issue(next);
+    fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+    if (c_out) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
+        c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
+    fft512_wave_tw<-1>(v, L, T, twA_g, twB_g, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = T + 64 * t;
+      L[k + (k >> 3)] = v[t];
+    }
+    wave_lds_sync();
+    const int64_t g0 = spec_row_flat(a, y0), g1 = spec_row_flat(a, y1);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int k = lane + 64 * t;
+      if (k <= N / 2) {
+        const int km = (N - k) & (N - 1);
+        const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
+        G[g0 + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+        G[g1 + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+      }
+    }
+    wave_lds_sync();
+    pair = next;
+  }
+}
+
 // =====================================================================================================================
 // 3-D (512^3): the same one-wave radix-8 transforms applied along y and along z of the [z][y][kx] half spectrum.
 // A workgroup owns 8 adjacent k_x columns (one full 128-byte line per row of the column) of one "batch" (a z-plane for
@@ -600,37 +851,50 @@ __global__ __launch_bounds__(64 * CWN) void f2_col512_direct_kernel(const F2Args
 template <int MODE, int CW3, bool EARLY = false>  // EARLY (MODE 2): request the resident spectrum before the forward FFT
 __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
                                                              double2* __restrict__ chat, double2* __restrict__ H,
-                                                             int64_t col_stride, int64_t batch_stride, int nblk,
+                                                             const ColMap mn, const ColMap ms, int spon, int nblk,
                                                              int nitems, const double2* __restrict__ twA_g,
-                                                             const double2* __restrict__ twB_g, const ColSplit sp) {
+                                                             const double2* __restrict__ twB_g,
+                                                             int* __restrict__ qset, int* __restrict__ qother) {
   __shared__ __attribute__((aligned(16))) double2 Lall[CW3 * W8C];
+  __shared__ int s_item;
   constexpr int N = 512, NT = 64 * CW3, PER = 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double2* L = Lall + wave * W8C + 4 * wave;
-  const int T = (lane >> 3) + 8 * (lane & 7);
   auto nat = [](int n) { return n + (n >> 3); };
-  const int ci = tid % CW3;
-  double2* Lc = Lall + ci * W8C + 4 * ci;
-  double2 v[8], ch[PER];
   // One work item (batch b, block of CW3 k_x columns) per workgroup.  (A persistent, software-pipelined form -- next
   // item's loads in flight during the transforms -- was measured and is slower: 3.85 vs 3.25 ms per step; its extra 32
   // VGPRs cost a wave per SIMD, and short-lived workgroups already overlap through the dispatcher.)
   // CW3 = 4: a 128-byte line holds two items' columns; items i and i + 8 are taken by workgroups on the same XCD back
   // to back (round-robin dispatch), so give THEM the two halves of one line.
-  {
-    const int item = blockIdx.x;
+  // qset != null: persistent workgroups fed by the per-XCD queues above (items in natural order: neighbours in time and
+  // L2); null: one item per workgroup, blockIdx -> item with the static pair swizzle (kept for A/B)
+  XcdQueue xq;
+  int item = blockIdx.x;
+  if (qset) {
+    xq.init(qset, qother, nitems);
+    item = xq.pop(&s_item);
+  }
+  while (item < nitems) {
+    // the twiddle tables are re-read from L1 right before each use BY DESIGN (fft512_wave_tw); hide the pointers from the
+    // optimiser once per item so that it cannot hoist those loads out of this loop into 56+ live VGPRs (= scratch)
+    asm volatile("" : "+s"(twA_g), "+s"(twB_g));
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // same for the per-thread index arithmetic (cheap to redo, expensive to keep live)
+    const int lane = tid & 63, wave = tid >> 6;
+    double2* L = Lall + wave * W8C + 4 * wave;
+    const int T = (lane >> 3) + 8 * (lane & 7);
+    const int ci = tid % CW3;
+    double2* Lc = Lall + ci * W8C + 4 * ci;
+    double2 v[8], ch[PER];
     int lb = item;
-    if (CW3 == 4) {
+    if (CW3 == 4 && !qset) {
       const int grp = lb >> 4, r = lb & 15;
       if ((grp << 4) + 16 <= nitems) lb = (grp << 4) + ((r & 7) << 1) + (r >> 3);  // ragged last group: identity
     }
     const int b = lb / nblk, kx = (lb % nblk) * CW3 + ci;
     const bool on = kx < a.nxh;
-    const int64_t base = (int64_t)b * batch_stride + kx;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int r = (tid + NT * i) / CW3;
-      const int64_t src = (MODE == 1 && sp.on == 2) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+      const int64_t src = col_addr((MODE == 1 && spon == 2) ? ms : mn, b, r) + kx;
       v[i] = on ? A[src] : make_double2(0.0, 0.0);
     }
 #pragma unroll
@@ -640,7 +904,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        ch[i] = on ? chat[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+        ch[i] = on ? chat[col_addr(mn, b, r) + kx] : make_double2(0.0, 0.0);
       }
     }
     __syncthreads();
@@ -657,7 +921,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        ch[i] = on ? chat[base + (int64_t)r * col_stride] : make_double2(0.0, 0.0);
+        ch[i] = on ? chat[col_addr(mn, b, r) + kx] : make_double2(0.0, 0.0);
       }
     }
     __syncthreads();
@@ -685,14 +949,14 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        if (on) A[base + (int64_t)r * col_stride] = Lc[nat(r)];
+        if (on) A[col_addr(mn, b, r) + kx] = Lc[nat(r)];
       }
     } else if (MODE == 0 || MODE == 1 || MODE == 3) {
-      double2* dst = MODE == 3 ? chat : (sp.on ? H : A);
+      double2* dst = MODE == 3 ? chat : (spon ? H : A);
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        const int64_t di = (MODE == 0 && sp.on == 1) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+        const int64_t di = col_addr((MODE == 0 && spon == 1) ? ms : mn, b, r) + kx;
         if (on) dst[di] = Lc[nat(r)];
       }
     } else {
@@ -712,7 +976,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
         double2 r;
         r.x = fma(-num, gh.x, ch[i].x) * den;
         r.y = fma(-num, gh.y, ch[i].y) * den;
-        if (on) chat[base + (int64_t)kz * col_stride] = r;
+        if (on) chat[col_addr(mn, b, kz) + kx] = r;
         Lc[nat(kz)] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
       }
       __syncthreads();
@@ -726,9 +990,11 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        if (on) H[base + (int64_t)r * col_stride] = Lc[nat(r)];
+        if (on) H[col_addr(mn, b, r) + kx] = Lc[nat(r)];
       }
     }
+    if (!qset) break;
+    item = xq.pop(&s_item);
   }
 }
 
@@ -739,9 +1005,8 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 template <int MODE, int CWG, int G, int NMAX>  // G threads per column, axis length N <= NMAX
 __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, double2* __restrict__ A,
                                                           double2* __restrict__ chat, double2* __restrict__ H,
-                                                          int64_t col_stride, int64_t batch_stride, int nblk, int nitems,
-                                                          int N, int lg, const double2* __restrict__ tw_g,
-                                                          const ColSplit sp) {
+                                                          const ColMap mn, const ColMap ms, int spon, int nblk, int nitems,
+                                                          int N, int lg, const double2* __restrict__ tw_g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int NP = px(N) + 1;
   double2* X = reinterpret_cast<double2*>(smem_raw);  // [CWG][NP]
@@ -755,12 +1020,11 @@ __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, doub
   }
   const int b = lb / nblk, kx = (lb % nblk) * CWG + ci;
   const bool on = kx < a.nxh;
-  const int64_t base = (int64_t)b * batch_stride + kx;
   for (int k = tid; k < N / 2; k += NT) TW[k] = tw_g[k];
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int r = (tid + NT * i) / CWG;
-    const int64_t src = (MODE == 1 && sp.on == 2) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+    const int64_t src = col_addr((MODE == 1 && spon == 2) ? ms : mn, b, r) + kx;
     if (r < N) X[ci * NP + px(brev(r, lg))] = on ? A[src] : make_double2(0.0, 0.0);
   }
   __syncthreads();
@@ -769,11 +1033,11 @@ __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, doub
   else
     fft_inplace<-1, G, NMAX>(X + wave * NP, TW, N, lg, lane);
   if (MODE == 0 || MODE == 1 || MODE == 3) {
-    double2* dst = MODE == 3 ? chat : (sp.on ? H : A);
+    double2* dst = MODE == 3 ? chat : (spon ? H : A);
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       const int r = (tid + NT * i) / CWG;
-      const int64_t di = (MODE == 0 && sp.on == 1) ? split_addr(sp, b, kx, r, col_stride) : base + (int64_t)r * col_stride;
+      const int64_t di = col_addr((MODE == 0 && spon == 1) ? ms : mn, b, r) + kx;
       if (r < N && on) dst[di] = X[ci * NP + px(r)];
     }
     return;
@@ -793,11 +1057,11 @@ __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, doub
         const double num = a.dtM * k2;
         const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
         const double2 gh = X[ci * NP + px(kz)];
-        const double2 ch = on ? chat[base + (int64_t)kz * col_stride] : make_double2(0.0, 0.0);
+        const double2 ch = on ? chat[col_addr(mn, b, kz) + kx] : make_double2(0.0, 0.0);
         double2 r;
         r.x = fma(-num, gh.x, ch.x) * den;
         r.y = fma(-num, gh.y, ch.y) * den;
-        if (on) chat[base + (int64_t)kz * col_stride] = r;
+        if (on) chat[col_addr(mn, b, kz) + kx] = r;
         o[i] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
       }
     }
@@ -827,7 +1091,345 @@ __global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, doub
 #pragma unroll
   for (int i = 0; i < MAXP; ++i) {
     const int r = (tid + NT * i) / CWG;
-    if (r < N && on) dst[base + (int64_t)r * col_stride] = X[ci * NP + px(r)];
+    if (r < N && on) dst[col_addr(mn, b, r) + kx] = X[ci * NP + px(r)];
+  }
+}
+
+// =====================================================================================================================
+// MIXED-RADIX passes: axes whose length factors into 2, 3 and 5 (8 .. 1024 points) -- the reference's own lattices (100
+// intervals -> 200 / 400 points, dolfin/bench1.py:21-23) and any other such box -- on hand-written transforms too, so that
+// the library (rocFFT, fftplan.hip) is left with sizes that have a larger prime factor.  Same pass structure, same
+// spectrum layout (rocFFT's D2Z), same k-space arithmetic as the power-of-two kernels above; the transform is a
+// Stockham autosort FFT in LDS (two buffers per transform, natural order in and out, radix 4 / 2 / 3 / 5 stages, twiddles
+// from a full-circle table staged in LDS), G threads per transform.
+struct Radices {
+  int n = 0;
+  int r[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// X -> (result in the buffer X points at on return; Y is the other one).  Called by all G threads of the transform's
+// group (t = index in the group); every stage ends with a workgroup barrier (the groups of a workgroup run in lockstep).
+template <int SIGN, int G>
+__device__ __forceinline__ void fft_stockham(double2*& X, double2*& Y, const double2* TW, int N, const Radices& rd, int t) {
+  constexpr double S3 = 0.86602540378443864676372317075294;   // sin(pi/3)
+  constexpr double C51 = 0.30901699437494742410229341718282;  // cos(2 pi/5)
+  constexpr double C52 = -0.80901699437494742410229341718282; // cos(4 pi/5)
+  constexpr double S51 = 0.95105651629515357211643933337938;  // sin(2 pi/5)
+  constexpr double S52 = 0.58778525229247312916870595463907;  // sin(4 pi/5)
+  auto tw = [&](int idx) {  // W_N^idx for the direction of this transform
+    double2 w = TW[idx];
+    if (SIGN > 0) w.y = -w.y;
+    return w;
+  };
+  // i * SIGN * v  (forward: -i v ... the rotation every odd butterfly output needs)
+  auto rot = [](double2 v) { return SIGN < 0 ? make_double2(v.y, -v.x) : make_double2(-v.y, v.x); };
+  int Ns = 1;
+  for (int st = 0; st < rd.n; ++st) {
+    const int R = rd.r[st], M = N / R, step = N / (Ns * R);
+    for (int j = t; j < M; j += G) {
+      const int k = j % Ns, base = (j - k) * R + k;
+      if (R == 4) {
+        double2 a0 = X[j], a1 = X[j + M], a2 = X[j + 2 * M], a3 = X[j + 3 * M];
+        if (Ns > 1) {
+          a1 = cmul2(tw(k * step), a1);
+          a2 = cmul2(tw(2 * k * step), a2);
+          a3 = cmul2(tw(3 * k * step), a3);
+        }
+        const double2 s0 = cadd(a0, a2), d0 = csub(a0, a2), s1 = cadd(a1, a3), d1 = rot(csub(a1, a3));
+        Y[base] = cadd(s0, s1);
+        Y[base + Ns] = cadd(d0, d1);
+        Y[base + 2 * Ns] = csub(s0, s1);
+        Y[base + 3 * Ns] = csub(d0, d1);
+      } else if (R == 2) {
+        double2 a0 = X[j], a1 = X[j + M];
+        if (Ns > 1) a1 = cmul2(tw(k * step), a1);
+        Y[base] = cadd(a0, a1);
+        Y[base + Ns] = csub(a0, a1);
+      } else if (R == 3) {
+        double2 a0 = X[j], a1 = X[j + M], a2 = X[j + 2 * M];
+        if (Ns > 1) {
+          a1 = cmul2(tw(k * step), a1);
+          a2 = cmul2(tw(2 * k * step), a2);
+        }
+        const double2 sm = cadd(a1, a2), df = rot(csub(a1, a2));
+        const double2 m = make_double2(a0.x - 0.5 * sm.x, a0.y - 0.5 * sm.y);
+        Y[base] = cadd(a0, sm);
+        Y[base + Ns] = make_double2(m.x + S3 * df.x, m.y + S3 * df.y);
+        Y[base + 2 * Ns] = make_double2(m.x - S3 * df.x, m.y - S3 * df.y);
+      } else {  // 5
+        double2 a0 = X[j], a1 = X[j + M], a2 = X[j + 2 * M], a3 = X[j + 3 * M], a4 = X[j + 4 * M];
+        if (Ns > 1) {
+          a1 = cmul2(tw(k * step), a1);
+          a2 = cmul2(tw(2 * k * step), a2);
+          a3 = cmul2(tw(3 * k * step), a3);
+          a4 = cmul2(tw(4 * k * step), a4);
+        }
+        const double2 t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = rot(csub(a1, a4)), t4 = rot(csub(a2, a3));
+        const double2 m1 = make_double2(a0.x + C51 * t1.x + C52 * t2.x, a0.y + C51 * t1.y + C52 * t2.y);
+        const double2 m2 = make_double2(a0.x + C52 * t1.x + C51 * t2.x, a0.y + C52 * t1.y + C51 * t2.y);
+        const double2 n1 = make_double2(S51 * t3.x + S52 * t4.x, S51 * t3.y + S52 * t4.y);
+        const double2 n2 = make_double2(S52 * t3.x - S51 * t4.x, S52 * t3.y - S51 * t4.y);
+        Y[base] = make_double2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+        Y[base + Ns] = cadd(m1, n1);
+        Y[base + 2 * Ns] = cadd(m2, n2);
+        Y[base + 3 * Ns] = csub(m2, n2);
+        Y[base + 4 * Ns] = csub(m1, n1);
+      }
+    }
+    __syncthreads();
+    double2* sw = X;
+    X = Y;
+    Y = sw;
+    Ns *= R;
+  }
+}
+
+// Row pass (x): 256 threads per pair of rows; contract of f2_row_kernel.  twx_g: nx entries e^{-2 pi i k / nx}.
+__global__ __launch_bounds__(RT) void mx_row_kernel(const F2Args a, const double2* __restrict__ H,
+                                                    const double* __restrict__ c_in, double* __restrict__ c_out,
+                                                    double2* __restrict__ G, const double2* __restrict__ twx_g,
+                                                    int from_spectrum, int use_fprime, const Radices rx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = a.nx, lane = threadIdx.x;
+  double2* X = reinterpret_cast<double2*>(smem_raw);
+  double2* Y = X + N + 1;
+  double2* TW = Y + N + 1;
+  const int y0 = 2 * blockIdx.x, y1 = y0 + 1;
+  for (int k = lane; k < N; k += RT) TW[k] = twx_g[k];
+  constexpr int MAXP = 1024 / RT;
+  double2 z[MAXP];
+  if (from_spectrum) {
+    for (int k = lane; k <= N / 2; k += RT) {
+      const double2 p = H[spec_row_flat(a, y0) + k], q = H[spec_row_flat(a, y1) + k];
+      X[k] = make_double2(p.x - q.y, p.y + q.x);                                // p + i q
+      if (k > 0 && 2 * k < N) X[N - k] = make_double2(p.x + q.y, q.x - p.y);  // conj(p) + i conj(q)
+    }
+    __syncthreads();
+    fft_stockham<+1, RT>(X, Y, TW, N, rx, lane);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int x = lane + RT * i;
+      if (x < N) {
+        z[i] = X[x];
+        if (c_out) {
+          c_out[(int64_t)y0 * N + x] = z[i].x;
+          c_out[(int64_t)y1 * N + x] = z[i].y;
+        }
+      }
+    }
+    if (from_spectrum == 2) return;
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int x = lane + RT * i;
+      if (x < N) z[i] = make_double2(c_in[(int64_t)y0 * N + x], c_in[(int64_t)y1 * N + x]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int x = lane + RT * i;
+    if (x < N) X[x] = use_fprime ? make_double2(fp2(z[i].x, a), fp2(z[i].y, a)) : z[i];
+  }
+  __syncthreads();
+  fft_stockham<-1, RT>(X, Y, TW, N, rx, lane);
+  for (int k = lane; k <= N / 2; k += RT) {
+    const double2 w = X[k], m = X[k == 0 ? 0 : N - k];
+    G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + m.x), 0.5 * (w.y - m.y));
+    G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + m.y), -0.5 * (w.x - m.x));
+  }
+}
+
+// Column pass (y, or z of a 3-D box): MXC adjacent k_x columns per workgroup, MXG threads per column; MODEs and address
+// maps of f3_col_kernel.  two_d: the column axis is y of a 2-D grid (the k-space arithmetic then has k_y = row, k_z = 0).
+constexpr int MXC = 4, MXG = 64;
+template <int MODE>
+__global__ __launch_bounds__(MXC * MXG) void mx_col_kernel(const F2Args a, double2* __restrict__ A,
+                                                            double2* __restrict__ chat, double2* __restrict__ H,
+                                                            const ColMap mn, const ColMap ms, int spon, int nblk, int N,
+                                                            const double2* __restrict__ tw_g, const Radices rd, int two_d,
+                                                            int ext) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int NP = N + 1;
+  double2* S = reinterpret_cast<double2*>(smem_raw);  // [MXC][2][NP]
+  double2* TW = S + MXC * 2 * NP;
+  constexpr int NT = MXC * MXG;
+  const int tid = threadIdx.x, lane = tid % MXG, grp = tid / MXG, ci = tid % MXC;
+  const int lb = blockIdx.x;
+  const int b = lb / nblk, kx = (lb % nblk) * MXC + ci;
+  const bool on = kx < a.nxh;
+  for (int k = tid; k < N; k += NT) TW[k] = tw_g[k];
+  for (int idx = tid; idx < N * MXC; idx += NT) {
+    const int r = idx / MXC;
+    // ext: the column holds the N/2 + 1 physical nodes of a no-flux axis; the transform runs on its EVEN extension
+    const int rs = (ext && 2 * r > N) ? N - r : r;
+    const int64_t src = col_addr((MODE == 1 && spon == 2) ? ms : mn, b, rs) + kx;
+    S[ci * 2 * NP + r] = on ? A[src] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  double2* X = S + grp * 2 * NP;
+  double2* Y = X + NP;
+  if (MODE == 1)
+    fft_stockham<+1, MXG>(X, Y, TW, N, rd, lane);
+  else
+    fft_stockham<-1, MXG>(X, Y, TW, N, rd, lane);
+  const int res = (int)(X - (S + grp * 2 * NP));  // 0 or NP: which buffer holds the result (the same for every group)
+  if (MODE == 0 || MODE == 1 || MODE == 3) {
+    double2* dst = MODE == 3 ? chat : (spon ? H : A);
+    for (int idx = tid; idx < N * MXC; idx += NT) {
+      const int r = idx / MXC;
+      const int64_t di = col_addr((MODE == 0 && spon == 1) ? ms : mn, b, r) + kx;
+      if (on && !(ext && 2 * r > N)) dst[di] = S[ci * 2 * NP + res + r];
+    }
+    return;
+  }
+  // k-space stage on the transformed columns; the result goes into the OTHER buffer (input of the inverse transform)
+  const int oth = res ? 0 : NP;
+  for (int idx = tid; idx < N * MXC; idx += NT) {
+    const int r = idx / MXC;
+    const double2 gh = S[ci * 2 * NP + res + r];
+    double2 o;
+    if (MODE == 2) {
+      const int ky_i = two_d ? r : b + a.yoff, kz_i = two_d ? 0 : r;
+      const int my = 2 * ky_i > a.ny ? ky_i - a.ny : ky_i;
+      const int mz = 2 * kz_i > a.nz ? kz_i - a.nz : kz_i;
+      const double kxv = a.kx0 * kx, kyv = a.ky0 * my, kzv = a.kz0 * mz;
+      const double k2 = (kxv * kxv + kyv * kyv) + kzv * kzv;  // same grouping as spectral.hip's ksq
+      const double num = a.dtM * k2;
+      const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
+      const int64_t ca = col_addr(mn, b, r) + kx;
+      const double2 ch = on ? chat[ca] : make_double2(0.0, 0.0);
+      double2 rr;
+      rr.x = fma(-num, gh.x, ch.x) * den;
+      rr.y = fma(-num, gh.y, ch.y) * den;
+      if (on) chat[ca] = rr;
+      o = make_double2(rr.x * a.inv_n, rr.y * a.inv_n);
+    } else {  // MODE 4: Poisson, divide by the eigenvalue of the 5- / 7-point Laplacian (tables in `chat`, see f3_col512_kernel)
+      const double* sym = reinterpret_cast<const double*>(chat);
+      const double lam = two_d ? (sym[on ? kx : 0] + sym[a.nx + r]) * a.dtM
+                               : ((sym[on ? kx : 0] + sym[a.nx + b]) + sym[a.nx + a.ny + r]) * a.dtM;
+      const bool zero = kx == 0 && (two_d ? r == 0 : (b == 0 && r == 0));
+      const double sc = zero ? 0.0 : (a.inv_n / lam) * a.dtMkappa;
+      o = make_double2(gh.x * sc, gh.y * sc);
+      if (ext) {
+        // sine / cosine transforms on the physical nodes (fused_poisson_dirichlet): a complex element is TWO real
+        // columns, k_x = 2 kx and 2 kx + 1, each with its own eigenvalue; a.nxh counts the complex columns
+        const int ka = 2 * kx, kb = 2 * kx + 1;
+        const double rest = two_d ? sym[a.nx + r] : sym[a.nx + b] + sym[a.nx + a.ny + r];
+        const double la = (sym[on ? ka : 0] + rest) * a.dtM, lbv = (sym[on && kb < a.nx ? kb : 0] + rest) * a.dtM;
+        o = make_double2(la != 0.0 ? gh.x * (a.inv_n / la) : 0.0, lbv != 0.0 ? gh.y * (a.inv_n / lbv) : 0.0);
+      }
+    }
+    S[ci * 2 * NP + oth + r] = o;
+  }
+  __syncthreads();
+  X = S + grp * 2 * NP + oth;
+  Y = S + grp * 2 * NP + res;
+  fft_stockham<+1, MXG>(X, Y, TW, N, rd, lane);
+  const int res2 = (int)(X - (S + grp * 2 * NP));
+  double2* dst = MODE == 2 ? H : A;
+  for (int idx = tid; idx < N * MXC; idx += NT) {
+    const int r = idx / MXC;
+    if (on && !(ext && 2 * r > N)) dst[col_addr(mn, b, r) + kx] = S[ci * 2 * NP + res2 + r];
+  }
+}
+
+// ---- Poisson problem of the reference's BM6: phi = 0 on x = 0, phi = sin(y / 7) on x = Lx, no flux elsewhere ------------
+// (dolfin/bench6.py:77-90, pfbase.py:410-421) as a sine transform along x and cosine transforms along y (and z) ON THE
+// PHYSICAL NODES: the odd / even extensions exist only inside LDS, HBM sees the (Nx + 1)(Ny + 1)(Nz + 1) node values once
+// per pass -- a quarter (2-D) or an eighth (3-D) of the lattice the round-2 solver transformed, and the right-hand side,
+// the eigenvalue division and the Dirichlet values are fused into the passes (three library calls and three pointwise
+// kernels before).  S: real array [zp][yp][kx], kx = 0 .. Nx (+ pad to an even count), read as complex by the cosine passes.
+struct DirGeom {
+  int npx, npy, npz;   // physical nodes per axis (lattice n = 2 (np - 1)); npz = 1 in 2-D
+  int spitch;          // doubles per row of S (even)
+  double h, k_over_eps, inv_h2;
+};
+__device__ __forceinline__ double dir_right(double y) { return sin(y / 7.0); }  // bench6.py:84 phi_right
+
+// rows (yp, zp) in pairs: odd extension of the right-hand side -> forward FFT -> S = its (imaginary) sine coefficients
+__global__ __launch_bounds__(RT) void dst_row_fwd_kernel(const F2Args a, const DirGeom g, const double* __restrict__ c,
+                                                         double* __restrict__ S, const double2* __restrict__ twx_g,
+                                                         const Radices rx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = a.nx, Np = N / 2, lane = threadIdx.x;
+  double2* X = reinterpret_cast<double2*>(smem_raw);
+  double2* Y = X + N + 1;
+  double2* TW = Y + N + 1;
+  for (int k = lane; k < N; k += RT) TW[k] = twx_g[k];
+  const int nrows = g.npy * g.npz, r0 = 2 * blockIdx.x, r1 = r0 + 1;
+  const bool two = r1 < nrows;
+  const int y0 = r0 % g.npy, z0 = r0 / g.npy, y1 = two ? r1 % g.npy : 0, z1 = two ? r1 / g.npy : 0;
+  const double* c0 = c + ((int64_t)z0 * a.ny + y0) * N;   // physical nodes are the first np lattice points of each axis
+  const double* c1 = c + ((int64_t)z1 * a.ny + y1) * N;
+  const double g0 = dir_right(y0 * g.h) * g.inv_h2, g1 = dir_right(y1 * g.h) * g.inv_h2;
+  for (int x = lane; x < N; x += RT) {
+    const int xr = x <= Np ? x : N - x;
+    double va = 0.0, vb = 0.0;
+    if (xr != 0 && xr != Np) {
+      va = -g.k_over_eps * c0[xr];
+      vb = two ? -g.k_over_eps * c1[xr] : 0.0;
+      if (xr == Np - 1) {  // the Dirichlet value of x = Lx moved to the right-hand side
+        va -= g0;
+        if (two) vb -= g1;
+      }
+      if (x > Np) {
+        va = -va;
+        vb = -vb;
+      }
+    }
+    X[x] = make_double2(va, vb);
+  }
+  __syncthreads();
+  fft_stockham<-1, RT>(X, Y, TW, N, rx, lane);
+  for (int k = lane; k <= Np; k += RT) {
+    const double2 w = X[k], m = X[k == 0 ? 0 : N - k];
+    S[(int64_t)r0 * g.spitch + k] = 0.5 * (w.y - m.y);             // Im of the first row's transform
+    if (two) S[(int64_t)r1 * g.spitch + k] = -0.5 * (w.x - m.x);   // Im of the second row's
+  }
+}
+
+// S (solution's sine coefficients along x, already back in real space along y, z) -> phi on the whole lattice: even in x
+// with the Dirichlet values on x = 0, Lx (the Cahn-Hilliard kernel needs mu mirror symmetric), even in y and z
+__global__ __launch_bounds__(RT) void dst_row_inv_kernel(const F2Args a, const DirGeom g, const double* __restrict__ S,
+                                                         double* __restrict__ phi, const double2* __restrict__ twx_g,
+                                                         const Radices rx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = a.nx, Np = N / 2, lane = threadIdx.x;
+  double2* X = reinterpret_cast<double2*>(smem_raw);
+  double2* Y = X + N + 1;
+  double2* TW = Y + N + 1;
+  for (int k = lane; k < N; k += RT) TW[k] = twx_g[k];
+  const int nrows = g.npy * g.npz, r0 = 2 * blockIdx.x, r1 = r0 + 1;
+  const bool two = r1 < nrows;
+  for (int k = lane; k <= Np; k += RT) {
+    const double sa = S[(int64_t)r0 * g.spitch + k], sb = two ? S[(int64_t)r1 * g.spitch + k] : 0.0;
+    X[k] = make_double2(-sb, sa);                            // i sa + i (i sb)
+    if (k > 0 && k < Np) X[N - k] = make_double2(sb, -sa);   // conj(i sa) + i conj(i sb)
+  }
+  __syncthreads();
+  fft_stockham<+1, RT>(X, Y, TW, N, rx, lane);
+  for (int rr = 0; rr < (two ? 2 : 1); ++rr) {
+    const int r = r0 + rr, yp = r % g.npy, zp = r / g.npy;
+    const double right = dir_right(yp * g.h);
+    const int ym = (yp > 0 && yp < g.npy - 1) ? a.ny - yp : -1;   // mirror images on the lattice (none for the wall nodes)
+    const int zm = (g.npz > 1 && zp > 0 && zp < g.npz - 1) ? a.nz - zp : -1;
+    for (int x = lane; x <= Np; x += RT) {
+      const double2 zz = X[x];
+      const double v = x == 0 ? 0.0 : (x == Np ? right : (rr ? zz.y : zz.x));
+      const int xm = (x > 0 && x < Np) ? N - x : -1;
+      for (int iz = 0; iz < 2; ++iz) {
+        const int zl = iz ? zm : zp;
+        if (zl < 0) continue;
+        for (int iy = 0; iy < 2; ++iy) {
+          const int yl = iy ? ym : yp;
+          if (yl < 0) continue;
+          double* row = phi + ((int64_t)zl * a.ny + yl) * N;
+          row[x] = v;
+          if (xm >= 0) row[xm] = v;
+        }
+      }
+    }
   }
 }
 
@@ -835,6 +1437,11 @@ int g_generic512 = 0;  // PFHIP_FFT3D_GENERIC512 = 1: 512-point columns by f3_co
 int g_cwg = 0;  // columns per workgroup of f3_col_kernel on 128- / 256-point axes: 0 = 8; PFHIP_FFT3D_CWG = 4 | 8
 int g_zearly = 0;  // z pass: request the resident spectrum before the forward FFT (PFHIP_FFT3D_ZEARLY = 0 | 1)
 int g_cw3 = 0;  // k_x columns per workgroup of the 3-D column passes: 0 = per pass (z: 4, y: 8), PFHIP_FFT3D_CW = 4 | 8 forces one
+int g_queue = 1;  // per-XCD work queues for the 512-point 3-D column passes: 0 = off, 1 = z passes (default), 2 = all (PFHIP_FFT3D_QUEUE)
+int g_row3 = 0;   // 3-D row pass form (PFHIP_FFT3D_ROWK): 0 = f2_row512_kernel<true>; 1 = <1,5>; 2 = <2,4>; 3 = <4,4>; 4 = persistent <1,4>;
+                  // 5 = persistent <1,5>; 6 = persistent <4,4>
+int g_cwy = 0;    // columns per workgroup of the y passes when set (PFHIP_FFT3D_CWY = 4 | 8)
+int g_qwgs = 0;   // persistent workgroups per CU in queue mode: 0 = what fits (PFHIP_FFT3D_QWGS)
 int g_cw512 = 1;  // columns per workgroup of the 2-D column kernel (PFHIP_FFT512_CW = 1 | 2 | 4): 13.05 / 14.3 / 17.5 us
 
 int ilog2(int n) {
@@ -845,8 +1452,30 @@ int ilog2(int n) {
 
 }  // namespace
 
+// n = product of radices 4, 2, 3, 5 (false if n has another prime factor)
+bool factor235(int n, Radices* out) {
+  Radices r;
+  while (n % 4 == 0 && r.n < 12) {
+    r.r[r.n++] = 4;
+    n /= 4;
+  }
+  for (int p : {2, 3, 5})
+    while (n % p == 0 && r.n < 12) {
+      r.r[r.n++] = p;
+      n /= p;
+    }
+  if (out) *out = r;
+  return n == 1;
+}
+bool smooth_axis(int n) { return n >= 8 && n <= 1024 && factor235(n, nullptr); }
+bool pow2_axis(int n) { return ilog2(n) >= 7 && ilog2(n) <= 10; }
+
 struct Fused2D {
   F2Args a;
+  bool mixed = false;  // some axis is not a power of two in 128..1024: every pass by the mixed-radix kernels (mx_*)
+  Radices rx, ry, rz;
+  double2 *twfx = nullptr, *twfy = nullptr, *twfz = nullptr;  // full-circle tables e^{-2 pi i k / n}, n entries (mx_* kernels)
+  size_t lds_mrow = 0;
   double2 *twx = nullptr, *twy = nullptr;
   double2 *tw8a = nullptr, *tw8b = nullptr;  // radix-8 tables of the 512-point fast path
   bool row512 = false, col512 = false;
@@ -858,20 +1487,35 @@ struct Fused2D {
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
   bool g_valid = false;  // G holds the row transform of f'(current c)
+  int* queues = nullptr;  // 2 sets x 8 per-XCD heads (XcdQueue), zero-initialised; launch n uses set n & 1
+  mutable unsigned qepoch = 0;
+  int ncu = 256;
 };
 
-bool fused2d_supported(int dim, int nx, int ny, int nz) {
+// 0: not here (library transforms); 1: power-of-two kernels (every axis 128, 256, 512 or 1024); 2: mixed-radix kernels
+// (every axis 8 .. 1024 with prime factors 2, 3, 5 only; rows are transformed in pairs: nx and ny even)
+int fused_path(int dim, int nx, int ny, int nz) {
   if (dim == 3) {
     const char* e = getenv("PFHIP_SPECTRAL_3D");  // "rocfft" forces the library path (A/B comparison)
-    if (e && std::string(e) == "rocfft") return false;
-    const int lx = ilog2(nx), ly = ilog2(ny), lz = ilog2(nz);
-    if (!(lx >= 7 && lx <= 10 && ly >= 7 && ly <= 10 && lz >= 7 && lz <= 10)) return false;
+    if (e && std::string(e) == "rocfft") return 0;
     // measured per step against the rocFFT path (profiles/r02/spectral3d_ab_sizes.log, bench_spectral_sizes.log):
     // 128^3 0.080 ms vs 0.088; 256^3 0.375 vs 0.567; 512^3 2.64 vs 3.5; 1024^3 24.9 vs 49.3
-    return true;
+    if (pow2_axis(nx) && pow2_axis(ny) && pow2_axis(nz)) return 1;
+    if (smooth_axis(nx) && smooth_axis(ny) && smooth_axis(nz) && nx % 2 == 0 && ny % 2 == 0) return 2;
+    return 0;
   }
-  const int lx = ilog2(nx), ly = ilog2(ny);
-  return dim == 2 && lx >= 7 && lx <= 10 && ly >= 7 && ly <= 10;
+  if (dim != 2) return 0;
+  if (pow2_axis(nx) && pow2_axis(ny)) return 1;
+  const char* e = getenv("PFHIP_SPECTRAL_MIXED");  // "0": sizes that are not powers of two stay on the library (A/B)
+  if (e && e[0] == '0') return 0;
+  return (smooth_axis(nx) && smooth_axis(ny) && nx % 2 == 0 && ny % 2 == 0) ? 2 : 0;
+}
+bool fused2d_supported(int dim, int nx, int ny, int nz) {
+  if (dim == 3) {
+    const char* e = getenv("PFHIP_SPECTRAL_MIXED");
+    if (e && e[0] == '0' && fused_path(dim, nx, ny, nz) == 2) return false;
+  }
+  return fused_path(dim, nx, ny, nz) != 0;
 }
 
 // Row pitch (complex elements) of every half-spectrum array this file touches.  2-D: nx/2 + 1, rocFFT's D2Z layout (the
@@ -889,7 +1533,35 @@ int fused_spectrum_pitch(int dim, int nx, int ny, int nz) {
   return nxh;
 }
 
-int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream) {
+// Layout of every half-spectrum array handed to fused2d_* / fused3d_poisson (spec_row): pitch, z-block, pad rows, and
+// the number of rows to allocate.  2-D and the slab-decomposed passes: plain.  PFHIP_FFT3D_PLANEPAD = pad rows per plane
+// (default 1, 0 for A/B), PFHIP_FFT3D_ZBLOCK = log2 z-block (default 0; 1..6 for A/B, with one pad row per group).
+SpecLayout fused_spectrum_layout(int dim, int nx, int ny, int nz) {
+  SpecLayout L;
+  L.pitch = fused_spectrum_pitch(dim, nx, ny, nz);
+  L.zb = 0;
+  L.nyp = ny;
+  L.bp = 1;
+  if (dim == 3 && fused2d_supported(dim, nx, ny, nz)) {
+    int pad = 0;
+    if (const char* e = getenv("PFHIP_FFT3D_PLANEPAD")) {
+      const int v = std::atoi(e);
+      if (v >= 0 && v <= 64) pad = v;
+    }
+    if (const char* e = getenv("PFHIP_FFT3D_ZBLOCK")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 6 && nz % (1 << v) == 0) L.zb = v;
+    }
+    if (L.zb)
+      L.bp = (1 << L.zb) + (pad ? 1 : 0);
+    else
+      L.nyp = ny + pad;
+  }
+  L.rows = dim == 3 ? (int64_t)(nz >> L.zb) * L.nyp * L.bp : (int64_t)ny;
+  return L;
+}
+
+int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t stream, int want_mx) {
   Fused2D* f = new Fused2D();
   *out = f;
   f->stream = stream;
@@ -901,6 +1573,12 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   a.ny = ny;
   a.nxh = nx / 2 + 1;
   a.pitch = fused_spectrum_pitch(nz > 1 ? 3 : 2, nx, ny, nz);
+  {
+    const SpecLayout L = fused_spectrum_layout(nz > 1 ? 3 : 2, nx, ny, nz);
+    a.zb = L.zb;
+    a.nyp = L.nyp;
+    a.bp = L.bp;
+  }
   a.lgx = ilog2(nx);
   a.lgy = ilog2(ny);
   a.kx0 = TWO_PI_F / (nx * h);
@@ -921,15 +1599,62 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     f->lgz = ilog2(nz);
     if (table(nz, &f->twz) != hipSuccess) return -3;
   }
+  f->mixed = fused_path(nz > 1 ? 3 : 2, nx, ny, nz) == 2;
+  if (f->mixed || nz == 1 || want_mx) {  // (2-D power-of-two grids too: their Poisson solve runs on the mixed-radix column kernel)
+    auto full = [&](int N, double2** dev) -> hipError_t {
+      std::vector<double2> t(N);
+      for (int k = 0; k < N; ++k) {
+        const double ang = TWO_PI_F * k / N;
+        t[k] = make_double2(std::cos(ang), -std::sin(ang));
+      }
+      hipError_t e = hipMalloc(dev, sizeof(double2) * t.size());
+      if (e != hipSuccess) return e;
+      return hipMemcpy(*dev, t.data(), sizeof(double2) * t.size(), hipMemcpyHostToDevice);
+    };
+    if (!factor235(nx, &f->rx) || !factor235(ny, &f->ry) || (nz > 1 && !factor235(nz, &f->rz))) return -3;
+    if (full(nx, &f->twfx) != hipSuccess || full(ny, &f->twfy) != hipSuccess ||
+        (nz > 1 && full(nz, &f->twfz) != hipSuccess))
+      return -3;
+    f->lds_mrow = sizeof(double2) * (size_t)(2 * (nx + 1) + nx);
+    const int nmax = ny > nz ? ny : nz;
+    const size_t lds_mcol = sizeof(double2) * (size_t)(MXC * 2 * (nmax + 1) + nmax);
+    auto big = [&](const void* k, size_t bytes) {
+      return bytes <= 64 * 1024 ||
+             hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    };
+    if (!big(reinterpret_cast<const void*>(mx_row_kernel), f->lds_mrow) ||
+        !big(reinterpret_cast<const void*>(dst_row_fwd_kernel), f->lds_mrow) ||
+        !big(reinterpret_cast<const void*>(dst_row_inv_kernel), f->lds_mrow) ||
+        !big(reinterpret_cast<const void*>(mx_col_kernel<0>), lds_mcol) ||
+        !big(reinterpret_cast<const void*>(mx_col_kernel<1>), lds_mcol) ||
+        !big(reinterpret_cast<const void*>(mx_col_kernel<2>), lds_mcol) ||
+        !big(reinterpret_cast<const void*>(mx_col_kernel<3>), lds_mcol) ||
+        !big(reinterpret_cast<const void*>(mx_col_kernel<4>), lds_mcol))
+      return -3;
+  }
   const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
   const bool allow8 = !(e && std::string(e) == "radix2");
   f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
   if (const char* rg = getenv("PFHIP_FFT3D_ROW"))  // "generic": 512-point rows of a 3-D box by f2_row_kernel (A/B)
     if (f->cube512 && std::string(rg) == "generic") f->row512 = false;
   f->col512 = (allow8 || f->cube512) && (ny == 512 || nz == 512);  // (3-D: "some column pass needs the radix-8 tables")
-  if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : 8;
+  if (f->mixed) f->row512 = f->col512 = false;
+  if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : (std::atoi(c3) == 8 ? 8 : 0);  // 0: per pass
   if (const char* ze = getenv("PFHIP_FFT3D_ZEARLY")) g_zearly = std::atoi(ze) != 0;
   if (const char* gg = getenv("PFHIP_FFT3D_GENERIC512")) g_generic512 = std::atoi(gg) != 0;
+  if (const char* q = getenv("PFHIP_FFT3D_QUEUE")) g_queue = std::atoi(q);
+  if (const char* q = getenv("PFHIP_FFT3D_ROWK")) g_row3 = std::atoi(q);
+  if (const char* q = getenv("PFHIP_FFT3D_CWY")) g_cwy = std::atoi(q) == 4 ? 4 : (std::atoi(q) == 8 ? 8 : 0);
+  if (const char* q = getenv("PFHIP_FFT3D_QWGS")) g_qwgs = std::atoi(q);
+  if (f->cube512) {
+    if (hipMalloc(&f->queues, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess ||
+        hipMemset(f->queues, 0, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess)
+      return -3;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      f->ncu = prop.multiProcessorCount;
+  }
   if (const char* cg = getenv("PFHIP_FFT3D_CWG")) {
     const int c = std::atoi(cg);
     g_cwg = (c == 4 || c == 8) ? c : 0;
@@ -985,11 +1710,15 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
 void fused2d_destroy(Fused2D* f) {
   if (!f) return;
   if (f->twz) (void)hipFree(f->twz);
+  if (f->twfx) (void)hipFree(f->twfx);
+  if (f->twfy) (void)hipFree(f->twfy);
+  if (f->twfz) (void)hipFree(f->twfz);
   if (f->twx) (void)hipFree(f->twx);
   if (f->twy) (void)hipFree(f->twy);
   if (f->tw8a) (void)hipFree(f->tw8a);
   if (f->tw8b) (void)hipFree(f->tw8b);
   if (f->sym) (void)hipFree(f->sym);
+  if (f->queues) (void)hipFree(f->queues);
   delete f;
 }
 
@@ -998,14 +1727,34 @@ void fused2d_invalidate(Fused2D* f) { f->g_valid = false; }
 namespace {
 void launch_row(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
                 int from_spectrum, int use_fprime) {
-  if (f->row512)
+  if (f->mixed)
+    hipLaunchKernelGGL(mx_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_mrow, f->stream, a, H, c_in, c_out, G,
+                       (const double2*)f->twfx, from_spectrum, use_fprime, f->rx);
+  else if (f->row512)
     hipLaunchKernelGGL(f2_row512_kernel<false>, dim3(a.ny / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
   else
     hipLaunchKernelGGL(f2_row_kernel, dim3(a.ny / 2), dim3(RT), f->lds_row, f->stream, a, H, c_in, c_out, G,
                        (const double2*)f->twx, from_spectrum, use_fprime);
 }
+// 2-D column pass by the mixed-radix kernel: one batch, rows one pitch apart
+template <int MODE>
+void launch_mx_col2d(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H) {
+  ColMap m;
+  m.rstride = a.pitch;
+  const int nblk = (a.nxh + MXC - 1) / MXC;
+  const size_t lds = sizeof(double2) * (size_t)(MXC * 2 * (a.ny + 1) + a.ny);
+  hipLaunchKernelGGL(mx_col_kernel<MODE>, dim3(nblk), dim3(MXC * MXG), lds, f->stream, a, A, chat, H, m, ColMap(), 0, nblk,
+                     a.ny, (const double2*)f->twfy, f->ry, 1, 0);
+}
 void launch_col(const Fused2D* f, const F2Args& a, const double2* G, double2* chat, double2* H, int init_only) {
+  if (f->mixed) {
+    if (init_only)
+      launch_mx_col2d<3>(f, a, const_cast<double2*>(G), chat, nullptr);
+    else
+      launch_mx_col2d<2>(f, a, const_cast<double2*>(G), chat, H);
+    return;
+  }
   if (f->col512 && g_cw512 == 4)
     hipLaunchKernelGGL(f2_col512_direct_kernel<4>, dim3((a.nxh + 3) / 4), dim3(256), 0, f->stream, a, G, chat, H,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
@@ -1025,7 +1774,47 @@ namespace {
 // 3-D passes (512^3).  Rows: f2_row512_kernel over ny*nz/2 row pairs (its row index is the flattened (z, y) index).
 void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
                  int from_spectrum, int use_fprime) {
-  if (f->row512)
+  if (f->mixed) {
+    hipLaunchKernelGGL(mx_row_kernel, dim3(a.ny * a.nz / 2), dim3(RT), f->lds_mrow, f->stream, a, H, c_in, c_out, G,
+                       (const double2*)f->twfx, from_spectrum, use_fprime, f->rx);
+    return;
+  }
+  if (f->row512 && (g_row3 == 7 || g_row3 == 8) && from_spectrum == 1 && use_fprime) {
+    const int npairs = a.ny * a.nz / 2;
+    const int wpc = g_qwgs > 0 ? g_qwgs : (g_row3 == 7 ? 12 : 8);   // persistent one-wave workgroups per CU
+    const int grid = f->ncu * wpc < npairs ? f->ncu * wpc : npairs;
+    if (g_row3 == 7)
+      hipLaunchKernelGGL(f3_row512p_kernel<3>, dim3(grid), dim3(64), 0, f->stream, a, H, c_out, G, (const double2*)f->tw8a,
+                         (const double2*)f->tw8b, npairs);
+    else
+      hipLaunchKernelGGL(f3_row512p_kernel<2>, dim3(grid), dim3(64), 0, f->stream, a, H, c_out, G, (const double2*)f->tw8a,
+                         (const double2*)f->tw8b, npairs);
+    return;
+  }
+  if (f->row512 && g_row3 > 0 && g_row3 < 7 && f->queues) {
+    const int npairs = a.ny * a.nz / 2;
+    int* qset = nullptr;
+    int* qother = nullptr;
+    if (g_row3 >= 4) {  // only a launch that really pops (and zeroes the other set) may take an epoch
+      const unsigned e = f->qepoch++;
+      qset = f->queues + (e & 1) * 8 * QSTRIDE;
+      qother = f->queues + ((e + 1) & 1) * 8 * QSTRIDE;
+    }
+    const double2 *ta = f->tw8a, *tb = f->tw8b;
+#define PF_ROW3(RWT, MINW, PERS, GRID)                                                                                \
+  hipLaunchKernelGGL((f3_row512_kernel<RWT, MINW, PERS>), dim3(GRID), dim3(64 * RWT), 0, f->stream, a, H, c_in, c_out, G, ta, \
+                     tb, from_spectrum, use_fprime, npairs, qset, qother)
+    const int wpc = g_qwgs > 0 ? g_qwgs : 16;  // persistent waves per CU
+    switch (g_row3) {
+      case 1: PF_ROW3(1, 5, false, npairs); break;
+      case 2: PF_ROW3(2, 4, false, npairs / 2); break;
+      case 3: PF_ROW3(4, 4, false, npairs / 4); break;
+      case 4: PF_ROW3(1, 4, true, f->ncu * wpc); break;
+      case 5: PF_ROW3(1, 5, true, f->ncu * (g_qwgs > 0 ? g_qwgs : 17)); break;
+      default: PF_ROW3(4, 4, true, f->ncu * wpc / 4); break;
+    }
+#undef PF_ROW3
+  } else if (f->row512)
     hipLaunchKernelGGL(f2_row512_kernel<true>, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
   else
@@ -1036,20 +1825,36 @@ void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const doub
 struct ColGeom {
   int N, lg;
   const double2* tw;
-  int64_t col_stride, batch_stride;
+  ColMap mn, ms;  // natural side / the other side of the slab-decomposed passes (spon)
+  int spon = 0;
   int nbatch;
-  ColSplit sp;
+  const double2* twf = nullptr;  // mixed-radix path: full-circle table and radices of this axis
+  Radices rd;
 };
 ColGeom axis_geom(const Fused2D* f, const F2Args& a, int axis) {
-  const int64_t row = a.pitch, plane = (int64_t)a.pitch * a.ny;
+  const int64_t row = a.pitch;
   ColGeom g;
-  // axis 1: columns along y (stride one x-row), one batch per z-plane; axis 2: columns along z, one batch per y-row
+  // axis 1: columns along y, one batch per z-plane; axis 2: columns along z, one batch per y-row -- addresses = spec_row()
   g.N = axis == 1 ? a.ny : a.nz;
   g.lg = axis == 1 ? a.lgy : f->lgz;
   g.tw = axis == 1 ? f->twy : f->twz;
-  g.col_stride = axis == 1 ? row : plane;
-  g.batch_stride = axis == 1 ? plane : row;
   g.nbatch = axis == 1 ? a.nz : a.ny;
+  g.twf = axis == 1 ? f->twfy : f->twfz;
+  g.rd = axis == 1 ? f->ry : f->rz;
+  const int64_t grp = row * a.bp, plane_grp = grp * a.nyp;  // one (y, z-block) group of rows; one z-block of planes
+  ColMap m;
+  if (axis == 1) {  // r = y, b = z
+    m.rstride = grp;
+    m.lb = a.zb ? a.zb : 31;
+    m.bchunk = a.zb ? plane_grp : 0;
+    m.bstride = a.zb ? row : plane_grp;
+  } else {  // r = z, b = y
+    m.lr = a.zb ? a.zb : 31;
+    m.rchunk = a.zb ? plane_grp : 0;
+    m.rstride = a.zb ? row : plane_grp;
+    m.bstride = grp;
+  }
+  g.mn = m;
   return g;
 }
 template <int MODE, int CWG, int G, int NMAX>
@@ -1057,22 +1862,42 @@ void launch_col3_g(const Fused2D* f, const F2Args& a, double2* A, double2* chat,
   const int nblk = (a.nxh + CWG - 1) / CWG;
   const size_t lds = sizeof(double2) * ((size_t)CWG * (g.N + g.N / 32 + 1) + g.N / 2);
   hipLaunchKernelGGL((f3_col_kernel<MODE, CWG, G, NMAX>), dim3(nblk * g.nbatch), dim3(G * CWG), lds, f->stream, a, A, chat,
-                     H, g.col_stride, g.batch_stride, nblk, nblk * g.nbatch, g.N, g.lg, g.tw, g.sp);
+                     H, g.mn, g.ms, g.spon, nblk, nblk * g.nbatch, g.N, g.lg, g.tw);
 }
 template <int MODE, int CW3>
 void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
   const int nblk = (a.nxh + CW3 - 1) / CW3;
   const int nitems = nblk * g.nbatch;
+  const bool zpass = MODE == 2 || MODE == 3 || MODE == 4;
+  const bool queued = f->queues && (g_queue >= 2 || (g_queue == 1 && zpass));
+  int* qset = nullptr;
+  int* qother = nullptr;
+  int grid = nitems;
+  if (queued) {
+    const unsigned e = f->qepoch++;
+    qset = f->queues + (e & 1) * 8 * QSTRIDE;
+    qother = f->queues + ((e + 1) & 1) * 8 * QSTRIDE;
+    // persistent workgroups: what the CU holds at 4 waves per SIMD (<= 128 VGPRs) and ~39 KB of LDS per 4 columns
+    const int per_cu = g_qwgs > 0 ? g_qwgs : 16 / CW3;
+    grid = f->ncu * per_cu < nitems ? f->ncu * per_cu : nitems;
+  }
   if (MODE == 2 && g_zearly)
-    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, true>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                       g.col_stride, g.batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, g.sp);
+    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, true>), dim3(grid), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
+                       g.mn, g.ms, g.spon, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, qset, qother);
   else
-    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, false>), dim3(nitems), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                       g.col_stride, g.batch_stride, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, g.sp);
+    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, false>), dim3(grid), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
+                       g.mn, g.ms, g.spon, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, qset, qother);
 }
 template <int MODE>
 void launch_col3_geom(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
   const int N = g.N;
+  if (f->mixed) {
+    const int nblk = (a.nxh + MXC - 1) / MXC;
+    const size_t lds = sizeof(double2) * (size_t)(MXC * 2 * (N + 1) + N);
+    hipLaunchKernelGGL(mx_col_kernel<MODE>, dim3(nblk * g.nbatch), dim3(MXC * MXG), lds, f->stream, a, A, chat, H, g.mn, g.ms,
+                       g.spon, nblk, N, g.twf, g.rd, 0, 0);
+    return;
+  }
   if (N != 512 || g_generic512) {
     if (N == 512) {
       if (g_cwg == 4)
@@ -1091,9 +1916,12 @@ void launch_col3_geom(const Fused2D* f, const F2Args& a, double2* A, double2* ch
       launch_col3_g<MODE, 4, 64, 256>(f, a, A, chat, H, g);
     return;
   }
-  // measured after the aligned pitch (rocprofv3, 512^3): z pass 999 us with 4 columns per workgroup (4 workgroups of 4
-  // waves per CU) vs 1073 us with 8; y passes 441-452 us with 8 vs 466-471 us with 4
-  const int cw = g_cw3 ? g_cw3 : ((MODE == 2 || MODE == 4 || MODE == 3) ? 4 : 8);
+  // columns per workgroup: 8 = one full 128-byte line per row on every pass.  (Round 2 ran the z pass with 4 -- four
+  // independent workgroups per CU instead of two, 999 vs 1073 us then -- at the price of half-line requests that the L2s
+  // fetched 1.57x; with the round-3 changes 8 is the faster form on every box measured: 964-1028 vs 1008-1081 us under
+  // rocprofv3, 2.68 vs 2.74 ms per step in one process, profiles/r03.  PFHIP_FFT3D_CW = 4 | 8 forces one width.)
+  int cw = g_cw3 ? g_cw3 : 8;
+  if (g_cwy && (MODE == 0 || MODE == 1)) cw = g_cwy;
   if (cw == 4)
     launch_col3_t<MODE, 4>(f, a, A, chat, H, g);
   else
@@ -1107,20 +1935,89 @@ void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, d
 
 // 512^3 periodic Poisson solve lap_h(phi) = -(k/eps) c with the same passes: x forward, y forward, z (forward, divide
 // by the Laplacian's eigenvalue, inverse), y inverse, x inverse only.  W: nh complex work array.
-int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2) {
-  if (!f->cube512) return -3;
-  if (!f->sym) {
-    const int nn[3] = {f->a.nx, f->a.ny, f->a.nz};
-    std::vector<double> t;
-    for (int d = 0; d < 3; ++d)
-      for (int m = 0; m < nn[d]; ++m) t.push_back(2.0 * std::cos(TWO_PI_F * m / nn[d]) - 2.0);
-    if (hipMalloc(&f->sym, sizeof(double) * t.size()) != hipSuccess ||
-        hipMemcpy(f->sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice) != hipSuccess)
-      return -3;
+namespace {
+// 2 cos(2 pi m / n) - 2 for the x, y and z axis back to back: the eigenvalues of the 5- / 7-point Laplacian (times h^2)
+int ensure_sym(Fused2D* f) {
+  if (f->sym) return 0;
+  const int nn[3] = {f->a.nx, f->a.ny, f->a.nz};
+  std::vector<double> t;
+  for (int d = 0; d < 3; ++d)
+    for (int m = 0; m < nn[d]; ++m) t.push_back(2.0 * std::cos(TWO_PI_F * m / nn[d]) - 2.0);
+  if (hipMalloc(&f->sym, sizeof(double) * t.size()) != hipSuccess ||
+      hipMemcpy(f->sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return -3;
+  return 0;
+}
+}  // namespace
+
+// Lattices (2 (np - 1) points per axis) the sine / cosine solver below can run on
+bool fused_dirichlet_supported(int dim, int nx, int ny, int nz) {
+  const char* e = getenv("PFHIP_POISSON_DIRICHLET");  // "rocfft": the round-2 solver (library transforms of the extension)
+  if (e && std::string(e) == "rocfft") return false;
+  return smooth_axis(nx) && smooth_axis(ny) && (dim == 2 || smooth_axis(nz)) && nx % 2 == 0 && ny % 2 == 0 &&
+         (dim == 2 || nz % 2 == 0);
+}
+int64_t fused_dirichlet_work_doubles(int npx, int npy, int npz) { return (int64_t)((npx + 1) / 2 * 2) * npy * npz; }
+
+// phi (whole lattice) <- solution of the reference's BM6 Poisson problem for c (lattice, even extension); S: work array
+// of fused_dirichlet_work_doubles().  f: created for the LATTICE sizes with want_mx = 1.
+int fused_poisson_dirichlet(Fused2D* f, const double* c, double* phi, double* S, int npx, int npy, int npz, double h,
+                            double k_over_eps) {
+  if (ensure_sym(f) != 0) return -3;
+  const F2Args& a = f->a;
+  DirGeom g;
+  g.npx = npx;
+  g.npy = npy;
+  g.npz = npz;
+  g.spitch = (npx + 1) / 2 * 2;
+  g.h = h;
+  g.k_over_eps = k_over_eps;
+  g.inv_h2 = 1.0 / (h * h);
+  const int nrows = npy * npz, grid = (nrows + 1) / 2;
+  hipLaunchKernelGGL(dst_row_fwd_kernel, dim3(grid), dim3(RT), f->lds_mrow, f->stream, a, g, c, S, (const double2*)f->twfx, f->rx);
+  F2Args ac = a;                 // the cosine passes read S as complex: one element = two real k_x columns
+  const int spc = g.spitch / 2;
+  ac.nxh = spc;
+  ac.dtM = g.inv_h2;
+  ac.dtMkappa = 1.0;
+  double2* Sc = reinterpret_cast<double2*>(S);
+  double2* sym = reinterpret_cast<double2*>(f->sym);
+  const int nblk = (spc + MXC - 1) / MXC;
+  auto lds = [](int N) { return sizeof(double2) * (size_t)(MXC * 2 * (N + 1) + N); };
+  if (npz == 1) {
+    ColMap m;
+    m.rstride = spc;
+    hipLaunchKernelGGL(mx_col_kernel<4>, dim3(nblk), dim3(MXC * MXG), lds(a.ny), f->stream, ac, Sc, sym, nullptr, m, ColMap(), 0,
+                       nblk, a.ny, (const double2*)f->twfy, f->ry, 1, 1);
+  } else {
+    ColMap my, mz;
+    my.rstride = spc;                     // y columns: r = yp, one batch per physical plane
+    my.bstride = (int64_t)npy * spc;
+    mz.rstride = (int64_t)npy * spc;      // z columns: r = zp, one batch per k_y
+    mz.bstride = spc;
+    hipLaunchKernelGGL(mx_col_kernel<0>, dim3(nblk * npz), dim3(MXC * MXG), lds(a.ny), f->stream, ac, Sc, nullptr, nullptr, my,
+                       ColMap(), 0, nblk, a.ny, (const double2*)f->twfy, f->ry, 0, 1);
+    hipLaunchKernelGGL(mx_col_kernel<4>, dim3(nblk * npy), dim3(MXC * MXG), lds(a.nz), f->stream, ac, Sc, sym, nullptr, mz,
+                       ColMap(), 0, nblk, a.nz, (const double2*)f->twfz, f->rz, 0, 1);
+    hipLaunchKernelGGL(mx_col_kernel<1>, dim3(nblk * npz), dim3(MXC * MXG), lds(a.ny), f->stream, ac, Sc, nullptr, nullptr, my,
+                       ColMap(), 0, nblk, a.ny, (const double2*)f->twfy, f->ry, 0, 1);
   }
+  hipLaunchKernelGGL(dst_row_inv_kernel, dim3(grid), dim3(RT), f->lds_mrow, f->stream, a, g, (const double*)S, phi,
+                     (const double2*)f->twfx, f->rx);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2) {
+  if (ensure_sym(f) != 0) return -3;
   F2Args a = f->a;
   a.dtM = inv_h2;
   a.dtMkappa = -k_over_eps;
+  if (!f->cube512) {  // 2-D periodic box: x forward, y (forward, divide, inverse) by the mixed-radix column kernel, x inverse
+    launch_row(f, a, nullptr, c, nullptr, W, 0, 0);
+    launch_mx_col2d<4>(f, a, W, reinterpret_cast<double2*>(f->sym), nullptr);
+    launch_row(f, a, W, nullptr, phi, nullptr, 2, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   launch_row3(f, a, nullptr, c, nullptr, W, 0, 0);
   launch_col3<0>(f, a, W, nullptr, nullptr, 1);
   launch_col3<4>(f, a, W, reinterpret_cast<double2*>(f->sym), nullptr, 2);
@@ -1179,16 +2076,17 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
 // The local passes of a rank that owns nzl z-planes for the x and y transforms and, after the all-to-all, nyl = ny / P
 // y-rows of every z-plane for the z transform ("T" layout [z][yq][kx]).  Every spectrum array uses the padded pitch.
 bool fusedslab_supported(int nx, int ny, int nz, int P) {
-  return P >= 1 && ny % P == 0 && nz % P == 0 && ilog2(P) >= 0 && fused2d_supported(3, nx, ny, nz);
+  return P >= 1 && ny % P == 0 && nz % P == 0 && ilog2(P) >= 0 && ilog2(ny / P) >= 0 && fused2d_supported(3, nx, ny, nz);
 }
 namespace {
 ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
-  ColGeom g = axis_geom(f, a, 1);  // a.nz == nzl: one batch per local plane
+  ColGeom g = axis_geom(f, a, 1);  // a.nz == nzl: one batch per local plane (plain layout: a.zb == 0)
   const int nyl = a.ny / P;
-  g.sp.on = on;
-  g.sp.lg = ilog2(nyl);
-  g.sp.chunk = (int64_t)nzl * nyl * a.pitch;
-  g.sp.bstride = (int64_t)nyl * a.pitch;
+  g.spon = on;
+  g.ms.lr = ilog2(nyl);            // element r of a column goes to chunk r / nyl of the all-to-all layout
+  g.ms.rchunk = (int64_t)nzl * nyl * a.pitch;
+  g.ms.rstride = a.pitch;
+  g.ms.bstride = (int64_t)nyl * a.pitch;
   return g;
 }
 }  // namespace
@@ -1196,6 +2094,9 @@ ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
 int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double2* A, int nzl, int P, int use_fprime,
                          double ca, double cb, double two_rho) {
   F2Args a = f->a;
+  a.zb = 0;  // slab-decomposed passes: plain layouts
+  a.nyp = a.ny;
+  a.bp = 1;
   a.nz = nzl;
   a.ca = ca;
   a.cb = cb;
@@ -1207,6 +2108,9 @@ int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double
 // A [q][zl][yq][kx] -> inverse y columns -> tmp [zl][y][kx] -> inverse x rows -> real planes
 int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out, int nzl, int P) {
   F2Args a = f->a;
+  a.zb = 0;  // slab-decomposed passes: plain layouts
+  a.nyp = a.ny;
+  a.bp = 1;
   a.nz = nzl;
   launch_col3_geom<1>(f, a, A, nullptr, tmp, slab_y_geom(f, a, nzl, P, 2));
   launch_row3(f, a, tmp, nullptr, real_out, nullptr, 2, 0);
@@ -1216,6 +2120,9 @@ int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out,
 // (unnormalised); 2: forward -> k-space update of the resident chat -> inverse of chat / N; 3: forward, stored to chat.
 int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa) {
   F2Args a = f->a;
+  a.zb = 0;  // slab-decomposed passes: plain layouts
+  a.nyp = a.ny;
+  a.bp = 1;
   a.yoff = yoff;
   a.dtM = dtM;
   a.dtMkappa = dtMkappa;
@@ -1224,8 +2131,10 @@ int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yo
   g.N = a.nz;
   g.lg = f->lgz;
   g.tw = f->twz;
-  g.col_stride = (int64_t)nyl * a.pitch;
-  g.batch_stride = a.pitch;
+  g.mn.rstride = (int64_t)nyl * a.pitch;
+  g.mn.bstride = a.pitch;
+  g.twf = f->twfz;
+  g.rd = f->rz;
   g.nbatch = nyl;
   if (mode == 0)
     launch_col3_geom<0>(f, a, B, nullptr, nullptr, g);

@@ -135,7 +135,10 @@ def run_fem_be(bench="bench1", controller="fixture", end_time=None, out_dir="res
     # Newton cap: the reference's 10 (bench1.py:88) under its own controller; the committed time grid with exact linear
     # solves needs up to 24 plain Newton iterations (rows 21, 37), so the fixture controller lifts the cap
     with PhaseFieldSolver(dim=2, n=N + 1, h=L / N, bc="mirror", scheme="fem_be", model=model,
-                          device=device, max_newton=100 if controller == "fixture" else 10) as s:
+                          device=device, max_newton=100 if controller == "fixture" else 10,
+                          # the reference's dt rule reads the Newton iteration count (bench1.py:180-183): under it every
+                          # factorisation pivots, so the time grid never depends on the optimistic un-pivoted solve
+                          always_pivot=(controller == "reference")) as s:
         {"bm1": s.set_ic_bm1, "bm6": s.set_ic_bm6, "bm2": s.set_ic_bm2, "bm3": s.set_ic_bm3}[model]()
         if controller == "fixture":
             times = report_times(bench)

@@ -17,6 +17,8 @@ PF_FIELD_C, PF_FIELD_MU, PF_FIELD_PHI, PF_FIELD_ETA1, PF_FIELD_U = 0, 1, 2, 3, 7
 PF_KERNEL_AUTO, PF_KERNEL_FUSED, PF_KERNEL_TWOPASS = 0, 1, 2
 PF_FLAG_BM6_ELIMINATE_PHI = 1
 PF_FLAG_WIDE_HALO = 2
+PF_FLAG_FEM_ALWAYS_PIVOT = 4
+PF_STAT_FEM_ATTEMPTS, PF_STAT_FEM_NPVT_LEVELS = 0, 1
 
 
 class PfConfig(C.Structure):
@@ -93,9 +95,11 @@ SYMBOLS = {
     "pf_halo_layout_get": (C.c_int, [_H, C.POINTER(PfHaloLayout)]),
     "pf_step_begin": (C.c_int, [_H, C.c_double]),
     "pf_step_finish": (C.c_int, [_H]),
+    "pf_set_strip_stream": (C.c_int, [_H, C.c_void_p]),
     "pf_step_slab_fused": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pf_diagnostics": (C.c_int, [_H, _D]),
     "pf_diagnostics_local": (C.c_int, [_H, _D]),
+    "pf_get_stat": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int64)]),
     "pf_timing_enable": (C.c_int, [_H, C.c_int]),
     "pf_timing_read": (C.c_int, [_H, _D, C.POINTER(C.c_int64)]),
     "pf_timing_samples": (C.c_int, [_H, _D, _D, C.c_int64, C.POINTER(C.c_int64)]),
@@ -110,6 +114,7 @@ SYMBOLS = {
     "pfk_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "pfk_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pfk_grid_barrier_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
+    "pfk_xcd_barrier_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _D, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pfk_push_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pfk_signal_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "pfk_wait_flag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

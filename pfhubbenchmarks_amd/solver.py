@@ -20,6 +20,29 @@ import numpy as np
 from . import lib as _lib
 
 
+class _roctx:
+    """roctx range (rocprofv3 --marker-trace) around host-side phases; a no-op without torch / a GPU"""
+
+    def __init__(self, name):
+        self.name = name
+        self.on = False
+
+    def __enter__(self):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.nvtx.range_push(self.name)      # roctxRangePush on ROCm builds
+                self.on = True
+        except Exception:
+            self.on = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            import torch
+            torch.cuda.nvtx.range_pop()
+
+
 def stable_dt(h, M=5.0, kappa=2.0, dim=2, safety=0.5):
     """Forward-Euler limit of the fused FD step: the stiffest mode of dt*M*kappa*lap_h^2 is (4 dim / h^2)^2,
     so dt < 2 h^4 / (16 dim^2 M kappa); `safety` scales it (the f'' term moves the limit slightly)."""
@@ -30,7 +53,7 @@ class PhaseFieldSolver:
     """Single-GPU solver handle (pf_create .. pf_destroy)."""
 
     def __init__(self, dim=2, n=512, h=1.0, bc="periodic", scheme="fd", model="bm1", kernel="auto", device=0,
-                 stream=None, eliminate_phi=False, **params):
+                 stream=None, eliminate_phi=False, always_pivot=False, **params):
         self._lib = _lib.load()
         n3 = list(n) if isinstance(n, (tuple, list)) else [n] * dim
         cfg = _lib.default_config(dim, int(n3[0]), float(h))
@@ -48,6 +71,8 @@ class PhaseFieldSolver:
         cfg.device = int(device)
         if eliminate_phi:
             cfg.flags |= _lib.PF_FLAG_BM6_ELIMINATE_PHI
+        if always_pivot:        # fem_be: row exchanges in every dense factorisation (pfhip.h PF_FLAG_FEM_ALWAYS_PIVOT)
+            cfg.flags |= _lib.PF_FLAG_FEM_ALWAYS_PIVOT
         for k, v in params.items():
             if k == "model_params":
                 for i, x in enumerate(v):
@@ -114,6 +139,12 @@ class PhaseFieldSolver:
         """InitialConditionsBench3 (dolfin/bench3.py:52-57, pfbase.py:298-320)"""
         self._ck(self._lib.pf_set_ic_bm3(self._h, r, w, vin, vout))
         self.t = 0.0
+
+    def stat(self, key):
+        """pf_get_stat: counters of the last step (lib.PF_STAT_*; fem_be scheme)"""
+        v = C.c_int64(0)
+        self._ck(self._lib.pf_get_stat(self._h, int(key), C.byref(v)))
+        return int(v.value)
 
     FIELD_IDS = {"c": _lib.PF_FIELD_C, "mu": _lib.PF_FIELD_MU, "phi": _lib.PF_FIELD_PHI, "U": _lib.PF_FIELD_U,
                  "eta1": _lib.PF_FIELD_ETA1, "eta2": _lib.PF_FIELD_ETA1 + 1, "eta3": _lib.PF_FIELD_ETA1 + 2,
@@ -266,6 +297,7 @@ class HipSlabEngine:
         self._block, self.buffers = _placed_buffers(torch, self._lib, cfg, (self.nz + 2 * self.ghost, ly, lx),
                                                     self.device)
         self.stream = torch.cuda.Stream(device=self.device)
+        self.strip_stream = None
         cfg.stream = C.c_void_p(self.stream.cuda_stream)
         cfg.ext_c[0] = C.c_void_p(self.buffers[0].data_ptr())
         cfg.ext_c[1] = C.c_void_p(self.buffers[1].data_ptr())
@@ -325,6 +357,14 @@ class HipSlabEngine:
 
     def step_finish(self):
         self._ck(self._lib.pf_step_finish(self._h))
+
+    def use_strip_stream(self, on=True):
+        """boundary strips of pf_step_finish on a stream of their own (pf_set_strip_stream); SlabSolver orders the two"""
+        if on and self.strip_stream is None:
+            self.strip_stream = self.torch.cuda.Stream(device=self.device)
+        self._ck(self._lib.pf_set_strip_stream(self._h, C.c_void_p(self.strip_stream.cuda_stream) if on else None))
+        if not on:
+            self.strip_stream = None
 
     def step_fused(self, dt, flags, seq, timeout):
         """one step in one launch; the boundary-strip workgroups poll flags[0] / flags[1] (int64 device tensor) for seq"""
@@ -521,6 +561,7 @@ class SlabSolver:
         if fused and getattr(engine, "wide", False):
             raise ValueError("SlabSolver(fused=True) works on 2 ghost planes; the wide halo uses the two-launch step")
         self.fused = bool(fused)
+        self._ev_strips = None
 
     def _host_ordered(self):
         """RCCL collectives are ordered after the kernels already queued on the current stream.  Any other backend
@@ -534,6 +575,10 @@ class SlabSolver:
         if self.transport is not None:
             return self.transport.post()
         self._host_ordered()
+        with _roctx("halo exchange (post isend/irecv)"):
+            return self._post_exchange_rccl()
+
+    def _post_exchange_rccl(self):
         dist, e = self.dist, self.engine
         g, nz = e.ghost, e.nz
         buf = e.buffers[e.cur]
@@ -571,7 +616,31 @@ class SlabSolver:
                 e.step_fused(dt, tr.flags, tr.seq, tr.timeout)
             self.ghosts_fresh = False
             self.t += dt
+        s2 = getattr(e, "strip_stream", None) if self.transport is None else None
         for _ in range(0 if self.fused else nsteps):
+            if s2 is not None:
+                # boundary strips on their own stream: interior launch (compute stream) || [exchange -> strips (strip stream)];
+                # the compute stream rejoins before the next exchange is posted -- the exchange wait and the strips leave
+                # the critical path (on one GPU the RCCL self-copy ends with the interior launch; across xGMI it ends early)
+                torch = e.torch
+                with e.stream_context():
+                    if self._ev_strips is not None:
+                        e.stream.wait_event(self._ev_strips)      # strips of the previous step: they wrote planes we send / read
+                        self._ev_strips = None
+                    reqs = [] if (self.ghosts_fresh or (need is not None and not need())) else self._post_exchange()
+                    ev_start = torch.cuda.Event()
+                    ev_start.record(e.stream)                     # everything that read the output buffer is before this
+                    e.step_begin(dt)
+                with torch.cuda.stream(s2):
+                    s2.wait_event(ev_start)
+                    for r in reqs:
+                        r.wait()                                  # the strip stream (not the compute stream) waits for RCCL
+                    e.step_finish()
+                    self._ev_strips = torch.cuda.Event()
+                    self._ev_strips.record(s2)
+                self.ghosts_fresh = False
+                self.t += dt
+                continue
             with e.stream_context():
                 # wide-halo engines read their ghost planes every second step only (PF_FLAG_WIDE_HALO)
                 reqs = [] if (self.ghosts_fresh or (need is not None and not need())) else self._post_exchange()
@@ -581,6 +650,9 @@ class SlabSolver:
                 e.step_finish()
             self.ghosts_fresh = False
             self.t += dt
+        if s2 is not None and self._ev_strips is not None:       # leave the compute stream ordered behind the last strips
+            e.stream.wait_event(self._ev_strips)
+            self._ev_strips = None
         if self.transport is not None:
             self.transport.check()           # non-blocking (mapped host word): any wait that has already given up
 

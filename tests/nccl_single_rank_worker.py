@@ -45,10 +45,14 @@ def main():
     print("FD slab path over NCCL: ok", flush=True)
 
     # --- the same with PF_FLAG_WIDE_HALO (4 ghost planes every second step) through SlabSolver over RCCL, incl. a step
-    # right after diagnostics and the no-flux line with both walls on this rank
-    for bc, nn in (("periodic", n), ("mirror", (65, 17, 12))):
+    # right after diagnostics and the no-flux line with both walls on this rank; and with the boundary strips on a stream
+    # of their own (pf_set_strip_stream: interior || exchange -> strips), narrow and wide halo
+    for bc, nn, wide, side in (("periodic", n, True, False), ("mirror", (65, 17, 12), True, False),
+                               ("periodic", n, False, True), ("periodic", n, True, True), ("mirror", (65, 17, 12), True, True)):
         fw = 0.5 + 0.05 * rng.standard_normal(nn[::-1])
-        eng = HipSlabEngine(nn, 1.0, 1, 0, 0, bc=bc, wide=True)
+        eng = HipSlabEngine(nn, 1.0, 1, 0, 0, bc=bc, wide=wide)
+        if side:
+            eng.use_strip_stream()
         eng.set_local(fw)
         s = SlabSolver(eng)
         with PhaseFieldSolver(dim=3, n=nn, h=1.0, bc=bc) as ref:
@@ -60,9 +64,9 @@ def main():
             s.step(1e-3, 4)
             ref.step(1e-3, 4)
             eng.sync()
-            assert np.array_equal(s.gather_field(), ref.get_c()), "wide-halo slab path differs (%s)" % bc
+            assert np.array_equal(s.gather_field(), ref.get_c()), "slab path differs (%s wide=%s strips-on-side-stream=%s)" % (bc, wide, side)
         eng.close()
-    print("wide-halo slab path over NCCL: ok", flush=True)
+    print("wide-halo slab path and strip stream over NCCL: ok", flush=True)
 
     # --- BASELINE.json config 4's per-GPU shape: one 1024 x 1024 x 128 slab of the 1024^3 box over 8 GPUs (8 MiB planes,
     # 16 MiB ghost messages, 32-bit in-plane offsets at their largest) on the production path, against the plain

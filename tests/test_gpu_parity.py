@@ -364,13 +364,16 @@ def test_full_size_properties_1024cubed(lib):
 
 @pytest.mark.parametrize("shape", [(512, 512), (128, 256), (1024, 128), (256, 512), (512, 128), (96, 40), (34, 18, 10),
                                    (64, 64, 64), (128, 128, 128), (256, 128, 512), (128, 512, 256), (1024, 128, 128),
-                                   (128, 128, 1024), (128, 1024, 128)])
+                                   (128, 128, 1024), (128, 1024, 128), (200, 200), (400, 400), (40, 96, 200), (9, 12, 30),
+                                   (1000, 8), (250, 1024, 16)])
 def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
     """BASELINE.json config 2 (512^2 semi-implicit spectral) vs the pocketfft oracle, 1e-11 relative: 2-D power-of-two
     shapes take the fused LDS-FFT path (csrc/spectral2d_fused.hip: one-wave radix-8 kernels on 512-point axes -- (256, 512)
     and (512, 128) pair one of them with the generic radix-2^2 kernel of the other axis); 3-D boxes whose axes are all
     powers of two in 128..1024 take the hand-written 4-pass path too (every axis length on every axis: 128, 256, 512 and
-    1024 along x, y and z); everything else rocFFT."""
+    1024 along x, y and z); axes that factor into 2, 3 and 5 (8..1024 points: the reference's 200- and 400-point lattices,
+    40 x 96, 64^3, 200 x 96 x 40, 30 x 12 x 9, 8 x 1000, 16 x 1024 x 250) the mixed-radix Stockham kernels (mx_row_kernel /
+    mx_col_kernel); only (10, 18, 34), with its factor 17, goes to the library (rocFFT through its native API)."""
     from oracle import ch_spectral
     dim = len(shape)
     n = shape[::-1]                      # (nx, ny[, nz])
@@ -404,7 +407,8 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
 
 
-@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10), (128, 128, 128), (256, 128, 512)])
+@pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10), (128, 128, 128), (256, 128, 512),
+                                   (200, 400), (20, 24, 50)])
 def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
     """BM6 with the semi-implicit spectral scheme in a periodic box: phi eliminated in Fourier space (one more implicit
     term in the k-space update, every kernel form: radix-8 LDS FFT, radix-2^2 LDS FFT, rocFFT 2-D and 3-D), f_elec by
@@ -583,16 +587,56 @@ def test_bm6_reference_boundary_conditions(lib, golden_dir):
         assert abs(C - csv[0, 2]) / csv[0, 2] < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(12, 20, 128), (128, 128, 128), (256, 128, 1024)])
+@pytest.mark.parametrize("nodes", [(65, 65), (61, 49), (101, 51), (21, 17, 13), (33, 21, 9)])
+def test_bm6_dirichlet_poisson_on_the_physical_nodes(lib, nodes, monkeypatch):
+    """The reference's BM6 Poisson problem (phi = 0 / sin(y/7) on x = 0 / Lx, no flux elsewhere: dolfin/bench6.py:77-90,
+    pfbase.py:410-421) by the hand-written sine (x) / cosine (y, z) passes on the PHYSICAL nodes (fused_poisson_dirichlet:
+    dst_row_fwd_kernel, mx_col_kernel with the even extension in LDS, dst_row_inv_kernel) for lattices of 128, 120 / 96,
+    200 / 100 points and two 3-D boxes: phi within 1e-12 of the numpy restatement (FFT of the odd / even extension on the
+    whole lattice), exact boundary values, a few coupled steps -- and equal to the library route of round 2
+    (PFHIP_POISSON_DIRICHLET=rocfft: rocFFT of the extension + three pointwise kernels), which stays the fallback for
+    lattices with a prime factor above 5."""
+    from oracle import bm6_fd, ch_fd
+    dim = len(nodes)
+    shape = nodes[::-1]                                  # numpy order (z, y, x)
+    rng = np.random.default_rng(sum(nodes))
+    c = 0.5 + 0.04 * rng.standard_normal(shape)
+    ext = ch_fd.even_extend(c if dim == 3 else c[None])
+    ext = ext if dim == 3 else ext[0]
+    sl = tuple(slice(0, m) for m in shape)
+    got = {}
+    for route in ("lds", "rocfft"):
+        monkeypatch.setenv("PFHIP_POISSON_DIRICHLET", route)
+        o = bm6_fd.BM6FD(ext.copy(), 1.0, nodes[:2])
+        with PhaseFieldSolver(dim=dim, n=nodes, h=1.0, bc="mirror", model="bm6") as s:
+            s.set_c(c)
+            phi = s.get_phi()
+            assert np.abs(phi - o.phi()[sl]).max() <= 1e-12, route
+            y = np.arange(nodes[1])
+            assert np.abs(phi[..., 0]).max() == 0.0
+            assert np.abs(phi[..., -1] - np.sin(y / 7.0)[(None,) * (dim - 2) + (slice(None),)]).max() < 1e-15
+            s.step(5e-4, 6)
+            o.step(5e-4, 6)
+            assert np.abs(s.get_c() - o.c[sl]).max() <= 1e-12, route
+            F, C, E = s.diagnostics()
+            Fo, Co, Eo = o.diagnostics()
+            assert abs(F - Fo) <= 1e-12 * abs(Fo) and abs(E - Eo) <= 1e-10 * abs(Eo)
+            got[route] = (phi, s.get_c())
+    assert np.abs(got["lds"][0] - got["rocfft"][0]).max() <= 1e-12
+    assert np.abs(got["lds"][1] - got["rocfft"][1]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("shape", [(12, 20, 128), (128, 128, 128), (256, 128, 1024), (24, 40, 200), (100, 100), (384, 200)])
 def test_bm6_periodic_box_3d(lib, shape, monkeypatch):
-    """BM6 FD scheme in a periodic box; the Poisson solve runs on rocFFT for general shapes and on the hand-written
-    passes (fused3d_poisson: f2_row_kernel + f3_col_kernel MODE 4) for power-of-two boxes (forced here for 128^3)."""
+    """BM6 FD scheme in a periodic box; the Poisson solve runs on the hand-written passes: power-of-two boxes on
+    fused3d_poisson's f2_row_kernel + f3_col_kernel MODE 4, boxes whose axes factor into 2, 3, 5 (128 x 20 x 12,
+    200 x 40 x 24, and the 2-D 100 x 100 and 200 x 384) on the mixed-radix kernels (mx_row_kernel, mx_col_kernel MODE 4)."""
     from oracle import bm6_fd
     monkeypatch.setenv("PFHIP_SPECTRAL_3D", "lds")
     rng = np.random.default_rng(21)
     c = 0.5 + 0.04 * rng.standard_normal(shape)
     o = bm6_fd.BM6FD(c, 1.0)
-    with PhaseFieldSolver(dim=3, n=shape[::-1], h=1.0, model="bm6") as s:
+    with PhaseFieldSolver(dim=len(shape), n=shape[::-1], h=1.0, model="bm6") as s:
         s.set_c(c)
         assert np.abs(s.get_phi() - o.phi()).max() <= 1e-12
         s.step(5e-4, 5)
@@ -915,11 +959,13 @@ def test_fem_be_bm2_against_reference_rows_and_oracle(lib, golden_dir):
 
 
 @pytest.mark.parametrize("model,shape", [("bm2", (40, 64)), ("bm2", (6, 10, 34)), ("bm3", (48, 96)), ("bm3", (5, 12, 20)),
-                                         ("bm2", (3, 2)), ("bm3", (2, 1, 4))])
+                                         ("bm2", (3, 2)), ("bm3", (2, 1, 4)), ("bm2", (12, 16, 128)), ("bm3", (9, 24, 256)),
+                                         ("bm2", (4, 8, 384)), ("bm3", (70, 8, 128))])
 def test_multifield_fd_schemes_bit_exact_vs_numpy_oracle(lib, model, shape):
     """PF_SCHEME_FD_EXPLICIT for PF_MODEL_BM2 (c + 4 order parameters: mu pass + update pass) and PF_MODEL_BM3 (U, phi):
     periodic 2-D / 3-D boxes, random fields, several steps: BIT-identical to oracle/multi_fd.py (same operation order, no
-    fma on either side); diagnostics to 1e-13; rollback; blow-up guard."""
+    fma on either side); diagnostics to 1e-13; rollback; blow-up guard.  The last four shapes tile (x a multiple of 128, y
+    of 8, >= 4 planes) and run on the streaming LDS-tiled kernels (mfd_stream_kernel: several z-chunks, chunk ends, wraps)."""
     from oracle import multi_fd
     dim = len(shape)
     n = shape[::-1]
@@ -934,6 +980,7 @@ def test_multifield_fd_schemes_bit_exact_vs_numpy_oracle(lib, model, shape):
     u3 = u.reshape((len(names),) + ((1,) + shape if dim == 2 else shape))
     with PhaseFieldSolver(dim=dim, n=n, h=h, scheme="fd", model=model) as s:
         assert s.status.startswith("fd: explicit multi-field")
+        assert ("streaming" in s.status) == (dim == 3 and shape[2] % 128 == 0 and shape[1] % 8 == 0 and shape[0] >= 4)
         for f, name in enumerate(names):
             s.set_field(name, u[f])
         F, C, _ = s.diagnostics()
@@ -1025,6 +1072,141 @@ def test_fem_be_static_condensation_equals_the_full_block_solve(lib, model, n, h
         for a, b in zip(out["1"][1], out[other][1]):
             assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), other
         assert abs(out["1"][2][0] - out[other][2][0]) <= 1e-11 * abs(out[other][2][0]), other
+
+
+def _bm23(model):
+    if model == "bm2":
+        return dict(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", model="bm2", max_newton=100)
+    return dict(dim=2, n=351, h=960.0 / 350, bc="mirror", scheme="fem_be", model="bm3", max_newton=100)
+
+
+@pytest.mark.parametrize("model,rows", [("bm2", 9), ("bm3", 7)])
+def test_fem_be_pivot_policies_agree_at_production_block_sizes(lib, golden_dir, monkeypatch, model, rows):
+    """The default factors the small batches of the dense reduction levels WITHOUT row exchanges when the blocks hold 400+
+    unknowns -- which only the production meshes do (BM2: 101 nodes per row x 6 fields = 606, BM3: 351 x 2 = 702; the
+    small meshes of the variant test above never take that branch).  On those meshes, along the reference's committed time
+    grid (dolfin/bench2.py:226-262, bench3.py:202-258; BM2's row 5 needs the cp line search): PFHIP_FEM_PIVOT=1 (row
+    exchanges everywhere) and the default give identical Newton iteration counts, fields within 1e-10 and the same CSV
+    rows; pf_get_stat shows that the default really took the un-pivoted branch and never needed the repeat."""
+    import os
+    csv = np.loadtxt(os.path.join(golden_dir, "bench%s_out.csv" % model[-1]), delimiter=",", skiprows=1)
+    names = ("c", "mu", "eta1", "eta4") if model == "bm2" else ("U", "phi")
+    out = {}
+    for mode in ("auto", "1"):
+        monkeypatch.setenv("PFHIP_FEM_PIVOT", mode)
+        with PhaseFieldSolver(**_bm23(model)) as s:
+            (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+            its, npvt, tprev = [], [], 0.0
+            for i in range(rows):
+                ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+                assert ok, (mode, i)
+                tprev = csv[i, 0]
+                its.append(s.last_iters)
+                npvt.append(s.stat(L.PF_STAT_FEM_NPVT_LEVELS))
+                assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1, (mode, i)
+                F = s.diagnostics()[0]
+                assert abs(F - csv[i, 1]) <= 1e-8 * abs(csv[i, 1]), (mode, i, F, csv[i, 1])
+            out[mode] = (its, npvt, [s.get_field(k) for k in names])
+    assert min(out["auto"][1]) >= 3, out["auto"][1]          # the dense levels with <= 32 blocks: un-pivoted by default
+    assert max(out["1"][1]) == 0, out["1"][1]
+    assert out["auto"][0] == out["1"][0], (out["auto"][0], out["1"][0])
+    assert max(out["auto"][0]) >= 3
+    for a, b in zip(out["auto"][2], out["1"][2]):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+
+
+def test_fem_be_failed_unpivoted_solve_is_repeated_with_row_exchanges(lib, monkeypatch):
+    """fembe_step's safety net, reached on purpose: PFHIP_FEM_TEST_POISON_NPVT=1 (test-only switch) spoils the first Newton
+    direction of any attempt that contained an un-pivoted factorisation.  The step must then (i) restore the state,
+    (ii) repeat the solve with row exchanges in EVERY factorisation -- including the first reduction level, which leaves the
+    banded block-Thomas kernels for the dense pivoted ones -- and (iii) land exactly where an always-pivoting handle lands:
+    same iteration count, same fields, ok = 1, two attempts on record."""
+    dts = (0.01, 0.02, 0.04)          # the first steps of the committed grid (rows 0..2 of bench2_out.csv)
+    monkeypatch.setenv("PFHIP_FEM_PIVOT", "auto")
+    monkeypatch.setenv("PFHIP_FEM_TEST_POISON_NPVT", "1")
+    with PhaseFieldSolver(**_bm23("bm2")) as s:
+        s.set_ic_bm2()
+        its = []
+        for dt in dts:
+            before = s.get_field("c")
+            ok, _, _ = s.step(dt, 1, check=True)
+            assert ok
+            assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == 2 and s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0
+            assert np.abs(s.get_field("c") - before).max() > 0.0
+            its.append(s.last_iters)
+        got = [s.get_field(k) for k in ("c", "mu", "eta2")]
+        s.rollback()                                      # the pre-step state of the LAST step, not of a failed attempt
+        np.testing.assert_array_equal(s.get_field("c"), before)
+    monkeypatch.delenv("PFHIP_FEM_TEST_POISON_NPVT")
+    with PhaseFieldSolver(always_pivot=True, **_bm23("bm2")) as s:          # PF_FLAG_FEM_ALWAYS_PIVOT
+        s.set_ic_bm2()
+        ref_its = []
+        for dt in dts:
+            ok, _, _ = s.step(dt, 1, check=True)
+            assert ok and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1 and s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0
+            ref_its.append(s.last_iters)
+        ref = [s.get_field(k) for k in ("c", "mu", "eta2")]
+    assert its == ref_its, (its, ref_its)
+    for a, b in zip(got, ref):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+
+
+def test_fem_be_rejected_step_costs_one_solve_when_every_factorisation_pivoted(lib, golden_dir, monkeypatch):
+    """A step the Newton cap rejects (the reference then halves dt, bench1.py:164-177) is reported after ONE solve whenever
+    that solve pivoted throughout: always for BM1 / BM6 (blocks below 400 unknowns), and for BM2 under
+    PF_FLAG_FEM_ALWAYS_PIVOT (what the drivers set with the reference's dt controller).  Only a failed solve that really
+    contained an un-pivoted factorisation is repeated (BM2 default: two attempts on record, state untouched)."""
+    import os
+    monkeypatch.setenv("PFHIP_FEM_PIVOT", "auto")
+    csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:       # cap 10
+        s.set_ic_bm1(0.5, 0.05)
+        tprev = 0.0
+        for i in range(21):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1 and s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0
+            tprev = csv[i, 0]
+        ok, _, _ = s.step(csv[21, 0] - tprev, 1, check=True)                            # needs 24 iterations
+        assert not ok and s.last_iters == 10 and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1
+    for always, attempts in ((True, 1), (False, 2)):
+        kw = dict(_bm23("bm2"), max_newton=2)
+        with PhaseFieldSolver(always_pivot=always, **kw) as s:
+            s.set_ic_bm2()
+            before = s.get_field("eta1")
+            ok, _, _ = s.step(0.64, 1, check=True)        # 2 iterations are not enough at this dt (row 7 takes 4+)
+            assert not ok and s.last_iters == 2
+            assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == attempts
+            np.testing.assert_array_equal(s.get_field("eta1"), before)
+
+
+@pytest.mark.parametrize("model", ["bm2", "bm3"])
+def test_fem_be_full_reference_trajectory_bm2_bm3(lib, golden_dir, monkeypatch, model):
+    """The WHOLE committed runs of dolfin/bench2.py (120 accepted steps, dt 0.01 ... 163.84; bench2.py:226-262) and
+    dolfin/bench3.py (46 steps; bench3.py:202-258) through the GPU BE-parity mode with its DEFAULT pivot policy: every row's
+    F within 1e-8 of the reference's CSV (C / solid fraction to the CSV's precision) -- the large-dt rows are where an
+    un-pivoted Schur complement would be most at risk; none of them may need the pivoted repeat."""
+    import os
+    monkeypatch.setenv("PFHIP_FEM_PIVOT", "auto")
+    csv = np.loadtxt(os.path.join(golden_dir, "bench%s_out.csv" % model[-1]), delimiter=",", skiprows=1)
+    assert csv.shape == ((120, 3) if model == "bm2" else (46, 3))
+    worst, its = 0.0, []
+    with PhaseFieldSolver(**_bm23(model)) as s:
+        (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+        tprev = 0.0
+        for i in range(len(csv)):
+            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+            assert ok, (i, s.last_iters)
+            assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1, i
+            its.append(s.last_iters)
+            tprev = csv[i, 0]
+            F, C, _ = s.diagnostics()
+            worst = max(worst, abs(F - csv[i, 1]) / abs(csv[i, 1]))
+            assert abs(F - csv[i, 1]) <= 1e-8 * abs(csv[i, 1]), (i, F, csv[i, 1])
+            if model == "bm2":
+                assert abs(C - csv[i, 2]) <= 1e-9 * csv[i, 2], (i, C, csv[i, 2])
+            else:
+                assert abs(C - csv[i, 2]) <= 2e-10 + 1e-8 * abs(csv[i, 2]), (i, C, csv[i, 2])
+    print("%s full trajectory: worst rel F %.3g, Newton its %s" % (model, worst, its))
 
 
 def test_fem_be_bm3_against_reference_rows(lib, golden_dir):
@@ -1354,6 +1536,63 @@ def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scali
     assert d["check"]["C_rel_drift"] < 1e-12 and d["check"]["F_after"] < d["check"]["F_before"]
     assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None
     assert d["repeats"] == 2 and len(d["block_ms_per_step"]) == 2 and d["preheat_steps"] >= 5
+    # the process group's own account of who ran: N ranks, one entry (rank, device, pid) each, distinct processes
+    rk = d["ranks"]
+    assert rk["world_size"] == world and rk["backend"] == "gloo"
+    assert sorted(r["rank"] for r in rk["ranks"]) == list(range(world)) and len({r["pid"] for r in rk["ranks"]}) == world
+
+
+def test_bench_gpus_n_without_a_launcher_starts_the_ranks_itself():
+    """One command, like the reference's `mpirun -np N python dolfin/bench1.py` (README.md:22): `python bench.py --gpus 2`
+    with no WORLD_SIZE in the environment starts `python -m torch.distributed.run --nproc-per-node 2 bench.py ...` as a child
+    process (before this process touches the GPU), relays rank 0's JSON line and returns the child's exit code.  Rehearsal
+    mode (both ranks on device 0 over gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PFHIP_BENCH_REHEARSAL"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--preheat-s", "0.05", "--repeats", "2", "--no-cpu-baseline"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "torch.distributed.run" in p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["config"]["grid"] == [512, 512, 1024]
+    # a mismatch that is NOT "no launcher" is still an error (exit code != 0, nothing measured)
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"], env=env2, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr
+
+
+@pytest.mark.parametrize("workload", ["bm1_fem_be", "bm2_fem_be"])
+def test_bench_fem_be_workloads_standalone(workload):
+    """`python bench.py --workload bm1_fem_be` (BASELINE.json config 1) on its own -- the round-2 form crashed on its
+    warm-up default -- and the BM2 counterpart: one JSON line, rc 0, node-updates/s on the committed time grid."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["unit"] == "node-updates/s" and d["steps"] == 4 and d["warmup"] == 1 and d["value"] > 0
+    assert d["config"]["workload"] == workload and d["config"]["newton_iterations"] >= 4
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "bm1_fem_be"], cwd=root,
+                       capture_output=True, text=True, timeout=600) if workload == "bm1_fem_be" else None
+    if p is not None:       # the documented defaults (100 steps are capped by the 73-row grid; warm-up 10)
+        assert p.returncode == 0, p.stderr[-3000:]
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+        assert d["warmup"] == 10 and d["steps"] == 63 and "cpu_baseline" in d
 
 
 def test_bench_contract_json_line():
@@ -1397,6 +1636,18 @@ def test_bench_contract_json_line():
     fb = d["also"]["bm1_fem_be"]
     assert fb["unit"] == "node-updates/s" and fb["cpu_baseline"]["kind"] == "port" and fb["fenics_on_host"] in (True, False)
     assert abs(fb["check"]["F"] - 190.1699) < 1e-3      # row t = 11.1 of the reference's bench1_out.csv
+    # BASELINE.json config 5 (BM6 at 512^3, one GPU's share) in both forms, and the two extra models of SURVEY 8f next-4
+    b6, b6e = d["also"]["bm6_fd_512c"], d["also"]["bm6_fd_512c_elim"]
+    assert b6["roofline"]["bytes_per_cell_update"] == 72.0 and b6e["roofline"]["bytes_per_cell_update"] == 16.0
+    assert b6["config"]["grid"] == [512, 512, 512] and 0.05 < b6["roofline"]["frac"] < 1.0 and 0.2 < b6e["roofline"]["frac"] < 1.0
+    assert b6["check"]["C_rel_drift"] < 1e-12 and b6e["check"]["C_rel_drift"] < 1e-12
+    for m, nodes in (("bm2", 20201), ("bm3", 245701)):
+        fm = d["also"]["%s_fem_be" % m]
+        assert fm["unit"] == "node-updates/s" and abs(fm["value"] - nodes * fm["steps"] / (fm["ms_per_step"] * 1e-3 * fm["steps"])) < 1e-6 * fm["value"]
+        assert fm["cpu_baseline"]["kind"] == "port" and fm["cpu_baseline"]["value"] > 0 and "reference_wall_time" in fm["config"]
+    assert abs(d["also"]["bm2_fem_be"]["check"]["F"] - 3621.6143739566) < 1e-5       # row t = 0.63 of bench2_out.csv
+    assert abs(r["frac"] - d["value"] * 16.0 / 1e9 / 8000.0) < 1e-9                  # the wall-clock figure IS the headline
+    assert r["frac_hip_events"] >= r["frac"] * 0.98 and d["ranks"]["world_size"] == 1
 
 
 def test_b13d_driver_3d_extrusion_invariants(lib, tmp_path):
