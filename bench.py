@@ -570,6 +570,8 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
         "ranks": ranks_info,
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
+    if not slab and getattr(solver, "status", ""):
+        out["config"]["status"] = solver.status      # pf_status_string: kernels in use; spectral: what the placement probe saw
     if scheme == "spectral" and not slab:
         # one pf_step call advances `steps` steps; the state is the resident spectrum, the real-space field is written by
         # the last two steps of the call (PFHIP_SPECTRAL_STORE_EVERY_STEP=1 writes it every step)

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void mfd_stream_kernel(const MfdParams p, cons
 //   P1  c(z+2) (own + halo, prefetched)            -> LDS ring                                            | barrier
 //   P2  mu(z+1) on tile + ring from the ring planes z, z+1, z+2 and h(eta(z+1))  -> LDS mu plane; prefetch c(z+3), eta(z+2) | barrier
 //   P3  c+(z) = c + dt M lap mu(z);  eta_k+(z) from the eta(z) tiles and the registers; 5 stores          | barrier
-//   P4  eta(z+1) (own + halo) -> LDS tiles; rotate registers
+//   P4  eta(z+1) (own + halo) -> LDS tiles; rotate registers   (eta(z+2), requested in P2, is taken over in the next P2)
 // Halo work by role: waves 0-3 load one halo row of c each, wave 4 its 4 halo columns, waves 5 / 6 the eta halo rows (and
 // compute mu on the ring rows), wave 7 the eta halo columns (and mu on the ring columns).  Two warm-up iterations per
 // z-chunk fill the pipeline (outputs suppressed).  Same arithmetic and operation order as bm2_mu_kernel /
@@ -417,20 +417,21 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
   B2_LOAD_C(zb - 1)
   B2_STORE_C(zb - 1)
   B2_LOAD_C(zb)
-  {
-    double2 t0[4], t1[4];
-    B2_LOAD_E(t0, t1, zb - 1)
+  B2_LOAD_E(pe, peh, zb - 1)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      e[k][2] = t0[k];
-      eh[k] = t1[k];
-    }
-  }
+  for (int k = 0; k < 4; ++k) eh[k] = make_double2(0.0, 0.0);
   for (int z = zb - 2; z < ze; ++z) {
     // ---- P1 ----
     B2_STORE_C(z + 2)
     __syncthreads();
     // ---- P2: mu(z+1) ----
+    // eta(z+1) was requested one whole plane ago (end of the previous P2) and is taken over only now: consuming it in P4 of
+    // the iteration that requested it gave the loads one P3 to land and left the memory pipe idle for half of every plane
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      e[k][2] = pe[k];
+      eh[k] = peh[k];
+    }
     {
       const int sm = (z + 3) % 3, sc = (z + 4) % 3, sp = (z + 5) % 3, ms = (z + 3) & 1;   // planes z, z+1, z+2; mu slot of z+1
       double2 en[4];
@@ -509,8 +510,6 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
       if (e_col) S.et[k][ecr][ecx] = eh[k].x;
       e[k][0] = e[k][1];
       e[k][1] = e[k][2];
-      e[k][2] = pe[k];
-      eh[k] = peh[k];
     }
     mu3[0] = mu3[1];
     mu3[1] = mu3[2];

@@ -664,6 +664,7 @@ const char* pf_status_string(const pf_handle* h) {
     m->status = "fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction";
   } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
     m->status = "spectral: semi-implicit Fourier";
+    if (h->sp && spectral_probe_log(h->sp)[0]) m->status += std::string("; ") + spectral_probe_log(h->sp);
   } else {
     FdArgs a = make_args(h, 1.0, 0, h->g.nz);
     const bool fused = c.kernel != PF_KERNEL_TWOPASS && ch_fd_fused_supported(a);

@@ -82,6 +82,7 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
                   double cb, double two_rho, hipStream_t stream, bool store_field = true);
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
+const char* spectral_probe_log(const Spectral* sp);  // "" or what the placement probe measured at create
 
 // rocFFT through its native API (fftplan.hip): the library fallback for sizes the hand-written passes do not cover
 struct FftPlan;
@@ -117,6 +118,7 @@ int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out,
 int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa);
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
+int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H);  // the 4 passes of a 3-D step, for timing only
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
                  double M, double kappa, double ca, double cb, double two_rho, double gam);
 

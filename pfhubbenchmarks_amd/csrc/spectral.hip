@@ -157,6 +157,7 @@ struct Spectral {
   Fused2D* fast = nullptr;  // 2-D power-of-two grids: hand-written LDS FFT path (2 launches per step)
   KsArgs ks;
   std::string err;
+  std::string probe_log;  // what the placement probe of spectral_create saw (empty: no probe)
 };
 
 #define SP_HIP(expr)                                                       \
@@ -173,6 +174,7 @@ struct Spectral {
   } while (0)
 
 const char* spectral_error(const Spectral* sp) { return sp->err.c_str(); }
+const char* spectral_probe_log(const Spectral* sp) { return sp->probe_log.c_str(); }
 
 int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, hipStream_t stream, std::string* err) {
   Spectral* sp = new Spectral();
@@ -211,34 +213,35 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
       SP_FFT(fftplan_real(&sp->fwd, dim, nn, 1, true, stream, &sp->err));
       SP_FFT(fftplan_real(&sp->inv, dim, nn, 1, false, stream, &sp->err));
     }
-    {
-      // The three half-spectrum arrays come from ONE allocation at chosen distances (like the FD path's time levels,
-      // pfhip_api.hip placed_offset_bytes): three separate hipMallocs land wherever the allocator puts them, and the
-      // column passes' time depends on where their read and write streams sit relative to each other in the HBM
-      // channel map (same binary: z pass 1.00 or 1.19 ms from process to process, profiles/r03).
-      // PFHIP_SPEC_PLACE="g_kb,h_kb": extra distance of ghat / scratch behind the array before it, in KB (A/B).
-      size_t off_g = 0, off_h = 0;
-      if (const char* e = getenv("PFHIP_SPEC_PLACE")) {
-        long a = 0, b = 0;
-        if (sscanf(e, "%ld,%ld", &a, &b) == 2 && a >= 0 && b >= 0 && a <= 4096 && b <= 4096) {
-          off_g = (size_t)a * 1024;
-          off_h = (size_t)b * 1024;
-        }
+    // The three half-spectrum arrays come from ONE allocation (three separate hipMallocs land wherever the allocator puts
+    // them).  PFHIP_SPEC_PLACE="g_kb,h_kb": extra distance of ghat / scratch behind the array before it, in KB;
+    // PFHIP_SPEC_ALIGN_MB / PFHIP_SPEC_BASE_MB: start of the block rounded up to / shifted by that many MiB (A/B only: none
+    // of these moved the step time by more than 0.5 %, profiles/r03/spectral_512c_base_offset_sweep.log).
+    size_t off_g = 0, off_h = 0, align = 0, shift = 0;
+    if (const char* e = getenv("PFHIP_SPEC_PLACE")) {
+      long a = 0, b = 0;
+      if (sscanf(e, "%ld,%ld", &a, &b) == 2 && a >= 0 && b >= 0 && a <= 4096 && b <= 4096) {
+        off_g = (size_t)a * 1024;
+        off_h = (size_t)b * 1024;
       }
-      const size_t bytes = sizeof(double2) * nh_alloc, slot = (bytes + 255) / 256 * 256;
-      size_t align = 0, shift = 0;  // PFHIP_SPEC_ALIGN_MB: start the block on a multiple of this many MiB, PFHIP_SPEC_BASE_MB: plus this
-      if (const char* e = getenv("PFHIP_SPEC_ALIGN_MB")) align = (size_t)std::atol(e) << 20;
-      if (const char* e = getenv("PFHIP_SPEC_BASE_MB")) shift = (size_t)std::atol(e) << 20;
-      SP_HIP(hipMalloc(&sp->block, 3 * slot + off_g + off_h + align + shift));
-      unsigned char* base = sp->block;
+    }
+    if (const char* e = getenv("PFHIP_SPEC_ALIGN_MB")) align = (size_t)std::atol(e) << 20;
+    if (const char* e = getenv("PFHIP_SPEC_BASE_MB")) shift = (size_t)std::atol(e) << 20;
+    const size_t bytes = sizeof(double2) * nh_alloc, slot = (bytes + 255) / 256 * 256;
+    const size_t block_bytes = 3 * slot + off_g + off_h + align + shift;
+    auto carve = [&](unsigned char* block) {
+      unsigned char* base = block;
       if (align) base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(base) + align - 1) / align * align);
       base += shift;
+      sp->block = block;
       sp->chat = reinterpret_cast<double2*>(base);
       sp->ghat = reinterpret_cast<double2*>(base + slot + off_g);
       sp->scratch = reinterpret_cast<double2*>(base + 2 * slot + off_g + off_h);
-      if (getenv("PFHIP_SPECTRAL_VERBOSE"))
-        fprintf(stderr, "[spectral] block %p chat %p ghat %p scratch %p (%zu bytes each)\n", (void*)sp->block, (void*)sp->chat,
-                (void*)sp->ghat, (void*)sp->scratch, bytes);
+    };
+    {
+      unsigned char* blk = nullptr;
+      SP_HIP(hipMalloc(&blk, block_bytes));
+      carve(blk);
     }
     if (nh_alloc != sp->nh) {  // padded rows: the pad columns are never written by the passes; keep them defined
       SP_HIP(hipMemsetAsync(sp->chat, 0, sizeof(double2) * nh_alloc, stream));
@@ -252,6 +255,69 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
         sp->err = "fused2d_create failed";
         return -3;
       }
+    }
+    // PLACEMENT PROBE (large 3-D boxes on the hand-written passes).  The step time is a property of the ALLOCATION the
+    // spectrum lives in: six handles created side by side in one process ran 2.43 / 2.43 / 2.44 and 2.61 / 2.63 / 2.66 ms
+    // per 512^3 step, the same on every repetition (profiles/r03/spectral_512c_allocation_probe.log) -- physical placement
+    // (which HBM channels / banks the column passes' 2 MB strides fall on), not the virtual address: relative offsets,
+    // alignment and base shifts inside one allocation change nothing.  User code cannot ask for a placement, but it can
+    // look: up to PFHIP_SPEC_PROBE candidate blocks (default 4; 0 or 1 = off) are allocated, the four passes of a step are
+    // timed on each (zero-filled arrays, 3 repetitions), the fastest block is kept and the others are freed.  The search
+    // stops early once two candidates differ by more than 3.5 % (both kinds seen).  Costs ~10 ms per candidate at 512^3.
+    int nprobe = 4;
+    if (const char* e = getenv("PFHIP_SPEC_PROBE")) nprobe = std::atoi(e);
+    if (sp->fast && dim == 3 && sp->n >= (int64_t)256 * 256 * 256 && nprobe > 1) {
+      if (block_bytes > ((size_t)12 << 30)) nprobe = 2;  // (1024^3: 26 GB per candidate)
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      SP_HIP(hipEventCreate(&e0));
+      SP_HIP(hipEventCreate(&e1));
+      unsigned char* best_blk = nullptr;
+      float best_ms = 0.f, worst_ms = 0.f;
+      std::string log;
+      for (int k = 0; k < nprobe; ++k) {
+        if (k > 0) {
+          unsigned char* blk = nullptr;
+          if (hipMalloc(&blk, block_bytes) != hipSuccess) {
+            (void)hipGetLastError();  // out of memory for another candidate: keep what we have
+            break;
+          }
+          carve(blk);
+        }
+        SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
+        float ms = 0.f;
+        for (int rep = 0; rep < 4; ++rep) {  // the first repetition is a warm-up
+          if (rep == 1) SP_HIP(hipEventRecord(e0, stream));
+          if (fused3d_probe_step(sp->fast, sp->chat, sp->ghat, sp->scratch) != 0) {
+            sp->err = "fused3d_probe_step launch failed";
+            return -3;
+          }
+        }
+        SP_HIP(hipEventRecord(e1, stream));
+        SP_HIP(hipEventSynchronize(e1));
+        SP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms /= 3.f;
+        log += (k ? ", " : "") + std::to_string(ms);
+        if (!best_blk || ms < best_ms) {
+          if (best_blk) SP_HIP(hipFree(best_blk));
+          best_blk = sp->block;
+          best_ms = ms;
+        } else {
+          SP_HIP(hipFree(sp->block));
+        }
+        if (ms > worst_ms) worst_ms = ms;
+        if (k > 0 && best_ms < 0.965f * worst_ms) break;
+      }
+      carve(best_blk);
+      SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      spectral_invalidate(sp);
+      {
+        char kept[64];
+        snprintf(kept, sizeof kept, "%.4f", best_ms);
+        sp->probe_log = "placement probe: candidates " + log + " ms per step -> kept " + kept;
+      }
+      if (getenv("PFHIP_SPECTRAL_VERBOSE")) fprintf(stderr, "[spectral] %s (block %p)\n", sp->probe_log.c_str(), (void*)sp->block);
     }
     return 0;
   };

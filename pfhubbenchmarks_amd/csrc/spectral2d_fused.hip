@@ -47,7 +47,16 @@ struct F2Args {
   int zb = 0;        // log2 of the z-block (0: planes are not blocked)
   int nyp = 0;       // rows reserved per plane (ny + pad rows; 0 = ny)
   int bp = 1;        // rows reserved per (y, z-block) group (2^zb + pad rows)
+  int nt = 0;        // 512-point 3-D passes: bit 0 = non-temporal stores of the pass outputs (PFHIP_FFT3D_NT, A/B)
 };
+__device__ __forceinline__ void st2(double2* p, double2 v, int nt) {
+  if (nt) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+  } else {
+    *p = v;
+  }
+}
 
 // Row (z, y) of a half-spectrum array starts at spec_row() complex elements:
 //   row = ((z >> zb) nyp + y) bp + (z & (2^zb - 1)),   element = row pitch + kx.
@@ -547,8 +556,8 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
     if (k <= N / 2) {
       const int km = (N - k) & (N - 1);
       const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-      G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
-      G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+      st2(&G[spec_row_flat(a, y0) + k], make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y)), a.nt);
+      st2(&G[spec_row_flat(a, y1) + k], make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x)), a.nt);
     }
   }
 }
@@ -780,6 +789,16 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
   const int lane = threadIdx.x;
   const int T = (lane >> 3) + 8 * (lane & 7);
   double2 p[8], q[8];
+  // MINW == 2 (256 VGPRs per wave): the twiddle rows of this lane stay in registers for the wave's whole life (it is
+  // persistent) -- 28 L1 loads of 1 KB per row pair less, more bytes than the row pair itself (the lazy form re-reads them
+  // from the 9 KB tables before every use to fit 4-5 waves per SIMD)
+  constexpr bool HOLD = MINW <= 2;
+  double2 twN[7], twT[7], twB[7];
+  if (HOLD) {
+    load_tw(twN, twA_g, lane);
+    load_tw(twT, twA_g, T);
+    load_tw(twB, twB_g, lane & 7);
+  }
   int pair = blockIdx.x;
   auto issue = [&](int pr) {
     const int64_t r0 = spec_row_flat(a, 2 * pr), r1 = spec_row_flat(a, 2 * pr + 1);
@@ -803,7 +822,10 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
     const int y0 = 2 * pair, y1 = y0 + 1;
     const int next = pair + gridDim.x;
     if (next < npairs) issue(next);
-    fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+    if (HOLD)
+      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+    else
+      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
     if (c_out) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -814,7 +836,10 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
-    fft512_wave_tw<-1>(v, L, T, twA_g, twB_g, lane);
+    if (HOLD)
+      fft512_wave<-1>(v, L, T, twT, twB, lane);
+    else
+      fft512_wave_tw<-1>(v, L, T, twA_g, twB_g, lane);
     wave_lds_sync();
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -829,8 +854,8 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
       if (k <= N / 2) {
         const int km = (N - k) & (N - 1);
         const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-        G[g0 + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
-        G[g1 + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+        st2(&G[g0 + k], make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y)), a.nt);
+        st2(&G[g1 + k], make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x)), a.nt);
       }
     }
     wave_lds_sync();
@@ -957,7 +982,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
         const int64_t di = col_addr((MODE == 0 && spon == 1) ? ms : mn, b, r) + kx;
-        if (on) dst[di] = Lc[nat(r)];
+        if (on) st2(&dst[di], Lc[nat(r)], a.nt);
       }
     } else {
       // MODE 2: this is the z pass -- b is the (local) y index, the row along the column is k_z
@@ -976,7 +1001,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
         double2 r;
         r.x = fma(-num, gh.x, ch[i].x) * den;
         r.y = fma(-num, gh.y, ch[i].y) * den;
-        if (on) chat[col_addr(mn, b, kz) + kx] = r;
+        if (on) st2(&chat[col_addr(mn, b, kz) + kx], r, a.nt);
         Lc[nat(kz)] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
       }
       __syncthreads();
@@ -990,7 +1015,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        if (on) H[col_addr(mn, b, r) + kx] = Lc[nat(r)];
+        if (on) st2(&H[col_addr(mn, b, r) + kx], Lc[nat(r)], a.nt);
       }
     }
     if (!qset) break;
@@ -1438,8 +1463,9 @@ int g_cwg = 0;  // columns per workgroup of f3_col_kernel on 128- / 256-point ax
 int g_zearly = 0;  // z pass: request the resident spectrum before the forward FFT (PFHIP_FFT3D_ZEARLY = 0 | 1)
 int g_cw3 = 0;  // k_x columns per workgroup of the 3-D column passes: 0 = per pass (z: 4, y: 8), PFHIP_FFT3D_CW = 4 | 8 forces one
 int g_queue = 1;  // per-XCD work queues for the 512-point 3-D column passes: 0 = off, 1 = z passes (default), 2 = all (PFHIP_FFT3D_QUEUE)
-int g_row3 = 0;   // 3-D row pass form (PFHIP_FFT3D_ROWK): 0 = f2_row512_kernel<true>; 1 = <1,5>; 2 = <2,4>; 3 = <4,4>; 4 = persistent <1,4>;
-                  // 5 = persistent <1,5>; 6 = persistent <4,4>
+int g_row3 = 8;   // 3-D row pass form (PFHIP_FFT3D_ROWK): 0 = f2_row512_kernel<true>; 1 = <1,5>; 2 = <2,4>; 3 = <4,4>; 4 = persistent <1,4>;
+                  // 5 = persistent <1,5>; 6 = persistent <4,4>; 7 / 8 (default 8) = f3_row512p_kernel<3> / <2>: the step's row pass by
+                  // persistent waves with the next row pair's loads in flight (2.432-2.439 vs 2.440-2.453 ms per step, three A/B rounds)
 int g_cwy = 0;    // columns per workgroup of the y passes when set (PFHIP_FFT3D_CWY = 4 | 8)
 int g_qwgs = 0;   // persistent workgroups per CU in queue mode: 0 = what fits (PFHIP_FFT3D_QWGS)
 int g_cw512 = 1;  // columns per workgroup of the 2-D column kernel (PFHIP_FFT512_CW = 1 | 2 | 4): 13.05 / 14.3 / 17.5 us
@@ -1599,6 +1625,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     f->lgz = ilog2(nz);
     if (table(nz, &f->twz) != hipSuccess) return -3;
   }
+  if (const char* e = getenv("PFHIP_FFT3D_NT")) a.nt = (nz > 1 && std::atoi(e) != 0) ? 1 : 0;
   f->mixed = fused_path(nz > 1 ? 3 : 2, nx, ny, nz) == 2;
   if (f->mixed || nz == 1 || want_mx) {  // (2-D power-of-two grids too: their Poisson solve runs on the mixed-radix column kernel)
     auto full = [&](int N, double2** dev) -> hipError_t {
@@ -2039,6 +2066,23 @@ int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   launch_row(f, a, nullptr, c, nullptr, G, 0, 0);
   launch_col(f, a, G, chat, nullptr, 1);
   f->g_valid = false;
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// The four passes of one 3-D step on the given arrays, no real-space field involved (values irrelevant: the arrays may
+// be all zero): what spectral_create times to choose among candidate allocations.
+int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H) {
+  if (!f->cube512) return -3;
+  F2Args a = f->a;
+  a.ca = 0.3;
+  a.cb = 0.7;
+  a.two_rho = 10.0;
+  a.dtM = 0.05;
+  a.dtMkappa = 0.1;
+  launch_col3<2>(f, a, G, chat, H, 2);
+  launch_col3<1>(f, a, H, nullptr, nullptr, 1);
+  launch_row3(f, a, H, nullptr, nullptr, G, 1, 1);
+  launch_col3<0>(f, a, G, nullptr, nullptr, 1);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

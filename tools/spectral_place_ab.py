@@ -87,6 +87,16 @@ elif what == "align":
         e = dict({"PFHIP_SPEC_ALIGN_MB": "0"}, **env)
         ms, F = run(e)
         print("%.3f ms/step  F=%.9e  %s" % (ms, F, env), flush=True)
+elif what == "forms3":
+    os.environ["PFHIP_SPEC_PROBE"] = "4"
+    forms = [{}, {"PFHIP_FFT3D_NT": "1"}, {"PFHIP_FFT3D_ROWK": "8"}, {"PFHIP_FFT3D_ROWK": "8", "PFHIP_FFT3D_NT": "1"},
+             {"PFHIP_FFT3D_ROWK": "1"}, {"PFHIP_FFT3D_QWGS": "1"}]
+    res = [[] for _ in forms]
+    for rnd in range(3):
+        for i, env in enumerate(forms):
+            res[i].append(run(dict({"PFHIP_FFT3D_NT": "0", "PFHIP_FFT3D_QWGS": "0"}, **env))[0])
+    for env, r in zip(forms, res):
+        print(" ".join("%.3f" % v for v in r), env, flush=True)
 elif what == "forms2":
     forms = [{}, {"PFHIP_FFT3D_CW": "4"}, {"PFHIP_FFT3D_ZEARLY": "1"}, {"PFHIP_FFT3D_ROWK": "2"}, {"PFHIP_FFT3D_ROWK": "1"},
              {"PFHIP_FFT3D_CWY": "4"}, {"PFHIP_FFT3D_QUEUE": "1"}]
