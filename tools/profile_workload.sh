@@ -15,4 +15,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > 
 echo "FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 echo "WRITE_SIZE pass done"
-python3 $ROOT/tools/summarize_profile.py $OUT $W $TAG
+case "$W" in
+  bm1_fd_512c|bm1_fd_1024c) python3 $ROOT/tools/summarize_profile.py $OUT $W $TAG ;;
+  *) python3 $ROOT/tools/summarize_profile_multi.py $OUT $W $TAG ;;
+esac
+find $OUT -name "*counter_collection.csv" -size +2M -delete 2>/dev/null || true
+find $OUT -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null || true

@@ -47,7 +47,7 @@ steady_avg_ns = sum(steady) / len(steady)
 alg = 16 * CELLS
 fetch_b, write_b = fetch_kb * 1024 * 2, write_kb * 1024
 avg_ns = float(fused["AverageNs"])
-s = {"round": 2, "workload": workload, "kernel": name, "calls": int(fused["Calls"]), "avg_ns": avg_ns,
+s = {"round": 3, "workload": workload, "kernel": name, "calls": int(fused["Calls"]), "avg_ns": avg_ns,
      "steady_avg_ns": steady_avg_ns, "steady_launches": len(steady),
      "steady_note": "kernel_trace durations of the last 200 launches (bench.py's timed blocks, after its declared "
                     "pre-heat): a load starting from an idle GPU runs ~25 ms at a reduced shader clock (DESIGN.md 6.1)",
