@@ -19,6 +19,9 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
   bm6_spectral_512c     BM6 with the semi-implicit spectral scheme (phi eliminated in Fourier space; 1 GPU)
   bm6_fd_512c_elim      the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c) exactly): the step is
                 the fused kernel alone, no transform in the time loop (phi is solved only for diagnostics)
+  bm2_fd_512c / bm3_fd_512c   the multi-field models (dolfin/bench2.py, bench3.py) by explicit FD on the stencil design: one-pass
+                LDS-tiled BM2 kernel (80 B/cell-update), streaming BM3 kernel (32 B/cell-update); 1 GPU
+  bm2_fem_be / bm3_fem_be     the same models in the BE-parity mode (the reference's own discretisation), node-updates/s
   bm1_fem_be    BASELINE.json config 1: the reference's own algorithm (100x100 crossed P1 mesh, backward Euler, Newton)
                 on the GPU; a "step" is one accepted BE step of the committed run's time grid; metric node-updates/s;
                 cpu_baseline = oracle/fem_be.py (numpy/scipy SuperLU) on the same rows; says whether FEniCS is present
@@ -660,6 +663,13 @@ def side_measurements(a, ctx):
         b6 = bench_grid(a, name, ctx, max(10, min(a.steps, 40)), min(a.warmup, 10), cpu=False)
         also[name] = {k: b6[k] for k in keys}
         also[name]["config"] = dict(b6["config"], note=note)
+    for name, note in (("bm2_fd_512c", "SURVEY 8f next-4 on the stencil design: BM2 (c + 4 order parameters) explicit FD, one-pass "
+                                       "LDS-tiled kernel; roofline at 80 B/cell-update (5 fields read once, written once)"),
+                       ("bm3_fd_512c", "BM3 (U, phi) explicit FD, streaming LDS-tiled kernel; roofline at 32 B/cell-update")):
+        bm = bench_grid(a, name, ctx, max(10, min(a.steps, 40)), min(a.warmup, 10), cpu=False)
+        also[name] = {k: bm[k] for k in keys if k != "check"}
+        also[name]["check"] = {"F_before": bm["check"]["F_before"], "F_after": bm["check"]["F_after"]}
+        also[name]["config"] = dict(bm["config"], note=note)
     for model in ("bm2", "bm3"):
         also["%s_fem_be" % model] = bench_fem_multi(a, model, steps=6, warmup=2, cpu=not a.no_cpu_baseline)
     if not a.no_cpu_baseline:

@@ -127,7 +127,7 @@ constexpr int SX = 128, SPITCH = 132;   // tile width; LDS row pitch (own cells 
 template <int PASS>
 struct PassTraits;
 template <>
-struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 2; };   // stencilled fields, pointwise inputs, rows per thread
+struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 4; };   // stencilled fields, pointwise inputs, rows per thread
 template <>
 struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2; };
 template <>
@@ -141,8 +141,14 @@ __global__ __launch_bounds__(256) void mfd_stream_kernel(const MfdParams p, cons
   constexpr int NS = T::NS, NPW = T::NPW, RPT = T::RPT, TY = 4 * RPT;
   __shared__ __attribute__((aligned(16))) double tile[NS][TY + 2][SPITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * SX, y0 = blockIdx.y * TY;
-  const int zb = blockIdx.z * zchunk, ze = zb + zchunk < p.nz ? zb + zchunk : p.nz;
+  // XCD-aware tile order (as in bm2_fused_kernel below): every XCD gets a contiguous run of tiles, so that the halo rows a
+  // tile reads are the own rows of a tile on the same L2
+  const int ntx = p.nx / SX, nty = p.ny / TY;
+  const int nb = gridDim.x, per = (nb + 7) / 8, full = nb % 8;
+  const int xq = blockIdx.x % 8, rq = blockIdx.x / 8;
+  const int tile_id = full == 0 ? xq * per + rq : ((xq < full ? xq * per : full * per + (xq - full) * (per - 1)) + rq);
+  const int x0 = (tile_id % ntx) * SX, y0 = ((tile_id / ntx) % nty) * TY;
+  const int zb = (tile_id / (ntx * nty)) * zchunk, ze = zb + zchunk < p.nz ? zb + zchunk : p.nz;
   const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
   const int xo = x0 + 2 * lane;
   // stencilled field s of this pass -> where it lives
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
   const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
   const int xo = x0 + 2 * lane, tx = 2 + 2 * lane;
   const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3], Mob = p.q[4], ke = p.q[5], w = p.q[6], al = p.q[7], L = p.q[8];
-  auto zw = [&](int z) { return ((z % p.nz) + p.nz) % p.nz; };
+  auto zw = [&](int z) { return z < 0 ? z + p.nz : (z >= p.nz ? z - p.nz : z); };  // z in [-nz, 2 nz): no integer division
   // ---- roles (every wave forms every address, clamped to something valid, and loads under a predicate) ----
   const bool c_row = wave < 4, c_col = wave == 4 && lane < 4 * (B2TY + 2), e_row = wave == 5 || wave == 6,
              e_col = wave == 7 && lane < 2 * B2TY;
@@ -754,15 +760,14 @@ void launch_stream(const MultiFD* mf, const double* u, const double* mu, double*
   if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
   const int zchunk = (p.nz + nchunk - 1) / nchunk;
   nchunk = (p.nz + zchunk - 1) / zchunk;
-  hipLaunchKernelGGL(mfd_stream_kernel<PASS>, dim3(p.nx / SX, p.ny / TY, nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt,
-                     zchunk);
+  hipLaunchKernelGGL(mfd_stream_kernel<PASS>, dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
 }
 }  // namespace
 
 // which kernels multifd_step uses on this box: 1 = the streaming LDS-tiled forms, 0 = one thread per cell
 int multifd_streaming(const MultiFD* mf) {
   const MfdParams& p = mf->p;
-  return g_mfd_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 8 == 0;
+  return g_mfd_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 16 == 0;   // tile heights: 16 (BM3), 8 / 4 (BM2 passes), 8 (one-pass BM2)
 }
 
 int multifd_step(MultiFD* mf, double dt, int nsteps) {

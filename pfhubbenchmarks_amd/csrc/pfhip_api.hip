@@ -973,6 +973,17 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   }
   for (int s = 0; s < nsteps;) {
     const int left = nsteps - s;
+    if (h->sp && left > 2 && h->g.ghost == 0) {
+      // 512^2 with PFHIP_SPECTRAL_PERSIST=1: all but the last two steps of the call (the ones that store no field) in ONE
+      // launch on one XCD; "not available" (first step after the field was replaced, other sizes) falls through
+      const pf_config& c = h->cfg;
+      const int prc = spectral_steps_persistent(h->sp, left - 2, dt, c.M, c.kappa, c.c_alpha, c.c_beta, 2.0 * c.rho_s);
+      if (prc < 0) return fail(h, PF_ERR_HIP, spectral_error(h->sp));
+      if (prc == 0) {
+        s += left - 2;
+        continue;
+      }
+    }
     // spectral scheme: the state is the resident spectrum; the real-space field is written by the last two steps of the
     // call only -- what the caller can observe afterwards and what pf_rollback returns to (the same rule as the 2-D FD
     // multi-step launches below).  PFHIP_SPECTRAL_STORE_EVERY_STEP=1 writes it every step (A/B).

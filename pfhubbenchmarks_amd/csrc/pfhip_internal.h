@@ -80,6 +80,7 @@ void spectral_invalidate(Spectral* sp);
 void spectral_set_screening(Spectral* sp, double gq);  // BM6: gq = k^2 / eps; the step then treats -M gq (c - mean) implicitly  // call whenever the real-space field changed behind the scheme's back
 int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
                   double cb, double two_rho, hipStream_t stream, bool store_field = true);
+int spectral_steps_persistent(Spectral* sp, int nsteps, double dt, double M, double kappa, double ca, double cb, double two_rho);
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
 const char* spectral_probe_log(const Spectral* sp);  // "" or what the placement probe measured at create
@@ -119,6 +120,9 @@ int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yo
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
 int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H);  // the 4 passes of a 3-D step, for timing only
+int fused2d_persistent_steps(Fused2D* f, double2* chat, double2* G, double2* H, int nsteps, double dt, double M, double kappa,
+                             double ca, double cb, double two_rho, double gam);  // 0 done, 1 not available, -3 error
+int fused2d_persistent_participants(const Fused2D* f);
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
                  double M, double kappa, double ca, double cb, double two_rho, double gam);
 

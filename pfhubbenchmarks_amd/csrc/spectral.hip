@@ -385,6 +385,17 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   return 0;
 }
 
+// 512^2 on the hand-written path with PFHIP_SPECTRAL_PERSIST=1: `nsteps` steps that store no real-space field in one
+// launch (fused2d_persistent_steps).  0 = done; 1 = not available right now (the caller steps the ordinary way); < 0 error.
+int spectral_steps_persistent(Spectral* sp, int nsteps, double dt, double M, double kappa, double ca, double cb,
+                              double two_rho) {
+  if (!sp->fast || !sp->chat_valid) return 1;
+  const int rc = fused2d_persistent_steps(sp->fast, sp->chat, sp->ghat, sp->scratch, nsteps, dt, M, kappa, ca, cb, two_rho,
+                                          dt * M * sp->gq);
+  if (rc < 0) sp->err = "the single-XCD multi-step kernel failed (launch error or a barrier gave up)";
+  return rc;
+}
+
 // sum_k w_k k^2 |c_k|^2  (= N sum over the lattice of |grad c|^2 by Parseval) -> out_dev[0];
 // sum_{k != 0} w_k |c_k|^2 / k^2 -> out_dev[1]
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream) {

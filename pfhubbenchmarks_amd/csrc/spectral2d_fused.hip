@@ -562,6 +562,160 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
   }
 }
 
+// =====================================================================================================================
+// 512^2: MANY time steps in ONE launch, on ONE XCD (round 3).  The two-launch step above is bound by
+// the dependent-launch floor (~3 us per launch of a 12.8 us step); a chip-wide grid barrier costs more than a launch
+// (7-8 us: the eight L2s are not coherent with each other), but a barrier among the workgroups of ONE XCD does not need an
+// L2 write-back at all -- 0.8 us measured (pfk_xcd_barrier_probe, profiles/r03/xcd_barrier_probe.log).  So: the grid is
+// launched chip-wide, every workgroup registers the XCD it landed on (HW_REG_XCC_ID), the ones on XCD `target` stay (the
+// census tells them how many they are: whatever the dispatcher did, the work is split over exactly those), the others leave
+// at once.  The three 2 MiB arrays live in that XCD's 4 MiB L2 (+ the Infinity Cache); a phase hands its output to the next
+// one through L2: plain stores, vmcnt(0), barrier, and loads that bypass the per-CU L1 (8-byte relaxed agent-scope loads =
+// global_load_dwordx2 sc1).  The resident spectrum column of a wave is only ever touched by that wave: plain accesses.
+// One wave per column / per row pair, 8 waves per workgroup, the same transforms, twiddles and k-space arithmetic as
+// f2_col512_direct_kernel / f2_row512_kernel<false> -- bit-identical fields.  Every spin is bounded; a barrier that gives up
+// raises ctl[128] and every workgroup leaves (the host then reports an error instead of hanging the GPU).
+// ctl: [0] registered workgroups, [32 + x] census of XCD x, [64] / [65] arrival counters of the two barriers of a step,
+// [128] gave up, [160] participants.
+__device__ __forceinline__ double2 ld_l2(const double2* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_double2(__longlong_as_double((long long)a), __longlong_as_double((long long)b));
+}
+
+__global__ __launch_bounds__(512) void f2_persist512_kernel(const F2Args a, double2* __restrict__ G, double2* __restrict__ chat,
+                                                           double2* __restrict__ H, const double2* __restrict__ twA_g,
+                                                           const double2* __restrict__ twB_g, int nsteps,
+                                                           unsigned* __restrict__ ctl, int target) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int s_me, s_n, s_bad;
+  double2* Lall = reinterpret_cast<double2*>(smem_raw);
+  constexpr int N = 512;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double2* L = Lall + wave * W8;
+  int id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  const int xcc = id & 7;
+  if (threadIdx.x == 0) {
+    s_bad = 0;
+    s_me = (int)__hip_atomic_fetch_add(ctl + 32 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (xcc == target) {  // the census of this XCD is final once every workgroup of the grid has registered
+      int spins = 0;
+      while (__hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) {
+          s_bad = 1;
+          break;
+        }
+      }
+      s_n = (int)__hip_atomic_load(ctl + 32 + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (xcc != target) return;
+  const int me = s_me, n = s_n, gw = me * 8 + wave, W = 8 * n;
+  if (threadIdx.x == 0 && me == 0) ctl[160] = (unsigned)n;
+  if (s_bad) {
+    if (threadIdx.x == 0) ctl[128] = 1;
+    return;
+  }
+  // one barrier among the participants: arrive on counter c, wait until round * n have arrived
+  auto xcd_barrier = [&](unsigned* c, unsigned round) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = round * (unsigned)n;
+      int spins = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (__hip_atomic_load(ctl + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > (1 << 23)) {
+          __hip_atomic_store(ctl + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_bad = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    return s_bad != 0;
+  };
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  double2 twN[7], twT[7], twB[7];
+  load_tw(twN, twA_g, lane);
+  load_tw(twT, twA_g, T);
+  load_tw(twB, twB_g, lane & 7);
+  for (int step = 1; step <= nsteps; ++step) {
+    // ---- columns: forward y-FFT of G -> k-space update of the resident spectrum -> inverse y-FFT -> H ----
+    for (int kx = gw; kx < a.nxh; kx += W) {
+      double2 v[8], ch[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ld_l2(&G[(int64_t)(lane + 64 * j) * a.pitch + kx]);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) ch[t] = chat[(int64_t)(T + 64 * t) * a.pitch + kx];
+      fft512_wave<-1>(v, L, lane, twN, twB, lane);
+      const double kxv = a.kx0 * kx;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int ky = T + 64 * t;
+        const int my = 2 * ky > N ? ky - N : ky;
+        const double kyv = a.ky0 * my;
+        const double k2 = (kxv * kxv + kyv * kyv) + 0.0;
+        const double num = a.dtM * k2;
+        const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
+        double2 r;
+        r.x = fma(-num, v[t].x, ch[t].x) * den;
+        r.y = fma(-num, v[t].y, ch[t].y) * den;
+        chat[(int64_t)ky * a.pitch + kx] = r;
+        v[t] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
+      }
+      wave_lds_sync();
+      fft512_wave<+1>(v, L, T, twT, twB, lane);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) H[(int64_t)(T + 64 * t) * a.pitch + kx] = v[t];
+      wave_lds_sync();
+    }
+    if (xcd_barrier(ctl + 64, (unsigned)step)) return;
+    // ---- rows: inverse x-FFT of H (two rows per transform) -> f'(c) -> forward x-FFT -> G ----
+    for (int pair = gw; pair < a.ny / 2; pair += W) {
+      const int y0 = 2 * pair, y1 = y0 + 1;
+      double2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = lane + 64 * j;
+        const bool upper = k > N / 2;
+        const int kk = upper ? N - k : k;
+        const double2 p = ld_l2(&H[(int64_t)y0 * a.pitch + kk]), q = ld_l2(&H[(int64_t)y1 * a.pitch + kk]);
+        v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
+      }
+      fft512_wave<+1>(v, L, lane, twN, twB, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
+      fft512_wave<-1>(v, L, T, twT, twB, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = T + 64 * t;
+        L[k + (k >> 3)] = v[t];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int k = lane + 64 * t;
+        if (k <= N / 2) {
+          const int km = (N - k) & (N - 1);
+          const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
+          G[(int64_t)y0 * a.pitch + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+          G[(int64_t)y1 * a.pitch + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+        }
+      }
+      wave_lds_sync();
+    }
+    if (xcd_barrier(ctl + 65, (unsigned)step)) return;
+  }
+}
+
 constexpr int W8C = W8 + 32;  // per-wave LDS region of the staged column kernels: FFT exchanges (576) or a skewed
                               // natural-order column (575) + 4 * column index
 
@@ -1513,6 +1667,9 @@ struct Fused2D {
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
   bool g_valid = false;  // G holds the row transform of f'(current c)
+  unsigned* pctl = nullptr;   // 512^2 persistent multi-step kernel: control words (f2_persist512_kernel)
+  unsigned* pctl_host = nullptr;
+  bool persist = false;       // 2-D 512 x 512: steps that store no field run many-per-launch on one XCD (PFHIP_SPECTRAL_PERSIST)
   int* queues = nullptr;  // 2 sets x 8 per-XCD heads (XcdQueue), zero-initialised; launch n uses set n & 1
   mutable unsigned qepoch = 0;
   int ncu = 256;
@@ -1709,6 +1866,21 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
         hipMemcpy(f->tw8b, tb.data(), sizeof(double2) * 64, hipMemcpyHostToDevice) != hipSuccess)
       return -3;
   }
+  if (nz == 1 && nx == 512 && ny == 512 && f->row512 && f->col512 && !f->mixed) {
+    const char* pe = getenv("PFHIP_SPECTRAL_PERSIST");
+    f->persist = pe && pe[0] == '1';
+    if (f->persist) {
+      if (hipMalloc(&f->pctl, sizeof(unsigned) * 256) != hipSuccess ||
+          hipHostMalloc(&f->pctl_host, sizeof(unsigned) * 256, hipHostMallocDefault) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(f2_persist512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double2) * 8 * W8)) != hipSuccess)
+        return -3;
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        f->ncu = prop.multiProcessorCount;
+    }
+  }
   f->lds_row = sizeof(double2) * (nx + nx / 32 + nx / 2);
   f->lds_col = sizeof(double2) * ((size_t)CW * (ny + ny / 32 + 1) + ny / 2);
   if (f->lds_col > 64 * 1024 &&
@@ -1746,6 +1918,8 @@ void fused2d_destroy(Fused2D* f) {
   if (f->tw8b) (void)hipFree(f->tw8b);
   if (f->sym) (void)hipFree(f->sym);
   if (f->queues) (void)hipFree(f->queues);
+  if (f->pctl) (void)hipFree(f->pctl);
+  if (f->pctl_host) (void)hipHostFree(f->pctl_host);
   delete f;
 }
 
@@ -2085,6 +2259,32 @@ int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H) {
   launch_col3<0>(f, a, G, nullptr, nullptr, 1);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// 512^2 only: `nsteps` steps that store no real-space field, in one launch (f2_persist512_kernel).  G must hold the row
+// transform of f'(current c) (fused2d_step leaves it so).  Returns 1 when this box / handle cannot do it (the caller steps
+// the ordinary way), -3 on a launch error or a barrier that gave up (state then undefined: the caller reports the error).
+int fused2d_persistent_steps(Fused2D* f, double2* chat, double2* G, double2* H, int nsteps, double dt, double M, double kappa,
+                             double ca, double cb, double two_rho, double gam) {
+  if (!f->persist || !f->g_valid || nsteps < 1) return 1;
+  F2Args a = f->a;
+  a.ca = ca;
+  a.cb = cb;
+  a.two_rho = two_rho;
+  a.dtM = dt * M;
+  a.dtMkappa = dt * M * kappa;
+  a.gam = gam;
+  if (hipMemsetAsync(f->pctl, 0, sizeof(unsigned) * 256, f->stream) != hipSuccess) return -3;
+  hipLaunchKernelGGL(f2_persist512_kernel, dim3(f->ncu), dim3(512), sizeof(double2) * 8 * W8, f->stream, a, G, chat, H,
+                     (const double2*)f->tw8a, (const double2*)f->tw8b, nsteps, f->pctl, 0);
+  if (hipGetLastError() != hipSuccess) return -3;
+  // the give-up flag must be looked at before anything is built on the result
+  if (hipMemcpyAsync(f->pctl_host, f->pctl, sizeof(unsigned) * 256, hipMemcpyDeviceToHost, f->stream) != hipSuccess ||
+      hipStreamSynchronize(f->stream) != hipSuccess)
+    return -3;
+  if (f->pctl_host[128] != 0 || f->pctl_host[160] == 0) return -3;
+  return 0;
+}
+int fused2d_persistent_participants(const Fused2D* f) { return f->pctl_host ? (int)f->pctl_host[160] : 0; }
 
 // one semi-implicit step c_in -> c_out; chat (resident, valid for c_in) is advanced; G, H are work arrays
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,

@@ -407,6 +407,39 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
 
 
+@pytest.mark.parametrize("model", ["bm1", "bm6"])
+def test_spectral_512sq_many_steps_in_one_launch_on_one_xcd(lib, monkeypatch, model):
+    """PFHIP_SPECTRAL_PERSIST=1 (BASELINE.json config 2, 512^2): all but the last two steps of a pf_step call run in ONE
+    launch whose workgroups all sit on one XCD (f2_persist512_kernel: single-XCD barriers, hand-offs through that XCD's L2
+    with L1-bypassing loads).  Same transforms, twiddles and k-space arithmetic as the two-launch step: the fields must be
+    BIT-identical, for several call lengths (incl. calls too short to use it), after set_c (first step of a call goes the
+    ordinary way), after rollback, and against the numpy oracle."""
+    from oracle import ch_fd, ch_spectral
+    c0 = ch_fd.ic(512, 512, 1)[0]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PFHIP_SPECTRAL_PERSIST", mode)
+        with PhaseFieldSolver(dim=2, n=512, h=1.0, scheme="spectral", model=model) as s:
+            s.set_c(c0)
+            got = []
+            for k in (1, 2, 3, 7, 40):
+                s.step(1e-2, k)
+                got.append(s.get_c())
+            s.step(1e-2, 9)
+            s.rollback()                       # back to the state before the LAST step of the call (step 8 of 9)
+            got.append(s.get_c())
+            s.step(1e-2, 5)
+            got.append(s.get_c())
+            got.append(np.array(s.diagnostics()))
+            out[mode] = got
+    for a, b in zip(out["0"], out["1"]):
+        np.testing.assert_array_equal(a, b)
+    if model == "bm1":
+        sp = ch_spectral.SpectralCH(c0, h=1.0)
+        sp.step(1e-2, 53)
+        assert np.abs(out["1"][4] - sp.c).max() <= 1e-10 * np.abs(sp.c).max()
+
+
 @pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10), (128, 128, 128), (256, 128, 512),
                                    (200, 400), (20, 24, 50)])
 def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
@@ -959,13 +992,13 @@ def test_fem_be_bm2_against_reference_rows_and_oracle(lib, golden_dir):
 
 
 @pytest.mark.parametrize("model,shape", [("bm2", (40, 64)), ("bm2", (6, 10, 34)), ("bm3", (48, 96)), ("bm3", (5, 12, 20)),
-                                         ("bm2", (3, 2)), ("bm3", (2, 1, 4)), ("bm2", (12, 16, 128)), ("bm3", (9, 24, 256)),
-                                         ("bm2", (4, 8, 384)), ("bm3", (70, 8, 128))])
+                                         ("bm2", (3, 2)), ("bm3", (2, 1, 4)), ("bm2", (12, 16, 128)), ("bm3", (9, 32, 256)),
+                                         ("bm2", (4, 48, 384)), ("bm3", (70, 16, 128)), ("bm2", (5, 512, 512))])
 def test_multifield_fd_schemes_bit_exact_vs_numpy_oracle(lib, model, shape):
     """PF_SCHEME_FD_EXPLICIT for PF_MODEL_BM2 (c + 4 order parameters: mu pass + update pass) and PF_MODEL_BM3 (U, phi):
     periodic 2-D / 3-D boxes, random fields, several steps: BIT-identical to oracle/multi_fd.py (same operation order, no
-    fma on either side); diagnostics to 1e-13; rollback; blow-up guard.  The last four shapes tile (x a multiple of 128, y
-    of 8, >= 4 planes) and run on the streaming LDS-tiled kernels (mfd_stream_kernel: several z-chunks, chunk ends, wraps)."""
+    fma on either side); diagnostics to 1e-13; rollback; blow-up guard.  The last five shapes tile (x a multiple of 128, y
+    of 16, >= 4 planes; 512 x 512 x 5 = full-width planes of the bench workloads) and run on the streaming LDS-tiled kernels (mfd_stream_kernel: several z-chunks, chunk ends, wraps)."""
     from oracle import multi_fd
     dim = len(shape)
     n = shape[::-1]
@@ -980,7 +1013,7 @@ def test_multifield_fd_schemes_bit_exact_vs_numpy_oracle(lib, model, shape):
     u3 = u.reshape((len(names),) + ((1,) + shape if dim == 2 else shape))
     with PhaseFieldSolver(dim=dim, n=n, h=h, scheme="fd", model=model) as s:
         assert s.status.startswith("fd: explicit multi-field")
-        assert ("streaming" in s.status) == (dim == 3 and shape[2] % 128 == 0 and shape[1] % 8 == 0 and shape[0] >= 4)
+        assert ("streaming" in s.status) == (dim == 3 and shape[2] % 128 == 0 and shape[1] % 16 == 0 and shape[0] >= 4)
         for f, name in enumerate(names):
             s.set_field(name, u[f])
         F, C, _ = s.diagnostics()
@@ -1646,6 +1679,10 @@ def test_bench_contract_json_line():
         assert fm["unit"] == "node-updates/s" and abs(fm["value"] - nodes * fm["steps"] / (fm["ms_per_step"] * 1e-3 * fm["steps"])) < 1e-6 * fm["value"]
         assert fm["cpu_baseline"]["kind"] == "port" and fm["cpu_baseline"]["value"] > 0 and "reference_wall_time" in fm["config"]
     assert abs(d["also"]["bm2_fem_be"]["check"]["F"] - 3621.6143739566) < 1e-5       # row t = 0.63 of bench2_out.csv
+    for nm, bpc in (("bm2_fd_512c", 80.0), ("bm3_fd_512c", 32.0)):                   # the same models on the stencil design
+        fd = d["also"][nm]
+        assert fd["roofline"]["bytes_per_cell_update"] == bpc and 0.3 < fd["roofline"]["frac"] < 1.0
+        assert "streaming" in fd["config"]["status"] and fd["config"]["grid"] == [512, 512, 512]
     assert abs(r["frac"] - d["value"] * 16.0 / 1e9 / 8000.0) < 1e-9                  # the wall-clock figure IS the headline
     assert r["frac_hip_events"] >= r["frac"] * 0.98 and d["ranks"]["world_size"] == 1
 

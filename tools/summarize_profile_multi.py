@@ -32,7 +32,9 @@ def short(name):
 stats = list(csv.DictReader(open(one("stats/**/*kernel_stats.csv"))))
 stats = [r for r in stats if "pfhip" in r["Name"]]
 top = max(int(r["Calls"]) for r in stats)
-step_kernels = [r for r in stats if int(r["Calls"]) >= 0.9 * top]
+step_kernels = [r for r in stats if int(r["Calls"]) >= 0.3 * top]
+counts = sorted(int(r["Calls"]) for r in step_kernels)
+top = counts[len(counts) // 2]            # launches of a once-per-step kernel = steps run (a kernel launched twice per step counts twice)
 cnt = {}
 for passdir, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     acc = defaultdict(list)
