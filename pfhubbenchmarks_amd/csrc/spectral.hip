@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "pfhip_internal.h"
 
@@ -261,16 +262,20 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     // per 512^3 step, the same on every repetition (profiles/r03/spectral_512c_allocation_probe.log) -- physical placement
     // (which HBM channels / banks the column passes' 2 MB strides fall on), not the virtual address: relative offsets,
     // alignment and base shifts inside one allocation change nothing.  User code cannot ask for a placement, but it can
-    // look: up to PFHIP_SPEC_PROBE candidate blocks (default 4; 0 or 1 = off) are allocated, the four passes of a step are
+    // look: up to PFHIP_SPEC_PROBE candidate blocks (default 12; 0 or 1 = off) are allocated (all held until the choice is made), the four passes of a step are
     // timed on each (zero-filled arrays, 3 repetitions), the fastest block is kept and the others are freed.  The search
     // stops early once two candidates differ by more than 3.5 % (both kinds seen).  Costs ~10 ms per candidate at 512^3.
-    int nprobe = 4;
+    int nprobe = 12;
     if (const char* e = getenv("PFHIP_SPEC_PROBE")) nprobe = std::atoi(e);
     if (sp->fast && dim == 3 && sp->n >= (int64_t)256 * 256 * 256 && nprobe > 1) {
       if (block_bytes > ((size_t)12 << 30)) nprobe = 2;  // (1024^3: 26 GB per candidate)
       hipEvent_t e0 = nullptr, e1 = nullptr;
       SP_HIP(hipEventCreate(&e0));
       SP_HIP(hipEventCreate(&e1));
+      // every candidate stays allocated until the choice is made: freeing a loser first would hand the very same block
+      // back as the next "candidate"
+      std::vector<unsigned char*> cand;
+      cand.push_back(sp->block);
       unsigned char* best_blk = nullptr;
       float best_ms = 0.f, worst_ms = 0.f;
       std::string log;
@@ -278,9 +283,10 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
         if (k > 0) {
           unsigned char* blk = nullptr;
           if (hipMalloc(&blk, block_bytes) != hipSuccess) {
-            (void)hipGetLastError();  // out of memory for another candidate: keep what we have
+            (void)hipGetLastError();  // out of memory for another candidate: choose among what we have
             break;
           }
+          cand.push_back(blk);
           carve(blk);
         }
         SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
@@ -298,15 +304,14 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
         ms /= 3.f;
         log += (k ? ", " : "") + std::to_string(ms);
         if (!best_blk || ms < best_ms) {
-          if (best_blk) SP_HIP(hipFree(best_blk));
           best_blk = sp->block;
           best_ms = ms;
-        } else {
-          SP_HIP(hipFree(sp->block));
         }
         if (ms > worst_ms) worst_ms = ms;
         if (k > 0 && best_ms < 0.965f * worst_ms) break;
       }
+      for (unsigned char* b : cand)
+        if (b != best_blk) SP_HIP(hipFree(b));
       carve(best_blk);
       SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
       (void)hipEventDestroy(e0);

@@ -428,9 +428,9 @@ __device__ __forceinline__ void fft512_wave(double2 (&v)[8], double2* L, int m, 
 // Same transform with the twiddles fetched from the (L1/L2-resident, 9 KB) tables right before each use instead of held
 // in 56 VGPRs for the whole kernel: the column passes then fit 128 VGPRs with the resident spectrum in flight, i.e. two
 // 8-wave workgroups per CU instead of one (f3_col512_kernel).  rowA = this lane's input index m, rowB = lane & 7.
-template <int SIGN>
+template <int SIGN, int BS = 8>  // BS: row stride of the second table (8: the global table; 9: its bank-skewed copy in LDS)
 __device__ __forceinline__ void fft512_wave_tw(double2 (&v)[8], double2* L, int m, const double2* __restrict__ twA_g,
-                                               const double2* __restrict__ twB_g, int lane) {
+                                               const double2* twB_g, int lane) {
   const int hi = lane >> 3, lo = lane & 7;
   {
     double2 tw[7];
@@ -452,7 +452,7 @@ __device__ __forceinline__ void fft512_wave_tw(double2 (&v)[8], double2* L, int 
   {
     double2 tw[7];
 #pragma unroll
-    for (int sx = 1; sx < 8; ++sx) tw[sx - 1] = twB_g[lo * 8 + sx];
+    for (int sx = 1; sx < 8; ++sx) tw[sx - 1] = twB_g[lo * BS + sx];
     radix8<SIGN>(v);
 #pragma unroll
     for (int sx = 1; sx < 8; ++sx) {
@@ -1035,7 +1035,11 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
                                                              const double2* __restrict__ twB_g,
                                                              int* __restrict__ qset, int* __restrict__ qother) {
   __shared__ __attribute__((aligned(16))) double2 Lall[CW3 * W8C];
+  __shared__ __attribute__((aligned(16))) double2 TWB[72];  // the 64-entry second twiddle table, rows skewed to 9 slots (no bank
+                                                            // conflicts for the 8 distinct rows a wave reads): 7 of the 14
+                                                            // twiddle loads of a transform leave the L1 path
   __shared__ int s_item;
+  if (threadIdx.x < 64) TWB[(threadIdx.x >> 3) * 9 + (threadIdx.x & 7)] = twB_g[threadIdx.x];
   constexpr int N = 512, NT = 64 * CW3, PER = 8;
   auto nat = [](int n) { return n + (n >> 3); };
   // One work item (batch b, block of CW3 k_x columns) per workgroup.  (A persistent, software-pipelined form -- next
@@ -1090,9 +1094,9 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
     if (MODE == 1)
-      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+      fft512_wave_tw<+1, 9>(v, L, lane, twA_g, TWB, lane);
     else
-      fft512_wave_tw<-1>(v, L, lane, twA_g, twB_g, lane);
+      fft512_wave_tw<-1, 9>(v, L, lane, twA_g, TWB, lane);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
@@ -1120,7 +1124,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
-      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+      fft512_wave_tw<+1, 9>(v, L, lane, twA_g, TWB, lane);
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
@@ -1161,7 +1165,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
-      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
+      fft512_wave_tw<+1, 9>(v, L, lane, twA_g, TWB, lane);
       __syncthreads();
 #pragma unroll
       for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
