@@ -1089,6 +1089,11 @@ struct FemBE {
   int pivot_mode = 2;                      // 2 (default): row exchanges only in batches of more than 32 matrices, with a
                                            // pivoted retry of a failed Newton solve; PFHIP_FEM_PIVOT=1: always, =0: never
   bool force_pivot = false;                // set for the retry
+  bool own_trsm = true;                    // D^-1 [L | U | r] of the dense levels by lu_solve_mfma_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS trsm / rocSOLVER getrs)
+  bool own_gemv = true;                    // y -= A x of the levels by gemv_sub_kernel (PFHIP_FEM_GEMV=rocblas: rocBLAS)
+  bool own_getrs = true;                   // ... and of the pivoted levels of 400+ unknowns (PFHIP_FEM_TRSM=npvt: only the un-pivoted)
+  int* tperm = nullptr;                    // gather maps of the row exchanges: (ng / 2 + 1) x nb
+  double* tinv = nullptr;                  // its inverted 16 x 16 diagonal blocks: (ng / 2) matrices x ceil(nb / 16) blocks x 2 x 256
   bool used_npvt = false;                  // the current attempt factored at least one level without row exchanges
   int npvt_levels = 0;                     // ... how many (statistics of the last attempt)
   int attempts = 0;                        // Newton solves of the last fembe_step: 1, or 2 (optimistic solve + pivoted repeat)
@@ -1255,11 +1260,18 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_HIP(hipMalloc(&fb->Up, bs));
     FB_HIP(hipMalloc(&fb->Lo2, bs));
     FB_HIP(hipMalloc(&fb->Up2, bs));
+    FB_HIP(hipMalloc(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
+    FB_HIP(hipMalloc(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
       fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
       const char* pv = getenv("PFHIP_FEM_PIVOT");
       fb->pivot_mode = !pv ? 2 : (pv[0] == '0' ? 0 : (pv[0] == '1' ? 1 : 2));
+      const char* ts = getenv("PFHIP_FEM_TRSM");
+      fb->own_trsm = !(ts && std::string(ts) == "rocblas");
+      fb->own_getrs = !(ts && std::string(ts) == "npvt");
+      const char* gv = getenv("PFHIP_FEM_GEMV");
+      fb->own_gemv = !(gv && std::string(gv) == "rocblas");
       const char* tp = getenv("PFHIP_FEM_TEST_POISON_NPVT");
       fb->test_poison = tp && tp[0] == '1';
       const char* v = getenv("PFHIP_FEM_VERBOSE");
@@ -1354,7 +1366,7 @@ void fembe_destroy(FemBE* fb) {
   for (void* q : {(void*)fb->tri, (void*)fb->Ke, (void*)fb->ell_col, (void*)fb->ell_K, (void*)fb->ell_M,
                   (void*)fb->nt_ptr, (void*)fb->nt_tri, (void*)fb->nt_loc, (void*)fb->c, (void*)fb->mu, (void*)fb->phi,
                   (void*)fb->c0, (void*)fb->mu0, (void*)fb->phi0, (void*)fb->D, (void*)fb->Lo, (void*)fb->Up,
-                  (void*)fb->Lo2, (void*)fb->Up2,
+                  (void*)fb->Lo2, (void*)fb->Up2, (void*)fb->tinv, (void*)fb->tperm,
                   (void*)fb->rhs, (void*)fb->piv, (void*)fb->info, (void*)fb->scal, (void*)fb->partials})
     if (q) (void)hipFree(q);
   if (fb->scal_host) (void)hipHostFree(fb->scal_host);
@@ -1564,6 +1576,375 @@ static int block_solve(FemBE* fb) {
   return 0;
 }
 
+// ---- D^-1 [L | U | r] from an LU factorisation, all right-hand sides of a reduction level in ONE launch --------------------
+// rocBLAS' strided-batched trsm on these shapes (606 / 702 unknowns, 606 / 702 + 1 right-hand sides, <= 25 matrices) is a
+// storm of launches: per Newton iteration ~1200 Tensile GEMMs of 7 us, trtri kernels, copies and two trsv of 0.3-0.6 ms for
+// the single column -- 72 % of the BM2 step's kernel time (profiles/r03/bm2_fem_be_kernel_breakdown.txt).  Here a workgroup
+// of 8 waves takes 32 right-hand-side columns of one matrix and keeps them in registers for both substitutions, as 16 x 16
+// accumulator tiles of v_mfma_f64_16x16x4_f64 (row tile j belongs to wave j mod 8).  A block step of 16 rows:
+//   * the wave that owns the block's tile multiplies it by the pre-inverted 16 x 16 diagonal block (lu_diag_inv_kernel):
+//     the accumulator layout -- lane (q = lane >> 4, c = lane & 15) holds rows q + 4 r of column c -- IS the B-operand layout
+//     of a k-step that sums over k = q + 4 r, so the product needs no LDS and no lane movement; the result replaces the tile
+//     and goes to LDS (double-buffered: one barrier per block step);
+//   * every wave subtracts  L[tile rows, block columns] x Y  from its still-open tiles: A operands are 8-byte loads of L
+//     (resp. U), requested before the barrier; B operands are four ds_read_b64 per column tile, shared by all its row tiles.
+// Closed tiles cost nothing, so the triangle is not paid as a square.  Row exchanges of a pivoted factorisation are applied
+// when the right-hand side is loaded (perm from piv_to_perm_kernel).
+// (Earlier versions on the vector ALU: 256 threads x 3 rows = 256 VGPRs + AGPR spills, 365 us per workgroup; one row per
+// thread = bound by the LDS broadcasts of Y, profiles/r03/bm2_fem_be_kernel_breakdown_own_trsm.txt.)
+constexpr int TS_NB = 16, TS_W = 8, TS_NCT = 2, TS_NC = 16 * TS_NCT, TS_NMAX = 16 * TS_W * 6;   // n <= 768 (6 row tiles per wave: 213 VGPRs)
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// inv[e][blk][0] = inverse of the unit-lower diagonal block, [1] = inverse of the upper one (16 x 16, identity-padded), stored
+// in the order the MFMA A operand wants it: element [i][j] at (j >> 2) * 64 + (j & 3) * 16 + i, i.e. k-step r = j >> 2 is 64
+// consecutive doubles in lane order (lane = (j & 3) * 16 + i)
+__global__ __launch_bounds__(64) void lu_diag_inv_kernel(int n, const double* __restrict__ LU, int64_t lu_stride,
+                                                         double* __restrict__ inv) {
+  __shared__ double T[2][TS_NB][TS_NB + 1];
+  const int blk = blockIdx.x, e = blockIdx.y, nblk = gridDim.x, kb = blk * TS_NB;
+  const double* A = LU + (int64_t)e * lu_stride;
+  for (int idx = threadIdx.x; idx < TS_NB * TS_NB; idx += 64) {
+    const int i = idx % TS_NB, j = idx / TS_NB;
+    const bool in = kb + i < n && kb + j < n;
+    const double v = in ? A[(kb + i) + (int64_t)(kb + j) * n] : 0.0;
+    T[0][i][j] = i > j ? v : (i == j ? 1.0 : 0.0);
+    T[1][i][j] = i < j ? v : (i == j ? (in ? v : 1.0) : 0.0);
+  }
+  __syncthreads();
+  // thread c < 16: column c of the lower inverse; thread 16 + c: column c of the upper inverse
+  const int c = threadIdx.x & 15, which = threadIdx.x >> 4;
+  double* out = inv + (((int64_t)e * nblk + blk) * 2) * (TS_NB * TS_NB);
+  if (which == 0) {
+    double x[TS_NB];
+#pragma unroll
+    for (int i = 0; i < TS_NB; ++i) {
+      double sacc = i == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < TS_NB; ++j)
+        if (j < i) sacc -= T[0][i][j] * x[j];
+      x[i] = sacc;
+    }
+#pragma unroll
+    for (int i = 0; i < TS_NB; ++i) out[(c >> 2) * 64 + (c & 3) * 16 + i] = x[i];
+  } else if (which == 1) {
+    double x[TS_NB];
+#pragma unroll
+    for (int ii = 0; ii < TS_NB; ++ii) {
+      const int i = TS_NB - 1 - ii;
+      double sacc = i == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < TS_NB; ++j)
+        if (j > i) sacc -= T[1][i][j] * x[j];
+      x[i] = sacc / T[1][i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < TS_NB; ++i) out[TS_NB * TS_NB + (c >> 2) * 64 + (c & 3) * 16 + i] = x[i];
+  }
+}
+
+// LAPACK's sequential row exchanges ipiv (1-based) of ne factorisations -> gather maps: (P b)[i] = b[perm[i]]
+__global__ __launch_bounds__(64) void piv_to_perm_kernel(int n, const rocblas_int* __restrict__ ipiv, int64_t piv_stride,
+                                                         int* __restrict__ perm) {
+  __shared__ int P[TS_NMAX], V[TS_NMAX];
+  const int e = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    P[i] = i;
+    V[i] = ipiv[(int64_t)e * piv_stride + i] - 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 0; i < n; ++i) {
+      const int j = V[i], a = P[i];
+      P[i] = P[j];
+      P[j] = a;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 64) perm[(int64_t)e * n + i] = P[i];
+}
+
+// grid (2 npan + 1, ne): panels 0 .. npan-1 = column blocks of Xu, npan .. 2 npan-1 = of Xl, 2 npan = the single column xr;
+// 512 threads; MAXT >= ceil(ceil(n / 16) / 8) row tiles per wave.
+// Software pipeline: a workgroup's 8 waves move in lockstep (one barrier per block step) and the registers allow one
+// workgroup per CU, so nothing else hides latency.  The A operands (and the inverted diagonal block) of step s + 1 are
+// therefore requested before the barrier of step s, and the wave that owns the NEXT block's tile solves it right after giving
+// it its last update (its first open tile in the order the pass walks them), writing Y of step s + 1 into the other LDS buffer
+// while the other waves are still updating: the owner's dependent chain is off the critical path except at the start of a pass.
+template <int MAXT>
+__global__ __launch_bounds__(64 * TS_W) void lu_solve_mfma_kernel(int n, const double* __restrict__ LU, int64_t lu_stride,
+                                                                  const double* __restrict__ inv, const int* __restrict__ perm,
+                                                                  double* __restrict__ Xu, double* __restrict__ Xl,
+                                                                  int64_t x_stride, double* __restrict__ xr, int64_t r_stride,
+                                                                  int npan, int warm_l2) {
+  constexpr int YST = TS_NC + (TS_NCT % 2 == 0 ? 16 : 0);   // row stride of the LDS image of Y: rows q, q + 1 on other banks
+  extern __shared__ double lu_lds[];
+  double (*Ys)[TS_NB][YST] = reinterpret_cast<double (*)[TS_NB][YST]>(lu_lds);   // [2][16][YST]
+  double* Dl = lu_lds + 2 * TS_NB * YST;   // the pass's inverted diagonal blocks: ntile x 256 (<= 96 KB)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, c = lane & 15;
+  const int ntile = (n + TS_NB - 1) / TS_NB;
+  // workgroups are dealt to the 8 XCDs round-robin: give every XCD a contiguous run of (matrix, panel) items, so that the
+  // ~32 workgroups an XCD runs at a time read the SAME matrix and its L2 serves all but the first of them
+  int e, pan;
+  {
+    const int npn = (int)gridDim.x, total = npn * (int)gridDim.y, lin = (int)blockIdx.x + npn * (int)blockIdx.y;
+    const int xcd = lin & 7, k = lin >> 3, per = total >> 3, rem = total & 7;
+    const int item = xcd * per + (xcd < rem ? xcd : rem) + k;
+    e = item / npn;
+    pan = item - e * npn;
+  }
+  const double* A = LU + (int64_t)e * lu_stride;
+  double* B;
+  int ncol;
+  if (pan < 2 * npan) {
+    const int pp = pan < npan ? pan : pan - npan;
+    B = (pan < npan ? Xu : Xl) + (int64_t)e * x_stride + (int64_t)pp * TS_NC * n;
+    ncol = n - pp * TS_NC < TS_NC ? n - pp * TS_NC : TS_NC;
+  } else {
+    B = xr + (int64_t)e * r_stride;
+    ncol = 1;
+  }
+  const int* pm = perm ? perm + (int64_t)e * n : nullptr;
+  v4f64 acc[MAXT][TS_NCT];
+#pragma unroll
+  for (int jj = 0; jj < MAXT; ++jj) {
+    const int j = w + TS_W * jj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * j + q + 4 * r;
+      const int src = (pm && row < n) ? pm[row] : row;
+#pragma unroll
+      for (int ct = 0; ct < TS_NCT; ++ct) {
+        const int col = 16 * ct + c;
+        acc[jj][ct][r] = (row < n && col < ncol) ? B[src + (int64_t)col * n] : 0.0;
+      }
+    }
+  }
+  if (pm) __syncthreads();   // in place: every row of these columns is in registers before any of them is written
+  const double* invm = inv + (int64_t)e * ntile * 2 * (TS_NB * TS_NB);
+  // Tiles are taken in the order the pass walks them (ii = 0, 1, ..: tile jj = ii forward, MAXT - 1 - ii backward).  The
+  // first H of them get their A operands one block step ahead, into the other half of a ping-pong pair (no copies, no wait
+  // at the end of a step); the others at the top of their own step, where they are used after the early tiles' MFMAs: six
+  // tiles' worth of look-ahead registers do not fit beside the tiles themselves.
+  constexpr int H = MAXT <= 5 ? MAXT : 3, NL = MAXT - H > 0 ? MAXT - H : 1;
+  double early0[H][4], early1[H][4], late[NL][4], dn[4];
+
+  // A operands of the tiles still open at block blk: lane (m = c, k = q) of k-step r holds L[16 j + c][16 blk + q + 4 r].
+  // Buffer loads: a loop-invariant lane offset, tile and k-step in the scalar offset.  Nothing is done to a loaded value
+  // (a select on it would make the wave wait for the load where it is issued): rows past n -- last tile, forward pass
+  // only -- and columns past n -- last block, backward pass only -- get a lane offset outside the descriptor and read 0.
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A), 0, (int)((int64_t)n * n * 8), 0x00020000);
+  constexpr int OOB = 0x7ffffff0;
+  const int voffA = ((16 * w + c) + q * n) * 8;
+  const int voff_lastrow = 16 * (ntile - 1) + c < n ? voffA : OOB;
+  auto load_a = [&](auto passc, int blk, auto ii0c, auto ii1c, auto& dst) __attribute__((always_inline)) {
+    constexpr int P = decltype(passc)::value, ii0 = decltype(ii0c)::value, ii1 = decltype(ii1c)::value;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    int vo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vo[r] = (P == 1 && 16 * blk + q + 4 * r >= n) ? OOB : voffA;
+#pragma unroll
+    for (int ii = ii0; ii < ii1; ++ii) {
+      const int jj = P == 0 ? ii : MAXT - 1 - ii;
+      const int j = w + TS_W * jj;
+      const bool open = P == 0 ? (j > blk && j < ntile) : (j < blk);
+      if (open) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int soff = ((16 * blk + 4 * r) * n + 16 * TS_W * jj) * 8;
+          const int v = P == 0 ? (j == ntile - 1 ? voff_lastrow : voffA) : vo[r];
+          dst[ii - ii0][r] = __builtin_bit_cast(double, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(rsA, v, soff, 0));
+        }
+      }
+    }
+  };
+  // inverse of block blk's diagonal block as A operand: lane (m = c, k = q) of k-step r holds inv[c][q + 4 r].  From LDS
+  // (copied there at the start of the pass): as a global load it sat in the same in-order queue as the A-operand prefetches.
+  auto load_d = [&](int blk, double (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = Dl[blk * (TS_NB * TS_NB) + r * 64 + lane];
+  };
+  // Y = inv(diagonal block) * tile: the accumulator registers are the B operands (k = q + 4 r); result in place, -Y to LDS
+  auto solve_tile = [&](v4f64 (&t)[TS_NCT], const double (&dd)[4], int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < TS_NCT; ++ct) {
+      v4f64 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[r], t[ct][r], y, 0, 0, 0);
+      t[ct] = y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ys[buf][q + 4 * r][16 * ct + c] = -y[r];   // the updates are X_tile -= L Y
+    }
+  };
+
+  // Bring the triangle a pass reads into this XCD's L2 before the pass starts: one 4-byte load per 128-byte line, a column per
+  // instruction, wave w the columns w, w + 8, ...  Without it every block step's 16 columns are first touches that come from
+  // HBM / MALL.  Loads return in order, so this has to be a burst at the start of the pass and not a trickle a few steps
+  // ahead.  The results are never read.
+  auto warm = [&](auto passc, int& sink) {
+    constexpr int P = decltype(passc)::value;
+    const char* base = reinterpret_cast<const char*>(A);
+    for (int col = w; col < n; col += TS_W) {
+      const int b0 = ((col * n + (P == 0 ? col + 1 : 0)) * 8) & ~127, b1 = (col * n + (P == 0 ? n : col)) * 8;
+      const int off = b0 + lane * 128;
+      if (off < b1) {
+        const char* ptr = base + off;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(ptr) : "memory");
+      }
+    }
+    // the compiler does not know these loads are still in flight: let them land before their register can be reused
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+  };
+
+  int step = 0;
+  // one block step; cur holds the early tiles' A operands of this block, nx receives those of the next
+  using I0 = std::integral_constant<int, 0>;
+  using IH = std::integral_constant<int, H>;
+  using IM = std::integral_constant<int, MAXT>;
+  auto block_step = [&](auto passc, int bb, double (&cur)[H][4], double (&nx)[H][4]) __attribute__((always_inline)) {
+    constexpr int P = decltype(passc)::value;
+    const int blk = P == 0 ? bb : ntile - 1 - bb, nxt = P == 0 ? blk + 1 : blk - 1;
+    const bool has_next = bb + 1 < ntile;
+    const int buf = step & 1;
+    ++step;
+    if (bb == 0) {   // start of a pass: nothing was prepared by the step before
+      load_a(passc, blk, I0{}, IH{}, cur);
+      if (w == (blk & (TS_W - 1))) {
+        load_d(blk, dn);
+#pragma unroll
+        for (int jj = 0; jj < MAXT; ++jj)
+          if (jj == (blk >> 3)) solve_tile(acc[jj], dn, buf);
+      }
+    }
+    if (has_next && w == (nxt & (TS_W - 1))) load_d(nxt, dn);
+    if constexpr (H < MAXT) load_a(passc, blk, IH{}, IM{}, late);
+    if (has_next) load_a(passc, nxt, I0{}, IH{}, nx);
+    __syncthreads();
+    double b[TS_NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < TS_NCT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[ct][r] = Ys[buf][q + 4 * r][16 * ct + c];
+#pragma unroll
+    for (int ii = 0; ii < MAXT; ++ii) {
+      const int jj = P == 0 ? ii : MAXT - 1 - ii;   // the next block's tile is the first open one in this order
+      const int j = w + TS_W * jj;
+      const bool open = P == 0 ? (j > blk && j < ntile) : (j < blk);
+      if (open) {
+#pragma unroll
+        for (int ct = 0; ct < TS_NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[jj][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ii < H ? cur[ii < H ? ii : 0][r] : late[ii >= H ? ii - H : 0][r],
+                                                               b[ct][r], acc[jj][ct], 0, 0, 0);
+        if (has_next && j == nxt) solve_tile(acc[jj], dn, buf ^ 1);
+      }
+    }
+  };
+  // pass 0: forward substitution with the unit-lower factor (blocks top-down); pass 1: backward with the upper (bottom-up)
+  auto run_pass = [&](auto passc) __attribute__((always_inline)) {
+    constexpr int P = decltype(passc)::value;
+    int sink = 0;
+    if (warm_l2) warm(passc, sink);
+    for (int idx = threadIdx.x; idx < ntile * (TS_NB * TS_NB); idx += 64 * TS_W)
+      Dl[idx] = invm[(idx >> 8) * (2 * TS_NB * TS_NB) + P * (TS_NB * TS_NB) + (idx & 255)];
+    __syncthreads();
+    for (int bb = 0; bb < ntile; bb += 2) {
+      block_step(passc, bb, early0, early1);
+      if (bb + 1 < ntile) block_step(passc, bb + 1, early1, early0);
+    }
+  };
+  run_pass(std::integral_constant<int, 0>{});
+  run_pass(std::integral_constant<int, 1>{});
+#pragma unroll
+  for (int jj = 0; jj < MAXT; ++jj) {
+    const int j = w + TS_W * jj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * j + q + 4 * r;
+#pragma unroll
+      for (int ct = 0; ct < TS_NCT; ++ct) {
+        const int col = 16 * ct + c;
+        if (row < n && col < ncol) B[row + (int64_t)col * n] = acc[jj][ct][r];
+      }
+    }
+  }
+}
+
+// the launches of one level: diagonal-block inverses, (gather maps,) the substitutions
+static void lu_solve_level(hipStream_t stream, int nb, int ne, const double* De, int64_t st, const rocblas_int* piv,
+                           int64_t piv_stride, double* tinv, int* perm, double* Xu, double* Xl, double* xr, int64_t sv) {
+  static const int warm = [] {
+    const char* v = getenv("PFHIP_FEM_TRSM_WARM");   // A/B: 0 = no L2 warm-up of the factors
+    return v ? atoi(v) : 1;
+  }();
+  const int ntile = (nb + TS_NB - 1) / TS_NB, npan = (nb + TS_NC - 1) / TS_NC;
+  hipLaunchKernelGGL(lu_diag_inv_kernel, dim3(ntile, ne), dim3(64), 0, stream, nb, De, st, tinv);
+  if (piv) hipLaunchKernelGGL(piv_to_perm_kernel, dim3(ne), dim3(64), 0, stream, nb, piv, piv_stride, perm);
+  const int* pm = piv ? perm : nullptr;
+  const dim3 grid(2 * npan + 1, ne), block(64 * TS_W);
+  const int maxt = (ntile + TS_W - 1) / TS_W;
+  constexpr int YST = TS_NC + (TS_NCT % 2 == 0 ? 16 : 0);
+  const size_t lds = sizeof(double) * (2 * TS_NB * YST + (size_t)ntile * TS_NB * TS_NB);
+#define PF_LU_SOLVE(MT)                                                                                                      \
+  do {                                                                                                                       \
+    static bool attr = false;                                                                                                \
+    if (!attr) {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)lu_solve_mfma_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                                (int)(sizeof(double) * (2 * TS_NB * YST + (TS_NMAX / TS_NB) * TS_NB * TS_NB)));               \
+      attr = true;                                                                                                           \
+    }                                                                                                                        \
+    hipLaunchKernelGGL(lu_solve_mfma_kernel<MT>, grid, block, lds, stream, nb, De, st, (const double*)tinv, pm, Xu, Xl, st,   \
+                       xr, sv, npan, warm);                                                                                  \
+  } while (0)
+  if (maxt <= 2) PF_LU_SOLVE(2);
+  else if (maxt <= 4) PF_LU_SOLVE(4);
+  else if (maxt <= 5) PF_LU_SOLVE(5);
+  else PF_LU_SOLVE(6);
+#undef PF_LU_SOLVE
+}
+
+// y_e -= A_e x_e for a batch of dense n x n blocks (column-major): the right-hand-side updates of the reduction levels and the
+// back-substitution.  rocBLAS' strided-batched gemv spends 72 us (BM2) / 229 us (BM3) per call on these shapes, 10-13 % of
+// the step's kernel time; the matrices are read once, so the bound is their bytes.  A workgroup takes 64 rows of one block:
+// wave g the columns g, g + 8, .. (four 512-byte column segments in flight per wave), partial sums added in a fixed order.
+constexpr int GV_W = 8;
+__global__ __launch_bounds__(64 * GV_W) void gemv_sub_kernel(int n, const double* __restrict__ A, int64_t sa,
+                                                             const double* __restrict__ x, int64_t sx,
+                                                             double* __restrict__ y, int64_t sy) {
+  extern __shared__ double gv_lds[];   // x (n), then the partial sums [GV_W][64]
+  double* xs = gv_lds;
+  double* part = gv_lds + n;
+  const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), e = blockIdx.y;
+  const int row = blockIdx.x * 64 + lane;
+  const double* Ae = A + (int64_t)e * sa;
+  for (int i = threadIdx.x; i < n; i += 64 * GV_W) xs[i] = x[(int64_t)e * sx + i];
+  __syncthreads();
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (row < n) {
+    int col = g;
+    for (; col + 3 * GV_W < n; col += 4 * GV_W) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = Ae[row + (int64_t)(col + u * GV_W) * n];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fma(v[u], xs[col + u * GV_W], acc[u]);
+    }
+    for (; col < n; col += GV_W) acc[0] = fma(Ae[row + (int64_t)col * n], xs[col], acc[0]);
+  }
+  part[g * 64 + lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (g == 0 && row < n) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < GV_W; ++k) sum += part[k * 64 + lane];
+    y[(int64_t)e * sy + row] -= sum;
+  }
+}
+static void gemv_sub(hipStream_t stream, int n, const double* A, int64_t sa, const double* x, int64_t sx, double* y,
+                     int64_t sy, int count) {
+  hipLaunchKernelGGL(gemv_sub_kernel, dim3((n + 63) / 64, count), dim3(64 * GV_W), sizeof(double) * (n + 64 * GV_W), stream, n,
+                     A, sa, x, sx, y, sy);
+}
+
 // scal[3] <- 1 if any of the n factorisations of a batch reported a zero pivot (rocSOLVER info > 0)
 __global__ void info_flag_kernel(const rocblas_int* __restrict__ info, int n, double* __restrict__ flag) {
   bool bad = false;
@@ -1635,16 +2016,28 @@ static int block_solve_bcr(FemBE* fb) {
     };
     if (!banded && lvl_pivot) {
       FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
+      if (fb->own_trsm && fb->own_getrs && nb >= 400 && nb <= TS_NMAX) {
+        // row exchanges applied while the right-hand sides are loaded, then the same substitutions as without them
+        lu_solve_level(fb->stream, nb, ne, De, st, pe, sv, fb->tinv, fb->tperm, Xu, Xl, xr, sv);
+        FB_HIP(hipGetLastError());
+        if (fork()) return -3;
+      } else {
       if (fork()) return -3;
       FB_BLAS(rocsolver_dgetrs_strided_batched(hU, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xu, nb, st, ne));
       FB_BLAS(rocsolver_dgetrs_strided_batched(hR, rocblas_operation_none, nb, 1, De, nb, st, pe, sv, xr, nb, sv, ne));
       FB_BLAS(rocsolver_dgetrs_strided_batched(fb->bh, rocblas_operation_none, nb, nb, De, nb, st, pe, sv, Xl, nb, st, ne));
+      }
     } else if (!banded) {
       fb->used_npvt = true;
       ++fb->npvt_levels;
       FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, De, nb, st, fb->info, ne));
       // an exactly singular leading minor: raise the flag the Newton loop reads with the next residual norm
       hipLaunchKernelGGL(info_flag_kernel, dim3(1), dim3(64), 0, fb->stream, (const rocblas_int*)fb->info, ne, fb->scal + 3);
+      if (fb->own_trsm && nb <= TS_NMAX) {
+        lu_solve_level(fb->stream, nb, ne, De, st, nullptr, 0, fb->tinv, nullptr, Xu, Xl, xr, sv);
+        FB_HIP(hipGetLastError());
+        if (fork()) return -3;
+      } else {
       if (fork()) return -3;
       struct Rhs {
         rocblas_handle hh;
@@ -1658,6 +2051,7 @@ static int block_solve_bcr(FemBE* fb) {
         FB_BLAS(rocblas_dtrsm_strided_batched(r.hh, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
                                               rocblas_diagonal_non_unit, nb, r.n, &one, De, nb, st, r.b, nb, r.stride, ne));
       }
+      }
     }
     const int nl = nk - 1;  // kept blocks k = 2, 4, .. have a left neighbour (L_k at Lc + j0 bs)
     const int nr = ne;      // kept blocks k = 0, 2, .. with k + 1 <= m - 1 have a right neighbour (U_k at Uc)
@@ -1667,6 +2061,13 @@ static int block_solve_bcr(FemBE* fb) {
                                            X, nb, st, beta, C, nb, st, count);
     };
     auto gemv = [&](rocblas_handle hh, const double* Ab, double* y, int count) {
+      if (fb->own_gemv && nb <= 4096) {
+        hipStream_t hs = nullptr;
+        const rocblas_status rs = rocblas_get_stream(hh, &hs);
+        if (rs != rocblas_status_success) return rs;
+        gemv_sub(hs, nb, Ab, st, xr, sv, y, sv, count);
+        return rocblas_status_success;
+      }
       return rocblas_dgemv_strided_batched(hh, rocblas_operation_none, nb, nb, &mone, Ab, nb, st, xr, 1, sv, &one, y, 1, sv,
                                            count);
     };
@@ -1727,6 +2128,12 @@ static int block_solve_bcr(FemBE* fb) {
     const int nright = (L.m % 2) ? ne : ne - 1;  // eliminated blocks that have a right neighbour
     const int64_t st = 2 * (int64_t)L.s * bs, sv = 2 * (int64_t)L.s * nb;
     double* re = fb->rhs + (int64_t)L.s * nb;
+    if (fb->own_gemv && nb <= 4096) {
+      gemv_sub(fb->stream, nb, Ls[L.set] + (int64_t)L.s * bs, st, fb->rhs, sv, re, sv, ne);
+      if (nright > 0)
+        gemv_sub(fb->stream, nb, Us[L.set] + (int64_t)L.s * bs, st, fb->rhs + 2 * (int64_t)L.s * nb, sv, re, sv, nright);
+      continue;
+    }
     FB_BLAS(rocblas_dgemv_strided_batched(fb->bh, rocblas_operation_none, nb, nb, &mone, Ls[L.set] + (int64_t)L.s * bs,
                                           nb, st, fb->rhs, 1, sv, &one, re, 1, sv, ne));
     if (nright > 0)

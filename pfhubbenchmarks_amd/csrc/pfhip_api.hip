@@ -677,6 +677,7 @@ const char* pf_status_string(const pf_handle* h) {
       m->status = "WARNING fd: nx is odd (or a buffer is not 16-byte aligned), so the fused kernel cannot run -- two-pass "
                   "kernels, 40 B per cell update instead of 16 (about 6x slower); pad nx to an even number";
   }
+  if (h->po && poisson_probe_log(h->po)[0]) m->status += std::string("; Poisson work array: ") + poisson_probe_log(h->po);
   return m->status.c_str();
 }
 

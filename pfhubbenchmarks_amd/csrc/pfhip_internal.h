@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 
 #include "pfhip.h"
@@ -120,6 +121,9 @@ int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yo
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
 int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H);  // the 4 passes of a 3-D step, for timing only
+int fused3d_probe_poisson(Fused2D* f, double2* W);                           // the 3 column passes of the Poisson solve
+int place_block_by_probe(size_t bytes, unsigned char* first, hipStream_t stream, const std::function<int(unsigned char*)>& run,
+                         unsigned char** kept, std::string* log);
 int fused2d_persistent_steps(Fused2D* f, double2* chat, double2* G, double2* H, int nsteps, double dt, double M, double kappa,
                              double ca, double cb, double two_rho, double gam);  // 0 done, 1 not available, -3 error
 int fused2d_persistent_participants(const Fused2D* f);
@@ -134,6 +138,7 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
 void poisson_destroy(Poisson* po);
 int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream);
 const char* poisson_error(const Poisson* po);
+const char* poisson_probe_log(const Poisson* po);
 
 // slab-decomposed FFT building blocks (slabfft.hip)
 struct SlabFFT;

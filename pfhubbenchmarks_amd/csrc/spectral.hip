@@ -265,64 +265,24 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     // look: up to PFHIP_SPEC_PROBE candidate blocks (default 12; 0 or 1 = off) are allocated (all held until the choice is made), the four passes of a step are
     // timed on each (zero-filled arrays, 3 repetitions), the fastest block is kept and the others are freed.  The search
     // stops early once two candidates differ by more than 3.5 % (both kinds seen).  Costs ~10 ms per candidate at 512^3.
-    int nprobe = 12;
-    if (const char* e = getenv("PFHIP_SPEC_PROBE")) nprobe = std::atoi(e);
-    if (sp->fast && dim == 3 && sp->n >= (int64_t)256 * 256 * 256 && nprobe > 1) {
-      if (block_bytes > ((size_t)12 << 30)) nprobe = 2;  // (1024^3: 26 GB per candidate)
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      SP_HIP(hipEventCreate(&e0));
-      SP_HIP(hipEventCreate(&e1));
-      // every candidate stays allocated until the choice is made: freeing a loser first would hand the very same block
-      // back as the next "candidate"
-      std::vector<unsigned char*> cand;
-      cand.push_back(sp->block);
-      unsigned char* best_blk = nullptr;
-      float best_ms = 0.f, worst_ms = 0.f;
-      std::string log;
-      for (int k = 0; k < nprobe; ++k) {
-        if (k > 0) {
-          unsigned char* blk = nullptr;
-          if (hipMalloc(&blk, block_bytes) != hipSuccess) {
-            (void)hipGetLastError();  // out of memory for another candidate: choose among what we have
-            break;
-          }
-          cand.push_back(blk);
-          carve(blk);
-        }
-        SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
-        float ms = 0.f;
-        for (int rep = 0; rep < 4; ++rep) {  // the first repetition is a warm-up
-          if (rep == 1) SP_HIP(hipEventRecord(e0, stream));
-          if (fused3d_probe_step(sp->fast, sp->chat, sp->ghat, sp->scratch) != 0) {
-            sp->err = "fused3d_probe_step launch failed";
-            return -3;
-          }
-        }
-        SP_HIP(hipEventRecord(e1, stream));
-        SP_HIP(hipEventSynchronize(e1));
-        SP_HIP(hipEventElapsedTime(&ms, e0, e1));
-        ms /= 3.f;
-        log += (k ? ", " : "") + std::to_string(ms);
-        if (!best_blk || ms < best_ms) {
-          best_blk = sp->block;
-          best_ms = ms;
-        }
-        if (ms > worst_ms) worst_ms = ms;
-        if (k > 0 && best_ms < 0.965f * worst_ms) break;
+    if (sp->fast && dim == 3 && sp->n >= (int64_t)256 * 256 * 256) {
+      unsigned char* kept = nullptr;
+      const int prc = place_block_by_probe(
+          block_bytes, sp->block, stream,
+          [&](unsigned char* blk) {
+            carve(blk);
+            return fused3d_probe_step(sp->fast, sp->chat, sp->ghat, sp->scratch);
+          },
+          &kept, &sp->probe_log);
+      if (prc != 0) {
+        sp->err = "placement probe failed";
+        return -3;
       }
-      for (unsigned char* b : cand)
-        if (b != best_blk) SP_HIP(hipFree(b));
-      carve(best_blk);
+      carve(kept);
       SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
       spectral_invalidate(sp);
-      {
-        char kept[64];
-        snprintf(kept, sizeof kept, "%.4f", best_ms);
-        sp->probe_log = "placement probe: candidates " + log + " ms per step -> kept " + kept;
-      }
-      if (getenv("PFHIP_SPECTRAL_VERBOSE")) fprintf(stderr, "[spectral] %s (block %p)\n", sp->probe_log.c_str(), (void*)sp->block);
+      if (getenv("PFHIP_SPECTRAL_VERBOSE") && !sp->probe_log.empty())
+        fprintf(stderr, "[spectral] %s (block %p)\n", sp->probe_log.c_str(), (void*)sp->block);
     }
     return 0;
   };

@@ -17,7 +17,9 @@
 // 512-point axes by the one-wave radix-8 kernels, the others by the radix-2^2 kernels), the 3-D periodic Poisson solve of
 // BM6, and the slab-decomposed transforms of the multi-GPU modes (fusedslab_*, used by slabfft.hip).
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -2212,6 +2214,18 @@ int fused_poisson_dirichlet(Fused2D* f, const double* c, double* phi, double* S,
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// the three column passes of fused3d_poisson on W (values irrelevant), for the placement probe of poisson_create
+int fused3d_probe_poisson(Fused2D* f, double2* W) {
+  if (!f->cube512 || ensure_sym(f) != 0) return -3;
+  F2Args a = f->a;
+  a.dtM = 1.0;
+  a.dtMkappa = -1.0;
+  launch_col3<0>(f, a, W, nullptr, nullptr, 1);
+  launch_col3<4>(f, a, W, reinterpret_cast<double2*>(f->sym), nullptr, 2);
+  launch_col3<1>(f, a, W, nullptr, nullptr, 1);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2) {
   if (ensure_sym(f) != 0) return -3;
   F2Args a = f->a;
@@ -2245,6 +2259,72 @@ int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   launch_col(f, a, G, chat, nullptr, 1);
   f->g_valid = false;
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// PLACEMENT PROBE.  The time of the strided column passes is a property of the ALLOCATION they run on (see spectral.hip):
+// allocate up to PFHIP_SPEC_PROBE candidate blocks of `bytes` (default 12; 0 or 1 = off; 2 when a block exceeds 12 GB),
+// zero-fill each, time `run(block)` (3 repetitions after a warm-up) and keep the fastest; every candidate stays allocated until
+// the choice is made (freeing a loser first would hand the same block back), then the others are freed.  Stops early once two
+// candidates differ by more than 3.5 % (both kinds seen).  `first` = an already allocated block (candidate 0).  On return
+// *kept is the chosen block (its contents are whatever the probe left) and *log says what was measured.
+int place_block_by_probe(size_t bytes, unsigned char* first, hipStream_t stream, const std::function<int(unsigned char*)>& run,
+                         unsigned char** kept, std::string* log) {
+  int nprobe = 12;
+  if (const char* e = getenv("PFHIP_SPEC_PROBE")) nprobe = std::atoi(e);
+  *kept = first;
+  if (nprobe <= 1) return 0;
+  if (bytes > ((size_t)12 << 30)) nprobe = 2;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -3;
+  std::vector<unsigned char*> cand;
+  cand.push_back(first);
+  unsigned char* best = nullptr;
+  float best_ms = 0.f, worst_ms = 0.f;
+  std::string lg;
+  int rc = 0;
+  for (int k = 0; k < nprobe && rc == 0; ++k) {
+    if (k > 0) {
+      unsigned char* blk = nullptr;
+      if (hipMalloc(&blk, bytes) != hipSuccess) {
+        (void)hipGetLastError();  // no memory for another candidate: choose among what we have
+        break;
+      }
+      cand.push_back(blk);
+    }
+    unsigned char* blk = cand.back();
+    if (hipMemsetAsync(blk, 0, bytes, stream) != hipSuccess) rc = -3;
+    for (int rep = 0; rep < 4 && rc == 0; ++rep) {  // the first repetition is a warm-up
+      if (rep == 1 && hipEventRecord(e0, stream) != hipSuccess) rc = -3;
+      if (rc == 0 && run(blk) != 0) rc = -3;
+    }
+    float ms = 0.f;
+    if (rc == 0 && (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                    hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+      rc = -3;
+    if (rc) break;
+    ms /= 3.f;
+    char buf[32];
+    snprintf(buf, sizeof buf, "%s%.4f", k ? ", " : "", ms);
+    lg += buf;
+    if (!best || ms < best_ms) {
+      best = blk;
+      best_ms = ms;
+    }
+    if (ms > worst_ms) worst_ms = ms;
+    if (k > 0 && best_ms < 0.965f * worst_ms) break;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (!best) best = first;
+  for (unsigned char* b : cand)
+    if (b != best) (void)hipFree(b);
+  *kept = best;
+  if (log) {
+    char buf[48];
+    snprintf(buf, sizeof buf, " ms -> kept %.4f", best_ms);
+    *log = "placement probe: candidates " + lg + buf;
+  }
+  return rc;
 }
 
 // The four passes of one 3-D step on the given arrays, no real-space field involved (values irrelevant: the arrays may
