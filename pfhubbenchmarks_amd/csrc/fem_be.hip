@@ -1090,6 +1090,8 @@ struct FemBE {
                                            // pivoted retry of a failed Newton solve; PFHIP_FEM_PIVOT=1: always, =0: never
   bool force_pivot = false;                // set for the retry
   bool own_trsm = true;                    // D^-1 [L | U | r] of the dense levels by lu_solve_mfma_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS trsm / rocSOLVER getrs)
+  bool own_getrf = true;                   // un-pivoted LU of the dense levels by lu_npvt_coop_kernel (PFHIP_FEM_GETRF=rocsolver: getrf_npvt)
+  int* tflags = nullptr;                   // its panel flags: (ng / 2 + 1) x ceil(nb / 16)
   bool own_gemv = true;                    // y -= A x of the levels by gemv_sub_kernel (PFHIP_FEM_GEMV=rocblas: rocBLAS)
   bool own_getrs = true;                   // ... and of the pivoted levels of 400+ unknowns (PFHIP_FEM_TRSM=npvt: only the un-pivoted)
   int* tperm = nullptr;                    // gather maps of the row exchanges: (ng / 2 + 1) x nb
@@ -1262,6 +1264,7 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_HIP(hipMalloc(&fb->Up2, bs));
     FB_HIP(hipMalloc(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
     FB_HIP(hipMalloc(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
+    FB_HIP(hipMalloc(&fb->tflags, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
       fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
@@ -1270,6 +1273,8 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       const char* ts = getenv("PFHIP_FEM_TRSM");
       fb->own_trsm = !(ts && std::string(ts) == "rocblas");
       fb->own_getrs = !(ts && std::string(ts) == "npvt");
+      const char* gf = getenv("PFHIP_FEM_GETRF");
+      fb->own_getrf = !(gf && std::string(gf) == "rocsolver");
       const char* gv = getenv("PFHIP_FEM_GEMV");
       fb->own_gemv = !(gv && std::string(gv) == "rocblas");
       const char* tp = getenv("PFHIP_FEM_TEST_POISON_NPVT");
@@ -1366,7 +1371,7 @@ void fembe_destroy(FemBE* fb) {
   for (void* q : {(void*)fb->tri, (void*)fb->Ke, (void*)fb->ell_col, (void*)fb->ell_K, (void*)fb->ell_M,
                   (void*)fb->nt_ptr, (void*)fb->nt_tri, (void*)fb->nt_loc, (void*)fb->c, (void*)fb->mu, (void*)fb->phi,
                   (void*)fb->c0, (void*)fb->mu0, (void*)fb->phi0, (void*)fb->D, (void*)fb->Lo, (void*)fb->Up,
-                  (void*)fb->Lo2, (void*)fb->Up2, (void*)fb->tinv, (void*)fb->tperm,
+                  (void*)fb->Lo2, (void*)fb->Up2, (void*)fb->tinv, (void*)fb->tperm, (void*)fb->tflags,
                   (void*)fb->rhs, (void*)fb->piv, (void*)fb->info, (void*)fb->scal, (void*)fb->partials})
     if (q) (void)hipFree(q);
   if (fb->scal_host) (void)hipHostFree(fb->scal_host);
@@ -1871,12 +1876,13 @@ __global__ __launch_bounds__(64 * TS_W) void lu_solve_mfma_kernel(int n, const d
 
 // the launches of one level: diagonal-block inverses, (gather maps,) the substitutions
 static void lu_solve_level(hipStream_t stream, int nb, int ne, const double* De, int64_t st, const rocblas_int* piv,
-                           int64_t piv_stride, double* tinv, int* perm, double* Xu, double* Xl, double* xr, int64_t sv) {
+                           int64_t piv_stride, double* tinv, int* perm, double* Xu, double* Xl, double* xr, int64_t sv,
+                           bool rhs_only = false) {
   static const int warm = [] {
     const char* v = getenv("PFHIP_FEM_TRSM_WARM");   // A/B: 0 = no L2 warm-up of the factors
     return v ? atoi(v) : 1;
   }();
-  const int ntile = (nb + TS_NB - 1) / TS_NB, npan = (nb + TS_NC - 1) / TS_NC;
+  const int ntile = (nb + TS_NB - 1) / TS_NB, npan = rhs_only ? 0 : (nb + TS_NC - 1) / TS_NC;   // rhs_only: the column xr alone
   hipLaunchKernelGGL(lu_diag_inv_kernel, dim3(ntile, ne), dim3(64), 0, stream, nb, De, st, tinv);
   if (piv) hipLaunchKernelGGL(piv_to_perm_kernel, dim3(ne), dim3(64), 0, stream, nb, piv, piv_stride, perm);
   const int* pm = piv ? perm : nullptr;
@@ -1900,6 +1906,309 @@ static void lu_solve_level(hipStream_t stream, int nb, int ne, const double* De,
   else if (maxt <= 5) PF_LU_SOLVE(5);
   else PF_LU_SOLVE(6);
 #undef PF_LU_SOLVE
+}
+
+// ---- LU without row exchanges of a batch of dense blocks: G cooperating workgroups per matrix, ONE launch -------------------
+// rocSOLVER's getrf_npvt on 606 / 702 unknowns is 57 panel / trsm / gemm launches of 10-45 us whatever the batch size (<= 25):
+// ~1.2 ms per reduction level, 40 % of the BM2 step once the substitutions are own kernels.  Here a matrix is factored by G
+// workgroups of 8 waves that stay resident for the whole factorisation (right-looking, blocks of 16):
+//   * workgroup g owns the block columns j = g (mod G).  At block step k it waits for panel k (a flag per block column,
+//     release / acquire at device scope, bounded spin), then for each owned j > k: U_kj = inv(L_kk) A_kj (MFMA; the tile in
+//     accumulator layout is the B operand, see lu_solve_mfma_kernel) and A_ij -= L_ik U_kj for its row tiles i > k (row tile i
+//     belongs to wave i mod 8; A_ij in accumulator layout, L_ik as A operand straight from memory);
+//   * look-ahead: the owner of block column k + 1 updates that column first, factors its diagonal tile in registers (one row
+//     per lane, pivot rows by v_readlane), inverts both triangles (16 x 16), forms L_(k+1) = A inv(U) for the rows below with
+//     MFMA, publishes, and only then turns to its other columns.
+// The G workgroups of a matrix talk through ONE XCD's L2 (a device-scope release would write the whole L2 back at every block
+// step: measured, 6 ms per factorisation): a workgroup reads the XCD it landed on (HW_REG_XCC_ID) and draws a ticket from that
+// XCD's counter -- ticket t works on matrix  xcd + 8 (t / G)  as member t mod G -- so a matrix's workgroups share an L2 whatever
+// the dispatch order was.  Panels are written with plain (write-through) stores, completed (vmcnt) before the flag is raised
+// with a relaxed atomic; they are read with sc1 loads, which never hit a CU's L1.  A zero pivot raises the same flag
+// rocSOLVER's info would (the Newton loop reads it with the next residual norm); so does a partner that never shows up
+// (bounded spin): the solve is then repeated on the library path by the policy of section 3.5r3.
+constexpr int CL_W = 8, CL_SPIN = 1 << 21;
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+template <int MAXT>
+__global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* __restrict__ Aall, int64_t stride, int ne, int G,
+                                                                 double* __restrict__ dinv_all, int* __restrict__ flags_all,
+                                                                 int* __restrict__ tickets, double* __restrict__ sing_flag) {
+  __shared__ double T[16][17];   // the factored diagonal tile
+  __shared__ double IU[4][64];   // inv(U_kk) as B operand: k-step r, lane (k = q, n = c) -> element [q + 4 r][c]
+  __shared__ int s_bad, s_ticket;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, c = lane & 15;
+  const int ntile = (n + 15) / 16;
+  unsigned xcd;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
+  xcd &= 7;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&tickets[xcd * 32], 1);
+  __syncthreads();
+  const int e = (int)xcd + 8 * (s_ticket / G), g = s_ticket % G;
+  if (e >= ne) return;
+  double* A = Aall + (int64_t)e * stride;
+  double* dinv = dinv_all + (int64_t)e * ntile * 256;   // inv(L_kk) as A operand: [k][r][lane] -> element [c][q + 4 r]
+  int* flags = flags_all + (int64_t)e * ntile;
+  if (threadIdx.x == 0) s_bad = 0;
+
+  // Buffer accesses: a lane-constant offset in the VGPR, tile coordinates in the scalar offset; a lane whose row / column lies
+  // past n (last row / column tile only) gets an offset outside the descriptor: its loads return 0, its stores are dropped.
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(A, 0, (int)((int64_t)n * n * 8), 0x00020000);
+  constexpr int OOB = 0x7ffffff0;
+  const int last = ntile - 1;
+  const int vc = (q + c * n) * 8, va = (c + q * n) * 8;            // accumulator layout; A-operand layout
+  const bool c_col_ok = 16 * last + c < n, a_row_ok = 16 * last + c < n;
+  bool c_row_ok[4], a_col_ok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    c_row_ok[r] = 16 * last + q + 4 * r < n;
+    a_col_ok[r] = 16 * last + q + 4 * r < n;
+  }
+  // tile (ti, tj) in accumulator layout: register r of lane (q, c) <-> element [16 ti + q + 4 r][16 tj + c]
+  auto load_c = [&](int ti, int tj, v4f64& t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (ti < last || c_row_ok[r]) && (tj < last || c_col_ok);
+      const int soff = ((16 * ti + 4 * r) + 16 * tj * n) * 8;
+      t[r] = __builtin_bit_cast(double, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? vc : OOB, soff, 0));
+    }
+  };
+  auto store_c = [&](int ti, int tj, const v4f64& t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (ti < last || c_row_ok[r]) && (tj < last || c_col_ok);
+      const int soff = ((16 * ti + 4 * r) + 16 * tj * n) * 8;
+      const double tv = t[r];   // (bit_cast straight from the vector element stores element 0 four times)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tv), rsA, ok ? vc : OOB, soff, 0);
+    }
+  };
+  // tile (ti, tj) as A operand: k-step r of lane (m = c, k = q) <-> element [16 ti + c][16 tj + q + 4 r]
+  // (SC1 = 16: the tile was written by another workgroup of this XCD -- read it from L2, never from this CU's L1)
+  auto load_a = [&](auto sc1c, int ti, int tj, double (&a)[4]) __attribute__((always_inline)) {
+    constexpr int AUX = decltype(sc1c)::value;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (ti < last || a_row_ok) && (tj < last || a_col_ok[r]);
+      const int soff = (16 * ti + (16 * tj + 4 * r) * n) * 8;
+      a[r] = __builtin_bit_cast(double, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? va : OOB, soff, AUX));
+    }
+  };
+  using Plain = std::integral_constant<int, 0>;
+  using Sc1 = std::integral_constant<int, 16>;
+
+  // factor block column k (already updated by all earlier panels), publish it
+  auto factor_panel = [&](int k, auto from_lds) __attribute__((always_inline)) {
+    constexpr bool FROM_LDS = decltype(from_lds)::value;   // the diagonal tile is already in T (column_finish put it there)
+    // the tiles below the diagonal one: requested now, used after the diagonal tile is factored and inverted
+    double a[MAXT][4];
+#pragma unroll
+    for (int jj = 0; jj < MAXT; ++jj) {
+      const int i = w + CL_W * jj;
+      if (i > k && i < ntile) load_a(Plain{}, i, k, a[jj]);
+    }
+    if (w == 0) {
+      // diagonal tile: one row per lane (lanes 16.. repeat lanes 0..15), pivot rows by readlane
+      double r[16];
+      const int row = 16 * k + c;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int col = 16 * k + j;
+        const bool ok = row < n && col < n;
+        double v;
+        if constexpr (FROM_LDS)
+          v = T[c][j];
+        else
+          v = __builtin_bit_cast(double,
+                                 (u32x2)__builtin_amdgcn_raw_buffer_load_b64(rsA, ok ? c * 8 : OOB, (16 * k + col * n) * 8, 0));
+        r[j] = ok ? v : (c == j ? 1.0 : 0.0);
+      }
+      bool bad = false;
+#pragma unroll
+      for (int p = 0; p < 15; ++p) {
+        double pr[16];
+#pragma unroll
+        for (int j = p; j < 16; ++j) pr[j] = __shfl(r[j], p, 16);
+        bad = bad || pr[p] == 0.0;
+        if (c > p) {
+          const double l = r[p] / pr[p];
+          r[p] = l;
+#pragma unroll
+          for (int j = p + 1; j < 16; ++j) r[j] = fma(-l, pr[j], r[j]);
+        }
+      }
+      bad = bad || __shfl(r[15], 15, 16) == 0.0;
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          T[c][j] = r[j];
+          const int col = 16 * k + j;
+          const double rv = r[j];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, rv), rsA, (row < n && col < n) ? c * 8 : OOB,
+                                                (16 * k + col * n) * 8, 0);
+        }
+      }
+      if (bad && lane == 0) s_bad = 1;
+    }
+    __syncthreads();
+    // inverses of the two triangles, on two different waves (in one wave the two branches would run one after the other:
+    // measured 4.5 us of a 17.5 us block step): thread cc < 16 column cc of inv(L) (unit lower), thread 64 + cc column cc of inv(U)
+    if ((threadIdx.x & ~64) < 16) {
+      const int cc = threadIdx.x & 15;
+      double x[16];
+      if (threadIdx.x < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          double sacc = i == cc ? 1.0 : 0.0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j < i) sacc = fma(-T[i][j], x[j], sacc);
+          x[i] = sacc;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dinv[k * 256 + (cc >> 2) * 64 + (cc & 3) * 16 + i] = x[i];   // element [i][cc], A-operand order
+      } else {
+        double rd[16];   // the 16 divisions up front, side by side, instead of one at the end of every row's dependent chain
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rd[i] = 1.0 / T[i][i];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii) {
+          const int i = 15 - ii;
+          double sacc = i == cc ? 1.0 : 0.0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j > i) sacc = fma(-T[i][j], x[j], sacc);
+          x[i] = sacc * rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) IU[i >> 2][(i & 3) * 16 + cc] = x[i];   // element [i][cc], B-operand order
+      }
+    }
+    __syncthreads();
+    // L_ik = A_ik inv(U_kk) for the row tiles below
+    double bu[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bu[r] = IU[r][lane];
+#pragma unroll
+    for (int jj = 0; jj < MAXT; ++jj) {
+      const int i = w + CL_W * jj;
+      if (i > k && i < ntile) {
+        v4f64 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jj][r], bu[r], y, 0, 0, 0);
+        store_c(i, k, y);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's panel stores are in L2 ...
+    __syncthreads();                                      // ... and every other wave's
+    if (threadIdx.x == 0) {
+      if (s_bad) *sing_flag = 1.0;
+      __hip_atomic_store(&flags[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  // block column j takes the update of panel k (and its rows of U)
+  // block column j takes the update of panel k (and its rows of U), in two halves: this workgroup's own tiles can be
+  // requested BEFORE panel k is known to be ready
+  auto column_load_own = [&](int k, int j, v4f64& t, v4f64 (&acc)[MAXT]) __attribute__((always_inline)) {
+    load_c(k, j, t);
+#pragma unroll
+    for (int jj = 0; jj < MAXT; ++jj) {
+      const int i = w + CL_W * jj;
+      if (i > k && i < ntile) load_c(i, j, acc[jj]);
+    }
+  };
+  auto column_finish = [&](int k, int j, const double (&il)[4], const v4f64& t, v4f64 (&acc)[MAXT]) __attribute__((always_inline)) {
+    double a[MAXT][4];
+#pragma unroll
+    for (int jj = 0; jj < MAXT; ++jj) {
+      const int i = w + CL_W * jj;
+      if (i > k && i < ntile) load_a(Sc1{}, i, k, a[jj]);
+    }
+    v4f64 u = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u = __builtin_amdgcn_mfma_f64_16x16x4f64(il[r], t[r], u, 0, 0, 0);
+    const v4f64 un = -u;
+#pragma unroll
+    for (int jj = 0; jj < MAXT; ++jj) {
+      const int i = w + CL_W * jj;
+      if (i > k && i < ntile) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jj][r], un[r], acc[jj], 0, 0, 0);
+        store_c(i, j, acc[jj]);
+        if (j == k + 1 && i == k + 1) {   // the next diagonal tile: handed to factor_panel through LDS
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[q + 4 * r][c] = acc[jj][r];
+        }
+      }
+    }
+    __syncthreads();   // every wave has read A_kj before it becomes U_kj
+    if (w == 0) store_c(k, j, u);
+  };
+
+  __syncthreads();
+  if (g == 0) factor_panel(0, std::false_type{});
+  for (int k = 0; k + 1 < ntile; ++k) {
+    // owned block columns j > k, ascending: the first one is k + 1 when this workgroup owns it (look-ahead)
+    int j = k + 1 + ((g - (k + 1)) % G + G) % G;
+    v4f64 t, acc[MAXT];
+    if (j < ntile) column_load_own(k, j, t, acc);
+    // wait for panel k
+    if (g != k % G) {
+      if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > CL_SPIN) {
+            *sing_flag = 1.0;   // a lost partner: report the solve as failed rather than hang
+            s_bad = 2;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (s_bad == 2) return;
+    }
+    double il[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) il[r] = ld_sc1(&dinv[k * 256 + r * 64 + lane]);
+    for (; j < ntile; j += G) {
+      column_finish(k, j, il, t, acc);
+      if (j == k + 1) {
+        __syncthreads();
+        factor_panel(k + 1, std::true_type{});
+      }
+      if (j + G < ntile) column_load_own(k, j + G, t, acc);
+    }
+  }
+}
+
+// every matrix's last panel flag must be up: a part with another XCD count / dispatch order than the ticket scheme assumes
+// leaves matrices without workers -- reported like a singular block (the solve is then repeated on the library path)
+__global__ void lu_npvt_done_kernel(const int* __restrict__ flags, int ne, int ntile, double* __restrict__ sing_flag) {
+  bool bad = false;
+  for (int e = threadIdx.x; e < ne; e += 64) bad = bad || flags[(int64_t)e * ntile + ntile - 1] != 1;
+  if (__any(bad) && threadIdx.x == 0) *sing_flag = 1.0;
+}
+
+static void lu_npvt_coop(hipStream_t stream, int nb, int ne, int G, double* De, int64_t st, double* dinv, int* flags,
+                         double* sing_flag) {
+  // flags: [0, 256) the per-XCD ticket counters (one per 128 bytes), then ne x ntile panel flags
+  const int ntile = (nb + 15) / 16, maxt = (ntile + CL_W - 1) / CL_W;
+  (void)hipMemsetAsync(flags, 0, sizeof(int) * (256 + (size_t)ne * ntile), stream);
+  int* tickets = flags;
+  flags += 256;
+  const dim3 grid(8 * ((ne + 7) / 8) * G), block(64 * CL_W);
+  if (maxt <= 2)
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<2>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+  else if (maxt <= 4)
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<4>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+  else if (maxt <= 5)
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<5>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+  else
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<6>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+  hipLaunchKernelGGL(lu_npvt_done_kernel, dim3(1), dim3(64), 0, stream, (const int*)flags, ne, ntile, sing_flag);
 }
 
 // y_e -= A_e x_e for a batch of dense n x n blocks (column-major): the right-hand-side updates of the reduction levels and the
@@ -2030,9 +2339,94 @@ static int block_solve_bcr(FemBE* fb) {
     } else if (!banded) {
       fb->used_npvt = true;
       ++fb->npvt_levels;
+      if (fb->own_getrf && nb <= TS_NMAX && ne <= 32) {
+        // G cooperating workgroups per matrix, all resident: 8 * ceil(ne / 8) * G <= 256
+        static const int g_over = [] {
+          const char* v = getenv("PFHIP_FEM_LU_G");   // A/B: workgroups per matrix (<= 256 / (8 ceil(ne / 8)))
+          return v ? atoi(v) : 0;
+        }();
+        int G = ne <= 16 ? 16 : 8;   // (32 per matrix for ne <= 8 is slower: more pollers of the same flags)
+        if (g_over > 0 && g_over < G) G = g_over;
+        static const bool check = [] {
+          const char* v = getenv("PFHIP_FEM_GETRF");
+          return v && std::string(v) == "check";
+        }();
+        std::vector<double> ref, mine;
+        if (check) {   // DEBUG: the same batch through rocSOLVER, compared entry by entry on the host
+          double* tmp = nullptr;
+          FB_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)ne * bs));
+          FB_HIP(hipMemcpy2DAsync(tmp, sizeof(double) * bs, De, sizeof(double) * st, sizeof(double) * bs, ne,
+                                  hipMemcpyDeviceToDevice, fb->stream));
+          FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, tmp, nb, bs, fb->info, ne));
+          ref.resize((size_t)ne * bs);
+          FB_HIP(hipMemcpyAsync(ref.data(), tmp, sizeof(double) * ref.size(), hipMemcpyDeviceToHost, fb->stream));
+          FB_HIP(hipStreamSynchronize(fb->stream));
+          FB_HIP(hipFree(tmp));
+        }
+        lu_npvt_coop(fb->stream, nb, ne, G < (nb + 15) / 16 ? G : (nb + 15) / 16, De, st, fb->tinv, fb->tflags, fb->scal + 3);
+        FB_HIP(hipGetLastError());
+        if (check) {
+          mine.resize((size_t)ne * bs);
+          FB_HIP(hipMemcpy2DAsync(mine.data(), sizeof(double) * bs, De, sizeof(double) * st, sizeof(double) * bs, ne,
+                                  hipMemcpyDeviceToHost, fb->stream));
+          double flag = 0.0;
+          FB_HIP(hipMemcpyAsync(&flag, fb->scal + 3, sizeof(double), hipMemcpyDeviceToHost, fb->stream));
+          FB_HIP(hipStreamSynchronize(fb->stream));
+          double md = 0.0, mr = 0.0;
+          size_t at = 0;
+          for (size_t i2 = 0; i2 < ref.size(); ++i2) {
+            const double d = std::fabs(ref[i2] - mine[i2]);
+            if (!(d <= md)) {
+              md = d;
+              at = i2;
+            }
+            mr = std::fmax(mr, std::fabs(ref[i2]));
+          }
+          {
+            size_t nbad = 0, first = (size_t)-1;
+            for (size_t i2 = 0; i2 < (size_t)bs; ++i2) {
+              const double d = std::fabs(ref[i2] - mine[i2]);
+              if (!(d <= 1e-9 * (1.0 + std::fabs(ref[i2])))) {
+                if (first == (size_t)-1) first = i2;
+                ++nbad;
+              }
+            }
+            if (first != (size_t)-1)
+              fprintf(stderr, "[fem_be]   matrix 0: %zu bad entries, first at row %zu col %zu: ref %.6e mine %.6e\n", nbad,
+                      first % (size_t)nb, first / (size_t)nb, ref[first], mine[first]);
+            for (int col = 0; col < 16; col += 5) {
+              fprintf(stderr, "[fem_be]   col %d bad rows:", col);
+              int shown = 0;
+              for (int row = 0; row < nb && shown < 48; ++row) {
+                const size_t i2 = (size_t)row + (size_t)col * nb;
+                const double d = std::fabs(ref[i2] - mine[i2]);
+                if (!(d <= 1e-9 * (1.0 + std::fabs(ref[i2])))) {
+                  fprintf(stderr, " %d", row);
+                  ++shown;
+                }
+              }
+              fprintf(stderr, "\n");
+            }
+            // per block column: count of bad entries above / on+below the diagonal block
+            for (int tj = 0; tj < (nb + 15) / 16 && tj < 6; ++tj) {
+              size_t up = 0, dn = 0;
+              for (int col = 16 * tj; col < 16 * tj + 16 && col < nb; ++col)
+                for (int row = 0; row < nb; ++row) {
+                  const size_t i2 = (size_t)row + (size_t)col * nb;
+                  const double d = std::fabs(ref[i2] - mine[i2]);
+                  if (!(d <= 1e-9 * (1.0 + std::fabs(ref[i2])))) (row < 16 * tj ? up : dn)++;
+                }
+              fprintf(stderr, "[fem_be]   block column %d: bad above %zu, on/below %zu\n", tj, up, dn);
+            }
+          }
+          fprintf(stderr, "[fem_be] getrf check: ne %d G %d max|diff| %.3e (matrix %zu row %zu col %zu) max|ref| %.3e flag %g\n", ne,
+                  G, md, at / (size_t)bs, (at % (size_t)bs) % (size_t)nb, (at % (size_t)bs) / (size_t)nb, mr, flag);
+        }
+      } else {
       FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, De, nb, st, fb->info, ne));
       // an exactly singular leading minor: raise the flag the Newton loop reads with the next residual norm
       hipLaunchKernelGGL(info_flag_kernel, dim3(1), dim3(64), 0, fb->stream, (const rocblas_int*)fb->info, ne, fb->scal + 3);
+      }
       if (fb->own_trsm && nb <= TS_NMAX) {
         lu_solve_level(fb->stream, nb, ne, De, st, nullptr, 0, fb->tinv, nullptr, Xu, Xl, xr, sv);
         FB_HIP(hipGetLastError());
@@ -2112,7 +2506,13 @@ static int block_solve_bcr(FemBE* fb) {
     m = nk;
     set = 1 - set;
   }
-  if (fb->pivot_mode != 0) {  // the last block: always with row exchanges unless they are switched off altogether
+  if (fb->pivot_mode == 2 && !fb->force_pivot && fb->own_getrf && fb->own_trsm && nb >= 400 && nb <= TS_NMAX) {
+    // the last block under the optimistic policy: like the small batches before it (36 panel launches of 45 us otherwise)
+    fb->used_npvt = true;
+    lu_npvt_coop(fb->stream, nb, 1, 16 < (nb + 15) / 16 ? 16 : (nb + 15) / 16, fb->D, bs, fb->tinv, fb->tflags, fb->scal + 3);
+    lu_solve_level(fb->stream, nb, 1, fb->D, bs, nullptr, 0, fb->tinv, nullptr, nullptr, nullptr, fb->rhs, nb, true);
+    FB_HIP(hipGetLastError());
+  } else if (fb->pivot_mode != 0) {  // the last block: with row exchanges unless they are switched off altogether
     FB_BLAS(rocsolver_dgetrf(fb->bh, nb, nb, fb->D, nb, fb->piv, fb->info));
     FB_BLAS(rocsolver_dgetrs(fb->bh, rocblas_operation_none, nb, 1, fb->D, nb, fb->piv, fb->rhs, nb));
   } else {

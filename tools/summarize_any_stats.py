@@ -24,6 +24,9 @@ if len(sys.argv) > 3:
             if key in r["Kernel_Name"]:
                 g = (int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1))
                 groups.setdefault(g, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        seq = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                     for r in csv.DictReader(open(tr[-1])) if key in r["Kernel_Name"])
+        print("first launches of *%s* in order, us: %s" % (key, " ".join("%.0f" % d for _, d in seq[:21])))
         print("launches of *%s* by grid (workgroups x, y): calls, average us" % key)
         for g in sorted(groups, key=lambda t: -t[1]):
             v = groups[g]
