@@ -2001,12 +2001,15 @@ __global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* 
   // factor block column k (already updated by all earlier panels), publish it
   auto factor_panel = [&](int k, auto from_lds) __attribute__((always_inline)) {
     constexpr bool FROM_LDS = decltype(from_lds)::value;   // the diagonal tile is already in T (column_finish put it there)
-    // the tiles below the diagonal one: requested now, used after the diagonal tile is factored and inverted
+    // the tiles below the diagonal one: requested now, used after the diagonal tile is factored and inverted (wave 0, whose
+    // registers the elimination needs, asks for its tiles after that, ahead of the inverses)
     double a[MAXT][4];
+    if (w != 0) {
 #pragma unroll
-    for (int jj = 0; jj < MAXT; ++jj) {
-      const int i = w + CL_W * jj;
-      if (i > k && i < ntile) load_a(Plain{}, i, k, a[jj]);
+      for (int jj = 0; jj < MAXT; ++jj) {
+        const int i = w + CL_W * jj;
+        if (i > k && i < ntile) load_a(Plain{}, i, k, a[jj]);
+      }
     }
     if (w == 0) {
       // diagonal tile: one row per lane (lanes 16.. repeat lanes 0..15), pivot rows by readlane
@@ -2052,6 +2055,13 @@ __global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* 
       if (bad && lane == 0) s_bad = 1;
     }
     __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int jj = 0; jj < MAXT; ++jj) {
+        const int i = CL_W * jj;
+        if (i > k && i < ntile) load_a(Plain{}, i, k, a[jj]);
+      }
+    }
     // inverses of the two triangles, on two different waves (in one wave the two branches would run one after the other:
     // measured 4.5 us of a 17.5 us block step): thread cc < 16 column cc of inv(L) (unit lower), thread 64 + cc column cc of inv(U)
     if ((threadIdx.x & ~64) < 16) {
