@@ -1148,6 +1148,43 @@ def test_fem_be_pivot_policies_agree_at_production_block_sizes(lib, golden_dir, 
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("model,n", [("bm2", 68), ("bm2", 75), ("bm2", 101), ("bm2", 120), ("bm3", 201), ("bm3", 260), ("bm3", 351)])
+def test_fem_be_own_dense_kernels_match_the_library_path(lib, monkeypatch, model, n):
+    """The dense reduction levels on the repository's kernels (lu_npvt_coop_kernel: cooperative un-pivoted LU,
+    lu_solve_mfma_kernel: both substitutions on fp64 MFMA tiles, gemv_sub_kernel) against the same solve on rocSOLVER /
+    rocBLAS (PFHIP_FEM_GETRF=rocsolver PFHIP_FEM_TRSM=rocblas PFHIP_FEM_GEMV=rocblas), at block sizes that exercise ragged
+    last tiles and every instantiation in use: 6 x 69 = 414, 6 x 76 = 456, 606, 6 x 121 = 726 (BM2), 2 x 202 = 404, 522, 702
+    (BM3) unknowns per block -- 26..46 tiles of 16, i.e. 4, 5 and 6 tiles per wave.  Same Newton iteration counts, fields
+    within 1e-10, one attempt per step (no factorisation reported singular, no partner lost).  The reference side of the
+    computation is dolfin/bench2.py:126-158 / bench3.py:111-140 (one Newton solve per backward-Euler step)."""
+    kw = dict(_bm23(model))
+    kw["n"] = n
+    kw["h"] = (200.0 if model == "bm2" else 960.0) / (n - 1)
+    names = ("c", "mu", "eta1", "eta4") if model == "bm2" else ("U", "phi")
+    dts = (0.01, 0.02, 0.04) if model == "bm2" else (0.1, 0.2, 0.4)
+    out = {}
+    for mode in ("own", "library"):
+        for k in ("PFHIP_FEM_GETRF", "PFHIP_FEM_TRSM", "PFHIP_FEM_GEMV"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "library":
+            monkeypatch.setenv("PFHIP_FEM_GETRF", "rocsolver")
+            monkeypatch.setenv("PFHIP_FEM_TRSM", "rocblas")
+            monkeypatch.setenv("PFHIP_FEM_GEMV", "rocblas")
+        with PhaseFieldSolver(**kw) as s:
+            (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+            its = []
+            for dt in dts:
+                ok, _, _ = s.step(dt, 1, check=True)
+                assert ok, (mode, dt)
+                assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1, (mode, dt)
+                assert s.stat(L.PF_STAT_FEM_NPVT_LEVELS) >= 3, (mode, dt)      # the branch under test was taken
+                its.append(s.last_iters)
+            out[mode] = (its, [s.get_field(k) for k in names])
+    assert out["own"][0] == out["library"][0], (out["own"][0], out["library"][0])
+    for a, b in zip(out["own"][1], out["library"][1]):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+
+
 def test_fem_be_failed_unpivoted_solve_is_repeated_with_row_exchanges(lib, monkeypatch):
     """fembe_step's safety net, reached on purpose: PFHIP_FEM_TEST_POISON_NPVT=1 (test-only switch) spoils the first Newton
     direction of any attempt that contained an un-pivoted factorisation.  The step must then (i) restore the state,
