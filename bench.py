@@ -384,12 +384,12 @@ def workload_table(workload, world):
         # bench3.py:63-97), streaming LDS-tiled kernels (csrc/multi_fd.hip).  Algorithmic bytes per cell-update = every field
         # read once and written once: BM2 5 fields = 80 B, BM3 2 fields = 32 B (BM2's separate mu pass moves 136 B: the
         # roofline figure is still quoted against 80)
-        if world > 1:
-            sys.exit("%s is single-GPU" % workload)
+        # N > 1 (or --slab): a ring of 512 x 512 x 512 slabs (weak scaling), every field's ghost planes refreshed before each
+        # step (MultiFieldSlabSolver; no interior / boundary overlap)
         if workload.startswith("bm2"):
-            w.update(model="bm2", bytes_per_cell=80.0, gn=(512, 512, 512), dt=2e-4)
+            w.update(model="bm2", bytes_per_cell=80.0, gn=(512, 512, 512 * world), dt=2e-4)
         else:
-            w.update(model="bm3", bytes_per_cell=32.0, gn=(512, 512, 512), dt=2e-3)
+            w.update(model="bm3", bytes_per_cell=32.0, gn=(512, 512, 512 * world), dt=2e-3)
     elif workload == "bm1_fd_512s":
         w.update(dim=2, gn=(512, 512, 1), dt=1e-3)
     elif workload == "bm1_fd_512c":
@@ -431,6 +431,11 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
             eng = HipFFTSlabEngine(gn, h, world, rank, local_rank, scheme=scheme, model=model, eliminate_phi=elim)
             (eng.set_ic_bm6 if model == "bm6" else eng.set_ic_bm1)()
             solver = FFTSlabSolver(eng)
+        elif model in ("bm2", "bm3"):
+            from pfhubbenchmarks_amd.solver import HipMultiFieldSlabEngine, MultiFieldSlabSolver
+            eng = HipMultiFieldSlabEngine(model, gn, h, world, rank, local_rank)
+            eng.set_ic()
+            solver = MultiFieldSlabSolver(eng)
         else:
             wide = a.halo == "wide" and not a.fused_slab and gn[2] // world >= 4     # the smallest slab: same answer on every rank
             eng = HipSlabEngine(gn, h, world, rank, local_rank, wide=wide)
@@ -550,7 +555,9 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
         "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "grid": list(gn), "dt": dt, "h": h, "scheme": "fd-explicit" if scheme == "fd" else "spectral-semi-implicit",
-                   "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": "PFHub BM1 (pfbase.py:187-189), z-extruded",
+                   "kernel": a.kernel, "variant": a.variant, "target_wgs": a.target_wgs, "ic": {"bm1": "PFHub BM1 (pfbase.py:187-189), z-extruded", "bm6": "PFHub BM6 (pfbase.py:217-219), z-extruded",
+                                                                                             "bm2": "PFHub BM2 (pfbase.py:268-296), z-extruded",
+                                                                                             "bm3": "PFHub BM3 (pfbase.py:298-320), z-extruded"}[model],
                    "parallelism": "slab%d%s%s%s%s" % (world, "-forced" if a.slab else "", "-REHEARSAL-one-device-gloo" if rehearsal else "",
                                                     ("-ipc-fused" if a.fused_slab else "-ipc")
                                                     if (dist is not None and a.transport == "ipc") else "",

@@ -66,8 +66,8 @@ enum {
 enum {
   PF_MODEL_BM1 = 1,
   PF_MODEL_BM6 = 6,
-  PF_MODEL_BM2 = 2, /* Ostwald ripening: Cahn-Hilliard + 4 Allen-Cahn fields (dolfin/bench2.py); PF_SCHEME_FEM_BE only */
-  PF_MODEL_BM3 = 3  /* dendritic growth: heat diffusion + Allen-Cahn (dolfin/bench3.py);          PF_SCHEME_FEM_BE only */
+  PF_MODEL_BM2 = 2, /* Ostwald ripening: Cahn-Hilliard + 4 Allen-Cahn fields (dolfin/bench2.py); PF_SCHEME_FEM_BE or _FD_EXPLICIT */
+  PF_MODEL_BM3 = 3  /* dendritic growth: heat diffusion + Allen-Cahn (dolfin/bench3.py);          PF_SCHEME_FEM_BE or _FD_EXPLICIT */
 };
 enum {
   PF_FIELD_C = 0,
@@ -249,6 +249,14 @@ int pf_sync(pf_handle* h);
  * planes described by pf_halo_layout on its own stream and makes the handle's stream wait for it ->
  * finish (boundary planes + buffer swap). */
 int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
+/* BM2 / BM3 explicit FD in slab mode (PF_SCHEME_FD_EXPLICIT, nranks > 1 or force_slab, dim 3, periodic box): the ghost planes
+ * of field `field` (0 .. nf-1: BM2 c, eta1..4; BM3 U, phi -- dolfin/bench2.py:76-113, bench3.py:63-97 are the equations) in
+ * the CURRENT time level, ghost = 2 (BM2: c reaches through mu) or 1 (BM3) per side, the slabs a ring.  Protocol per step:
+ * refresh the ghost planes of EVERY field from the two ring neighbours, then pf_step(h, dt, 1, info); the layout moves to
+ * the other time level with each step (cur_index).  With pf_config.ext_c the two time levels live in caller-owned buffers
+ * of pf_field_elems_with_ghosts() doubles each (all fields, field-major), so a communication library can send / receive
+ * the planes in place.  Results are bit-identical to the single-GPU box. */
+int pf_field_halo_layout(pf_handle* h, int field, pf_halo_layout* out);
 int pf_step_begin(pf_handle* h, double dt);
 int pf_step_finish(pf_handle* h);
 /* Launch the boundary strips of pf_step_finish on `stream` instead of the handle's stream (NULL = back to the handle's

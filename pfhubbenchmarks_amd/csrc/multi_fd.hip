@@ -25,6 +25,7 @@ namespace {
 
 struct MfdParams {
   int model, nf, nx, ny, nz;
+  int gz;   // slab mode: ghost planes per side inside nz (refreshed by the caller before every step); diagnostics skip them
   double inv_h2;
   // BM2: ca, cb, rho2, kappa_c, M, kappa_eta, w, alpha, L     BM3: lam, 1/tau, W^2, D
   double q[9];
@@ -544,8 +545,9 @@ __global__ __launch_bounds__(256) void mfd_diag_kernel(const MfdParams p, const 
                                                        double* __restrict__ partials) {
   __shared__ double sh[5][4];
   const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
+  const int64_t own0 = (int64_t)p.nx * p.ny * p.gz, own1 = cells - own0;   // owned cells (all of them unless slab mode)
   double v[5] = {0.0, 0.0, 0.0, INFINITY, -INFINITY};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = own0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < own1; i += (int64_t)gridDim.x * 256) {
     const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
     if (p.model == 2) {
       const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3], ke = p.q[5], w = p.q[6], al = p.q[7];
@@ -664,6 +666,7 @@ struct MultiFD {
   double *partials = nullptr, *out5 = nullptr, *out5_host = nullptr;
   int cur = 0;
   bool have_prev = false;
+  bool own_u = true;
   hipStream_t stream = nullptr;
   std::string err;
 };
@@ -681,8 +684,8 @@ const char* multifd_error(const MultiFD* mf) { return mf->err.c_str(); }
 int multifd_nfields(const MultiFD* mf) { return mf->p.nf; }
 
 // model 2: mp = {c_alpha, c_beta, rho, kappa_c, M, kappa_eta, w, alpha, L}; model 3: mp = {W0, tau0, D, Delta}
-int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, const double* mp, hipStream_t stream,
-                   std::string* err) {
+int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, double h, const double* mp, double* ext0,
+                   double* ext1, hipStream_t stream, std::string* err) {
   MultiFD* mf = new MultiFD();
   *out = mf;
   MfdParams& p = mf->p;
@@ -691,6 +694,7 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, c
   p.nx = nx;
   p.ny = ny;
   p.nz = nz;
+  p.gz = gz;
   p.inv_h2 = 1.0 / (h * h);
   for (double& q : p.q) q = 0.0;
   if (model == 2) {
@@ -707,8 +711,14 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, c
   mf->stream = stream;
   auto body = [&]() -> int {
     const size_t bytes = sizeof(double) * (size_t)mf->cells * p.nf;
-    MF_HIP(hipMalloc(&mf->u[0], bytes));
-    MF_HIP(hipMalloc(&mf->u[1], bytes));
+    if (ext0 && ext1) {
+      mf->u[0] = ext0;
+      mf->u[1] = ext1;
+      mf->own_u = false;
+    } else {
+      MF_HIP(hipMalloc(&mf->u[0], bytes));
+      MF_HIP(hipMalloc(&mf->u[1], bytes));
+    }
     MF_HIP(hipMemsetAsync(mf->u[0], 0, bytes, stream));
     MF_HIP(hipMemsetAsync(mf->u[1], 0, bytes, stream));
     if (model == 2) MF_HIP(hipMalloc(&mf->mu, sizeof(double) * (size_t)mf->cells));
@@ -727,6 +737,7 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, c
 
 void multifd_destroy(MultiFD* mf) {
   if (!mf) return;
+  if (!mf->own_u) mf->u[0] = mf->u[1] = nullptr;
   for (void* q : {(void*)mf->u[0], (void*)mf->u[1], (void*)mf->mu, (void*)mf->partials, (void*)mf->out5})
     if (q) (void)hipFree(q);
   if (mf->out5_host) (void)hipHostFree(mf->out5_host);
@@ -744,7 +755,11 @@ int multifd_set_ic(MultiFD* mf, int mnx, int mny, const double* a) {
   return 0;
 }
 
-double* multifd_field_ptr(MultiFD* mf, int f) { return mf->u[mf->cur] + (int64_t)f * mf->cells; }
+double* multifd_field_base(MultiFD* mf, int f) { return mf->u[mf->cur] + (int64_t)f * mf->cells; }
+int multifd_cur_index(const MultiFD* mf) { return mf->cur; }
+double* multifd_field_ptr(MultiFD* mf, int f) {   // the owned planes
+  return mf->u[mf->cur] + (int64_t)f * mf->cells + (int64_t)mf->p.gz * mf->p.nx * mf->p.ny;
+}
 void multifd_touch(MultiFD* mf) { mf->have_prev = false; }
 
 namespace {

@@ -57,6 +57,20 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
       if (err) *err = "slab decomposition is implemented for dim == 3 only";
       return (int)PF_ERR_UNSUPPORTED;
     }
+    const bool mfd = cfg->scheme == PF_SCHEME_FD_EXPLICIT && (cfg->model == PF_MODEL_BM2 || cfg->model == PF_MODEL_BM3);
+    if (mfd) {
+      // BM2 / BM3 explicit FD: a ring of slabs, every field with `ghost` planes per side that the caller refreshes before
+      // each step (pf_field_halo_layout); ghost = the step's reach along z: 2 for BM2 (c through mu), 1 for BM3
+      if (g->mirror) {
+        if (err) *err = "BM2 / BM3 explicit FD in slab mode: periodic boxes only";
+        return (int)PF_ERR_UNSUPPORTED;
+      }
+      g->ghost = cfg->model == PF_MODEL_BM2 ? 2 : 1;
+      if (g->nzg < 2 * g->ghost * cfg->nranks) return bad("need >= 2 x ghost planes per rank");
+      pf_slab_partition(g->nzg, cfg->nranks, cfg->rank, &g->z0, &g->nz);
+      g->zwrap = 0;
+      return PF_OK;
+    }
     if (g->mirror) {
       // a line of slabs over the PHYSICAL planes: no even extension along z, the two wall ranks mirror their own planes
       // into the ghost layers (launch_reflect_ghosts) instead of receiving them
@@ -484,7 +498,8 @@ int pf_slab_partition(int n_planes, int nranks, int rank, int* first, int* count
 int64_t pf_field_elems_with_ghosts(const pf_config* cfg) {
   Geometry g;
   if (resolve(cfg, &g, nullptr) != PF_OK) return PF_ERR_INVALID;
-  return g.plane * (int64_t)(g.nz + 2 * g.ghost);
+  const int nf = cfg->scheme == PF_SCHEME_FD_EXPLICIT ? (cfg->model == PF_MODEL_BM2 ? 5 : (cfg->model == PF_MODEL_BM3 ? 2 : 1)) : 1;
+  return nf * g.plane * (int64_t)(g.nz + 2 * g.ghost);   // BM2 / BM3 explicit FD: all fields of a time level, field-major
 }
 
 int64_t pf_ext_buffer_offset(const pf_config* cfg, int which) {
@@ -513,8 +528,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   if (cfg->model != PF_MODEL_BM1 && cfg->model != PF_MODEL_BM6 && !multi) return fail(nullptr, PF_ERR_INVALID, "bad model");
   if (multi && cfg->scheme != PF_SCHEME_FEM_BE && cfg->scheme != PF_SCHEME_FD_EXPLICIT)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3: PF_SCHEME_FEM_BE (parity mode) or PF_SCHEME_FD_EXPLICIT");
-  if (multi && cfg->scheme == PF_SCHEME_FD_EXPLICIT && (cfg->nranks != 1 || cfg->force_slab == 1))
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3 with the FD scheme: one GPU (replicas only)");
+  if (multi && cfg->scheme == PF_SCHEME_FD_EXPLICIT && (cfg->nranks != 1 || cfg->force_slab == 1) && cfg->dim != 3)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "PF_MODEL_BM2 / PF_MODEL_BM3 with the FD scheme in slab mode: 3-D boxes");
   if (cfg->scheme != PF_SCHEME_FD_EXPLICIT && cfg->scheme != PF_SCHEME_SPECTRAL_SI && cfg->scheme != PF_SCHEME_FEM_BE)
     return fail(nullptr, PF_ERR_INVALID, "bad scheme");
   if (cfg->scheme == PF_SCHEME_FEM_BE &&
@@ -572,7 +587,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->own_stream = true;
   }
   const int64_t elems = g.plane * (int64_t)(g.nz + 2 * g.ghost);
-  if (cfg->ext_c[0]) {
+  const bool mfd = multi && cfg->scheme == PF_SCHEME_FD_EXPLICIT;
+  if (cfg->ext_c[0] && !mfd) {
     h->c[0] = cfg->ext_c[0];
     h->c[1] = cfg->ext_c[1];
   } else {
@@ -617,7 +633,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     } else {
       for (int i = 0; i < 4; ++i) mp[i] = cfg->model_params[i];
     }
-    if (multifd_create(&h->mf, cfg->model == PF_MODEL_BM2 ? 2 : 3, g.nx, g.ny, g.nz, cfg->h, mp, h->stream, &h->err) != 0)
+    if (multifd_create(&h->mf, cfg->model == PF_MODEL_BM2 ? 2 : 3, g.nx, g.ny, g.nz + 2 * g.ghost, g.ghost, cfg->h, mp,
+                       cfg->ext_c[0], cfg->ext_c[1], h->stream, &h->err) != 0)
       return bail(PF_ERR_HIP);
   } else if (cfg->model == PF_MODEL_BM6 && slab_fft) {
     if (cfg->ext_phi) {
@@ -934,7 +951,9 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   RoctxRange roctx_("pf_step");
   if (!h) return PF_ERR_INVALID;
   if (nsteps < 0 || !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step: need dt > 0 and nsteps >= 0");
-  if (h->g.ghost != 0) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
+  if (h->g.ghost != 0 && !h->mf) return fail(h, PF_ERR_STATE, "pf_step: slab mode uses pf_step_begin / pf_step_finish");
+  if (h->mf && h->g.ghost != 0 && nsteps > 1)
+    return fail(h, PF_ERR_STATE, "pf_step: BM2 / BM3 slabs take ONE step per ghost refresh (pf_field_halo_layout)");
   if (h->mf) {
     if (multifd_step(h->mf, dt, nsteps) != 0) return fail(h, PF_ERR_HIP, multifd_error(h->mf));
     if (info) {  // blow-up guard: every field finite and inside a generous band
@@ -1062,6 +1081,27 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out) {
   out->rank_hi = (g.zends & 2) ? -1 : (h->cfg.rank + 1) % h->cfg.nranks;
   out->cur_index = h->cur;
   out->needs_exchange = (h->wide && h->wide_phase == 1) ? 0 : 1;
+  return PF_OK;
+}
+
+int pf_field_halo_layout(pf_handle* h, int field, pf_halo_layout* out) {
+  if (!h || !out) return PF_ERR_INVALID;
+  const Geometry& g = h->g;
+  if (!h->mf) return fail(h, PF_ERR_STATE, "pf_field_halo_layout: BM2 / BM3 explicit FD handles only (else pf_halo_layout_get)");
+  if (g.ghost == 0) return fail(h, PF_ERR_STATE, "no ghost planes (nranks == 1)");
+  if (field < 0 || field >= multifd_nfields(h->mf)) return fail(h, PF_ERR_INVALID, "pf_field_halo_layout: field index 0 .. nf - 1");
+  out->base = multifd_field_base(h->mf, field);
+  out->plane_elems = g.plane;
+  out->ghost = g.ghost;
+  out->n_local = g.nz;
+  out->recv_lo_off = 0;
+  out->send_lo_off = (int64_t)g.ghost * g.plane;
+  out->send_hi_off = (int64_t)g.nz * g.plane;
+  out->recv_hi_off = (int64_t)(g.nz + g.ghost) * g.plane;
+  out->rank_lo = (h->cfg.rank + h->cfg.nranks - 1) % h->cfg.nranks;
+  out->rank_hi = (h->cfg.rank + 1) % h->cfg.nranks;
+  out->cur_index = multifd_cur_index(h->mf);
+  out->needs_exchange = 1;
   return PF_OK;
 }
 

@@ -185,11 +185,15 @@ const char* fembe_error(const FemBE* fb);
 
 // explicit finite-difference schemes of the multi-field benchmarks BM2 / BM3 (multi_fd.hip)
 struct MultiFD;
-int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, double h, const double* mp, hipStream_t stream,
-                   std::string* err);
+// gz > 0 (slab mode): nz INCLUDES gz ghost planes per side, refreshed by the caller before every step; ext0 / ext1: optional
+// caller-owned buffers for the two time levels (nf x nx x ny x nz doubles each, field-major)
+int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, double h, const double* mp, double* ext0,
+                   double* ext1, hipStream_t stream, std::string* err);
 void multifd_destroy(MultiFD* mf);
 int multifd_nfields(const MultiFD* mf);
 int multifd_set_ic(MultiFD* mf, int mnx, int mny, const double* a);
+double* multifd_field_base(MultiFD* mf, int f);  // ... including its ghost planes (slab mode)
+int multifd_cur_index(const MultiFD* mf);
 double* multifd_field_ptr(MultiFD* mf, int f);  // device pointer of field f of the current time level (lattice, no ghosts)
 void multifd_touch(MultiFD* mf);                // a field was overwritten: no rollback state
 int multifd_step(MultiFD* mf, double dt, int nsteps);

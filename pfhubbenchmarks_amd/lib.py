@@ -93,6 +93,7 @@ SYMBOLS = {
     "pf_set_mean_c": (C.c_int, [_H, C.c_double]),
     "pf_sync": (C.c_int, [_H]),
     "pf_halo_layout_get": (C.c_int, [_H, C.POINTER(PfHaloLayout)]),
+    "pf_field_halo_layout": (C.c_int, [_H, C.c_int, C.POINTER(PfHaloLayout)]),
     "pf_step_begin": (C.c_int, [_H, C.c_double]),
     "pf_step_finish": (C.c_int, [_H]),
     "pf_set_strip_stream": (C.c_int, [_H, C.c_void_p]),

@@ -686,6 +686,179 @@ class SlabSolver:
         return torch.cat(parts, 0).cpu().numpy()
 
 
+class HipMultiFieldSlabEngine:
+    """One rank's slab of a BM2 / BM3 explicit-FD box (periodic, 3-D) on one GPU: the throughput counterpart of
+    dolfin/bench2.py:76-113 / bench3.py:63-97 decomposed along z.  The two time levels are torch CUDA tensors of shape
+    (nf, nz_local + 2 ghost, ny, nx) handed to libpfhip as pf_config.ext_c, so torch.distributed sends / receives the ghost
+    planes in place; ghost = 2 (BM2: c reaches through mu) or 1 (BM3).  Every step needs fresh ghosts of every field
+    (pf_field_halo_layout); MultiFieldSlabSolver does that."""
+
+    def __init__(self, model, n, h, nranks, rank, device, **params):
+        import torch
+        self.torch = torch
+        self._lib = _lib.load()
+        nx, ny, nz = (n, n, n) if isinstance(n, int) else n
+        cfg = _lib.default_config(3, int(nx), float(h))
+        cfg.n[0], cfg.n[1], cfg.n[2] = int(nx), int(ny), int(nz)
+        cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
+        cfg.force_slab = 1
+        cfg.bc = _lib.PF_BC_PERIODIC
+        cfg.scheme = _lib.PF_SCHEME_FD_EXPLICIT
+        cfg.model = {"bm2": _lib.PF_MODEL_BM2, "bm3": _lib.PF_MODEL_BM3}[model]
+        _lib.check(self._lib.pf_config_model_defaults(C.byref(cfg), cfg.model))
+        for k, v in params.items():
+            setattr(cfg, k, float(v))
+        self.model = model
+        self.nf = 5 if model == "bm2" else 2
+        self.ghost = 2 if model == "bm2" else 1
+        self.fields = ("c", "eta1", "eta2", "eta3", "eta4") if model == "bm2" else ("U", "phi")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.z0, self.nz = slab_partition(nz, nranks, rank)
+        self.nx, self.ny, self.nz_global = nx, ny, nz
+        elems = int(self._lib.pf_field_elems_with_ghosts(C.byref(cfg)))
+        if elems < 0:
+            raise ValueError("invalid slab configuration (periodic box, >= 2 x ghost planes per rank)")
+        shape = (self.nf, self.nz + 2 * self.ghost, ny, nx)
+        assert elems == int(np.prod(shape))
+        self.buffers = [torch.zeros(shape, dtype=torch.float64, device=self.device) for _ in range(2)]
+        self.stream = torch.cuda.Stream(device=self.device)
+        cfg.stream = C.c_void_p(self.stream.cuda_stream)
+        cfg.ext_c[0] = C.c_void_p(self.buffers[0].data_ptr())
+        cfg.ext_c[1] = C.c_void_p(self.buffers[1].data_ptr())
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        lay = _lib.PfHaloLayout()
+        self._ck(self._lib.pf_field_halo_layout(self._h, 0, C.byref(lay)))
+        self.rank_lo, self.rank_hi = lay.rank_lo, lay.rank_hi
+        assert lay.ghost == self.ghost and lay.n_local == self.nz
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("libpfhip: %s" % _lib.error_string(self._lib, self._h, rc))
+
+    @property
+    def cur(self):
+        lay = _lib.PfHaloLayout()
+        self._ck(self._lib.pf_field_halo_layout(self._h, 0, C.byref(lay)))
+        assert lay.base == self.buffers[lay.cur_index].data_ptr()
+        return lay.cur_index
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def set_ic(self, *a):
+        """BM2: (c0, eps, eps_eta, psi) = (0.5, 0.05, 0.1, 1.5); BM3: (r, w, vin, vout) = (8, 1, 1, -1) -- z-extruded, as the
+        single-GPU handle's set_ic_bm2 / set_ic_bm3 (dolfin/bench2.py:58-62, bench3.py:52-58)"""
+        if not a:
+            a = (0.5, 0.05, 0.1, 1.5) if self.model == "bm2" else (8.0, 1.0, 1.0, -1.0)
+        self._ck((self._lib.pf_set_ic_bm2 if self.model == "bm2" else self._lib.pf_set_ic_bm3)(self._h, *[float(x) for x in a]))
+
+    def get_local(self, name):
+        """owned planes of one field, (nz_local, ny, nx)"""
+        self.sync()
+        return self.buffers[self.cur][self.fields.index(name), self.ghost:self.ghost + self.nz].cpu().numpy()
+
+    def set_local(self, name, arr):
+        self.sync()
+        t = self.torch.as_tensor(np.ascontiguousarray(arr, dtype=np.float64), device=self.device)
+        self.buffers[self.cur][self.fields.index(name), self.ghost:self.ghost + self.nz].copy_(t.view(self.nz, self.ny, self.nx))
+        self.torch.cuda.synchronize(self.device)
+
+    def step_local(self, dt):
+        """one explicit step of the whole local box; the ghost planes of every field must be fresh"""
+        self._ck(self._lib.pf_step(self._h, float(dt), 1, None))
+
+    def diag_local(self):
+        out = (C.c_double * 3)()
+        self._ck(self._lib.pf_diagnostics_local(self._h, out))
+        return np.array([out[0], out[1], out[2]])
+
+    def sync(self):
+        self._ck(self._lib.pf_sync(self._h))
+
+    def timing(self, on=True):
+        self._ck(self._lib.pf_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._lib.pf_timing_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class MultiFieldSlabSolver:
+    """Ring of slabs for the multi-field explicit schemes: per step, refresh `ghost` planes per side of EVERY field of the
+    current time level from the two ring neighbours (torch.distributed isend / irecv: RCCL between GPUs, gloo in the CPU
+    tests), then one step of the local box.  No interior / boundary split: the exchange of nf x 2 x ghost planes is not
+    overlapped with compute (the BM1 / BM6 path does that; here the point is that the models decompose at all -- results are
+    bit-identical to the single box).  `engine` is a HipMultiFieldSlabEngine or anything with its interface (buffers, cur,
+    nf, ghost, nz, rank_lo, rank_hi, step_local, diag_local, sync, stream_context)."""
+
+    def __init__(self, engine, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.engine = engine
+        self.group = group
+        self.t = 0.0
+        self.distributed = dist.is_available() and dist.is_initialized()
+
+    def exchange(self):
+        e, dist = self.engine, self.dist
+        g, nz = e.ghost, e.nz
+        buf = e.buffers[e.cur]
+        send_lo, send_hi = buf[:, g:2 * g], buf[:, nz:nz + g]
+        recv_lo, recv_hi = buf[:, 0:g], buf[:, nz + g:nz + 2 * g]
+        if not self.distributed or dist.get_world_size(self.group) == 1:
+            with e.stream_context():                       # the rank is its own neighbour on both sides
+                recv_lo.copy_(send_hi)
+                recv_hi.copy_(send_lo)
+            return
+        if getattr(e, "device", None) is not None and dist.get_backend(self.group) != "nccl":
+            e.sync()                                       # gloo reads GPU tensors from the host side
+        # strided views are staged through contiguous planes (nf x ghost x ny x nx each)
+        with e.stream_context():
+            s_lo, s_hi = send_lo.contiguous(), send_hi.contiguous()
+            r_lo, r_hi = recv_lo.new_empty(recv_lo.shape), recv_hi.new_empty(recv_hi.shape)
+            if getattr(e, "device", None) is not None and dist.get_backend(self.group) != "nccl":
+                e.sync()
+            ops = [dist.P2POp(dist.isend, s_hi, e.rank_hi, self.group, 1), dist.P2POp(dist.isend, s_lo, e.rank_lo, self.group, 2),
+                   dist.P2POp(dist.irecv, r_lo, e.rank_lo, self.group, 1), dist.P2POp(dist.irecv, r_hi, e.rank_hi, self.group, 2)]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            recv_lo.copy_(r_lo)
+            recv_hi.copy_(r_hi)
+
+    def step(self, dt, nsteps=1):
+        for _ in range(nsteps):
+            self.exchange()
+            self.engine.step_local(dt)
+            self.t += dt
+
+    def diagnostics(self):
+        """(F, total solute / solid fraction) of the whole box: the local sums are linear, all-reduced"""
+        e = self.engine
+        loc = e.diag_local()
+        if not self.distributed or self.dist.get_world_size(self.group) == 1:
+            return loc
+        t = e.torch.as_tensor(loc) if hasattr(e, "torch") else __import__("torch").as_tensor(loc)
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.to(e.device)
+        self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+
 class HipFFTSlabEngine(HipSlabEngine):
     """Slab engine of the FFT-based distributed modes: the spectral scheme (scheme="spectral") and BM6
     (model="bm6": Poisson solve by slab FFT + coupled FD step).  Adds the two all-to-all buffers (and the ghosted phi

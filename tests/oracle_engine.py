@@ -344,3 +344,55 @@ class OracleFFTSlabEngine(OracleSlabEngine):
         phi = self.phi.numpy() if self.model == "bm6" else None
         F, C, E = ch_fd.diagnostics(cur, h=self.h, dim=3, ghost=2, zwrap=0, phi=phi, k=self.k)
         return [F, C, E]
+
+
+class OracleMultiFieldSlabEngine:
+    """CPU stand-in for HipMultiFieldSlabEngine (same interface: buffers, cur, nf, ghost, nz, rank_lo / rank_hi, step_local,
+    diag_local): the local box INCLUDING its ghost planes is stepped as a periodic box by oracle/multi_fd.py -- exactly what
+    the HIP kernels do with it (the wrap only pollutes the ghost planes, which the next exchange overwrites).  Test
+    infrastructure only: lets the gloo jobs drive pfhubbenchmarks_amd.solver.MultiFieldSlabSolver on CPU."""
+
+    device = None
+
+    def __init__(self, model, n, h, nranks, rank):
+        import torch
+        from oracle import multi_fd
+        from pfhubbenchmarks_amd.solver import slab_partition
+        self.torch = torch
+        self.mf = multi_fd
+        self.model, self.h = model, float(h)
+        self.nx, self.ny, self.nz_global = n
+        self.nf = 5 if model == "bm2" else 2
+        self.ghost = 2 if model == "bm2" else 1
+        self.z0, self.nz = slab_partition(n[2], nranks, rank)
+        self.rank_lo, self.rank_hi = (rank - 1) % nranks, (rank + 1) % nranks
+        shape = (self.nf, self.nz + 2 * self.ghost, self.ny, self.nx)
+        self.buffers = [torch.zeros(shape, dtype=torch.float64) for _ in range(2)]
+        self.cur = 0
+        self.nranks = nranks
+
+    def stream_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def sync(self):
+        pass
+
+    def set_local(self, u):
+        """u: (nf, nz_local, ny, nx)"""
+        self.buffers[self.cur][:, self.ghost:self.ghost + self.nz] = self.torch.as_tensor(np.ascontiguousarray(u))
+
+    def get_local(self):
+        return self.buffers[self.cur][:, self.ghost:self.ghost + self.nz].numpy().copy()
+
+    def step_local(self, dt):
+        step = self.mf.bm2_step if self.model == "bm2" else self.mf.bm3_step
+        new = step(self.buffers[self.cur].numpy(), dt, self.h)
+        self.cur = 1 - self.cur
+        self.buffers[self.cur][...] = self.torch.as_tensor(np.ascontiguousarray(new))
+
+    def diag_local(self):
+        """two linear functionals of the owned planes (the energy itself is checked on the GPU against the oracle; what the
+        gloo jobs check is MultiFieldSlabSolver's all-reduce of whatever the engine returns)"""
+        u = self.buffers[self.cur][:, self.ghost:self.ghost + self.nz].numpy()
+        return np.array([u[0].sum(), (u[-1] * u[-1]).sum(), 0.0])
