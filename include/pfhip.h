@@ -128,7 +128,7 @@ enum {
                                    per step for 4 / nz more arithmetic.  Needs >= 4 (periodic) / 5 (mirror walls) planes per
                                    rank.  Results are bit-identical to the 2-ghost path. */
   PF_FLAG_FEM_ALWAYS_PIVOT = 4, /* PF_SCHEME_FEM_BE: row exchanges in EVERY dense factorisation of the Newton solve.  By default
-                                   the small batches of 400+-unknown blocks (BM2, BM3) are factored without them, and a Newton
+                                   the dense reduction levels are factored without them (own cooperative LU kernel), and a Newton
                                    solve that then fails is repeated once with them.  Same converged states either way; set this
                                    when the step's ITERATION COUNT steers the run -- the reference's dt rule, bench1.py:180-183
                                    -- so that the time grid never depends on that optimisation (drivers: controller="reference") */

@@ -2321,7 +2321,12 @@ static int block_solve_bcr(FemBE* fb) {
     const bool two = !banded && fb->bh2;
     // row exchanges: only in batches of more than 32 matrices (default; see fembe_step), always (PFHIP_FEM_PIVOT=1), never (=0)
     // (blocks below ~400 unknowns -- BM1's 202, BM6's 303 -- are faster through rocSOLVER's getrs: bench1.py 4.2 vs 5.7 s)
-    const bool lvl_pivot = fb->pivot_mode == 1 || fb->force_pivot || (fb->pivot_mode == 2 && (ne > 32 || nb < 400));
+    // Default policy (round 3, with the own kernels): NO row exchanges in any dense level -- batches of any size, blocks of any
+    // size up to TS_NMAX -- and a fully pivoted repeat of a Newton solve that fails (fembe_step).  (Round 2 pivoted the batches
+    // of more than 32 matrices and every block below 400 unknowns, because rocSOLVER's getrs was the faster substitution
+    // there; with lu_npvt_coop_kernel / lu_solve_mfma_kernel bench1.py runs in 1.3 s instead of 3.7 s, CSV byte-identical.)
+    const bool own_all = fb->own_getrf && fb->own_trsm && nb <= TS_NMAX;
+    const bool lvl_pivot = fb->pivot_mode == 1 || fb->force_pivot || (fb->pivot_mode == 2 && !own_all && (ne > 32 || nb < 400));
     rocblas_handle hU = two ? fb->bh2 : fb->bh;  // U_e solve, U_next
     rocblas_handle hR = two ? fb->bh3 : fb->bh;  // r_e solve, right-hand-side updates (third stream)
     double *Xl = Lc + (int64_t)s * bs, *Xu = Uc + (int64_t)s * bs, *xr = fb->rhs + (int64_t)s * nb;
@@ -2335,7 +2340,7 @@ static int block_solve_bcr(FemBE* fb) {
     };
     if (!banded && lvl_pivot) {
       FB_BLAS(rocsolver_dgetrf_strided_batched(fb->bh, nb, nb, De, nb, st, pe, sv, fb->info, ne));
-      if (fb->own_trsm && fb->own_getrs && nb >= 400 && nb <= TS_NMAX) {
+      if (fb->own_trsm && fb->own_getrs && nb <= TS_NMAX) {
         // row exchanges applied while the right-hand sides are loaded, then the same substitutions as without them
         lu_solve_level(fb->stream, nb, ne, De, st, pe, sv, fb->tinv, fb->tperm, Xu, Xl, xr, sv);
         FB_HIP(hipGetLastError());
@@ -2349,13 +2354,14 @@ static int block_solve_bcr(FemBE* fb) {
     } else if (!banded) {
       fb->used_npvt = true;
       ++fb->npvt_levels;
-      if (fb->own_getrf && nb <= TS_NMAX && ne <= 32) {
-        // G cooperating workgroups per matrix, all resident: 8 * ceil(ne / 8) * G <= 256
+      if (fb->own_getrf && nb <= TS_NMAX) {
+        // G cooperating workgroups per matrix, all resident: 8 * ceil(ne / 8) * G <= 256; larger batches 32 matrices at a time
         static const int g_over = [] {
           const char* v = getenv("PFHIP_FEM_LU_G");   // A/B: workgroups per matrix (<= 256 / (8 ceil(ne / 8)))
           return v ? atoi(v) : 0;
         }();
-        int G = ne <= 16 ? 16 : 8;   // (32 per matrix for ne <= 8 is slower: more pollers of the same flags)
+        const int ne_launch = ne < 32 ? ne : 32;
+        int G = ne_launch <= 16 ? 16 : 8;   // (32 per matrix for ne <= 8 is slower: more pollers of the same flags)
         if (g_over > 0 && g_over < G) G = g_over;
         static const bool check = [] {
           const char* v = getenv("PFHIP_FEM_GETRF");
@@ -2373,7 +2379,12 @@ static int block_solve_bcr(FemBE* fb) {
           FB_HIP(hipStreamSynchronize(fb->stream));
           FB_HIP(hipFree(tmp));
         }
-        lu_npvt_coop(fb->stream, nb, ne, G < (nb + 15) / 16 ? G : (nb + 15) / 16, De, st, fb->tinv, fb->tflags, fb->scal + 3);
+        for (int e0 = 0; e0 < ne; e0 += 32) {
+          const int nn = ne - e0 < 32 ? ne - e0 : 32;
+          const int GG = nn <= 16 ? (G > 16 ? 16 : G) : (G > 8 ? 8 : G);
+          lu_npvt_coop(fb->stream, nb, nn, GG < (nb + 15) / 16 ? GG : (nb + 15) / 16, De + (int64_t)e0 * st, st, fb->tinv,
+                       fb->tflags, fb->scal + 3);
+        }
         FB_HIP(hipGetLastError());
         if (check) {
           mine.resize((size_t)ne * bs);
@@ -2516,7 +2527,7 @@ static int block_solve_bcr(FemBE* fb) {
     m = nk;
     set = 1 - set;
   }
-  if (fb->pivot_mode == 2 && !fb->force_pivot && fb->own_getrf && fb->own_trsm && nb >= 400 && nb <= TS_NMAX) {
+  if (fb->pivot_mode == 2 && !fb->force_pivot && fb->own_getrf && fb->own_trsm && nb <= TS_NMAX) {
     // the last block under the optimistic policy: like the small batches before it (36 panel launches of 45 us otherwise)
     fb->used_npvt = true;
     lu_npvt_coop(fb->stream, nb, 1, 16 < (nb + 15) / 16 ? 16 : (nb + 15) / 16, fb->D, bs, fb->tinv, fb->tflags, fb->scal + 3);

@@ -1285,21 +1285,29 @@ def test_fem_be_failed_unpivoted_solve_is_repeated_with_row_exchanges(lib, monke
 
 def test_fem_be_rejected_step_costs_one_solve_when_every_factorisation_pivoted(lib, golden_dir, monkeypatch):
     """A step the Newton cap rejects (the reference then halves dt, bench1.py:164-177) is reported after ONE solve whenever
-    that solve pivoted throughout: always for BM1 / BM6 (blocks below 400 unknowns), and for BM2 under
-    PF_FLAG_FEM_ALWAYS_PIVOT (what the drivers set with the reference's dt controller).  Only a failed solve that really
-    contained an un-pivoted factorisation is repeated (BM2 default: two attempts on record, state untouched)."""
+    that solve pivoted throughout: under PF_FLAG_FEM_ALWAYS_PIVOT (what the drivers set with the reference's dt controller)
+    for BM1 as for BM2.  Only a failed solve that really contained an un-pivoted factorisation is repeated (the default
+    policy: two attempts on record, state untouched).  Along the way: BM1's first 21 committed steps take one attempt each
+    under either policy, with the same Newton iteration counts."""
     import os
     monkeypatch.setenv("PFHIP_FEM_PIVOT", "auto")
     csv = np.loadtxt(os.path.join(golden_dir, "bench1_out.csv"), delimiter=",", skiprows=1)
-    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be") as s:       # cap 10
-        s.set_ic_bm1(0.5, 0.05)
-        tprev = 0.0
-        for i in range(21):
-            ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
-            assert ok and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1 and s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0
-            tprev = csv[i, 0]
-        ok, _, _ = s.step(csv[21, 0] - tprev, 1, check=True)                            # needs 24 iterations
-        assert not ok and s.last_iters == 10 and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1
+    its = {}
+    for always, attempts in ((True, 1), (False, 2)):
+        with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", always_pivot=always) as s:       # cap 10
+            s.set_ic_bm1(0.5, 0.05)
+            tprev, its[always] = 0.0, []
+            for i in range(21):
+                ok, _, _ = s.step(csv[i, 0] - tprev, 1, check=True)
+                assert ok and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1
+                assert (s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0) == always
+                its[always].append(s.last_iters)
+                tprev = csv[i, 0]
+            before = s.get_c()
+            ok, _, _ = s.step(csv[21, 0] - tprev, 1, check=True)                            # needs 24 iterations
+            assert not ok and s.last_iters == 10 and s.stat(L.PF_STAT_FEM_ATTEMPTS) == attempts
+            np.testing.assert_array_equal(s.get_c(), before)
+    assert its[True] == its[False]
     for always, attempts in ((True, 1), (False, 2)):
         kw = dict(_bm23("bm2"), max_newton=2)
         with PhaseFieldSolver(always_pivot=always, **kw) as s:
