@@ -896,6 +896,118 @@ __global__ __launch_bounds__(256) void row_solve_kernel(int nb, int n1, const do
   }
 }
 
+// The same sweeps with the columns staged through LDS (round 3): one thread per column walking down its column reads one
+// 8 NF-byte piece per lane and step from 64 different cache lines (row_solve_kernel: 4.0 ms per BM3 call, 8 % of its step).
+// Here a workgroup takes 64 columns; chunks of ~32 rows are loaded by all 256 threads along the rows (coalesced), the first
+// wave runs the recurrence on them out of LDS (one column per lane, the carry in registers), and the chunk is stored back
+// the same way; several workgroups per CU overlap each other's phases.
+template <int NF>
+__global__ __launch_bounds__(256) void row_solve_tiled_kernel(int nb, int n1, const double* __restrict__ fac, double* Lm,
+                                                              double* Um, double* rv, int64_t stride_mat,
+                                                              int64_t stride_vec) {
+  constexpr int CW = 64, NR = 32 / NF > 0 ? 32 / NF : 1, RC = NR * NF, PITCH = RC | 1;   // odd pitch: no bank conflicts
+  __shared__ double tile[CW][PITCH];
+  __shared__ double* colptr[CW];
+  const int t = threadIdx.x, m = blockIdx.y, j0 = blockIdx.x * CW;
+  const int ncols = min(CW, 2 * nb + 1 - j0);
+  if (t < CW) {
+    const int j = j0 + t;
+    colptr[t] = t >= ncols ? nullptr
+                           : (j < nb ? Lm + (int64_t)m * stride_mat + (int64_t)j * nb
+                                     : (j < 2 * nb ? Um + (int64_t)m * stride_mat + (int64_t)(j - nb) * nb
+                                                   : rv + (int64_t)m * stride_vec));
+  }
+  const double* F = fac + (int64_t)m * n1 * 3 * NF * NF;
+  // a coupling column is zero above corner (its own corner - 1): this workgroup's sweep starts at its first column's
+  int lstart = 0;
+  {
+    const int jf = j0, jl = j0 + ncols - 1;
+    if (jl < nb || (jf >= nb && jl < 2 * nb)) lstart = max(0, (jf % nb) / NF - 1);   // all in L, or all in U
+  }
+  lstart = (lstart / NR) * NR;
+  __syncthreads();
+  double y[NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a) y[a] = 0.0;
+  const int nrows = n1 * NF;
+  auto load_chunk = [&](int l) {
+    const int r0 = l * NF, rc = min(RC, nrows - r0);
+    for (int idx = t; idx < CW * RC; idx += 256) {
+      const int r = idx % RC, c = idx / RC;
+      if (r < rc && c < ncols) tile[c][r] = colptr[c][r0 + r];
+    }
+  };
+  auto store_chunk = [&](int l) {
+    const int r0 = l * NF, rc = min(RC, nrows - r0);
+    for (int idx = t; idx < CW * RC; idx += 256) {
+      const int r = idx % RC, c = idx / RC;
+      if (r < rc && c < ncols) colptr[c][r0 + r] = tile[c][r];
+    }
+  };
+  // forward sweep
+  for (int l = lstart; l < n1; l += NR) {
+    load_chunk(l);
+    __syncthreads();
+    if (t < ncols) {
+      const int nn = min(NR, n1 - l);
+      for (int k = 0; k < nn; ++k) {
+        const double* Fl = F + (int64_t)(l + k) * 3 * NF * NF;
+        double tt[NF];
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+          double acc = tile[t][k * NF + a];
+#pragma unroll
+          for (int b = 0; b < NF; ++b) acc -= Fl[2 * NF * NF + a * NF + b] * y[b];
+          tt[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+          double acc = 0.0;
+#pragma unroll
+          for (int b = 0; b < NF; ++b) acc += Fl[a * NF + b] * tt[b];
+          y[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NF; ++a) tile[t][k * NF + a] = y[a];
+      }
+    }
+    __syncthreads();
+    store_chunk(l);
+    __syncthreads();
+  }
+  // backward sweep: y holds x of the last corner; corners n1 - 2 .. 0 (the rows above lstart of these columns are zero
+  // going in, but not coming out)
+  const int llast = ((n1 - 1) / NR) * NR;
+  for (int l = llast; l >= 0; l -= NR) {
+    load_chunk(l);
+    __syncthreads();
+    if (t < ncols) {
+      const int nn = min(NR, n1 - l);
+      for (int k = nn - 1; k >= 0; --k) {
+        const int node = l + k;
+        if (node > n1 - 2) continue;
+        const double* Fl = F + (int64_t)node * 3 * NF * NF;
+        double x[NF];
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+          double acc = tile[t][k * NF + a];
+#pragma unroll
+          for (int b = 0; b < NF; ++b) acc -= Fl[NF * NF + a * NF + b] * y[b];
+          x[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NF; ++a) {
+          tile[t][k * NF + a] = x[a];
+          y[a] = x[a];
+        }
+      }
+    }
+    __syncthreads();
+    store_chunk(l);
+    __syncthreads();
+  }
+}
+
 // C = beta C + alpha Lb X for a block-tridiagonal Lb (dense column-major storage, nonzeros of row r in columns
 // [(r / NF - 1) NF, (r / NF + 2) NF)); one thread per (row, strip of 8 columns), grid.z = matrix
 template <int NF>
@@ -1265,6 +1377,7 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_HIP(hipMalloc(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
     FB_HIP(hipMalloc(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
     FB_HIP(hipMalloc(&fb->tflags, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
+    FB_HIP(hipMemset(fb->tflags, 0, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
       fb->solver = (e && std::string(e) == "thomas") ? 1 : 0;
@@ -2196,17 +2309,21 @@ __global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* 
 
 // every matrix's last panel flag must be up: a part with another XCD count / dispatch order than the ticket scheme assumes
 // leaves matrices without workers -- reported like a singular block (the solve is then repeated on the library path)
-__global__ void lu_npvt_done_kernel(const int* __restrict__ flags, int ne, int ntile, double* __restrict__ sing_flag) {
+// ... and leaves the ticket counters and the flags zeroed for the next launch (they start zeroed: fembe_create)
+__global__ void lu_npvt_done_kernel(int* __restrict__ tickets, int* __restrict__ flags, int ne, int ntile,
+                                    double* __restrict__ sing_flag) {
   bool bad = false;
   for (int e = threadIdx.x; e < ne; e += 64) bad = bad || flags[(int64_t)e * ntile + ntile - 1] != 1;
   if (__any(bad) && threadIdx.x == 0) *sing_flag = 1.0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += 64) tickets[i] = 0;
+  for (int i = threadIdx.x; i < ne * ntile; i += 64) flags[i] = 0;
 }
 
 static void lu_npvt_coop(hipStream_t stream, int nb, int ne, int G, double* De, int64_t st, double* dinv, int* flags,
                          double* sing_flag) {
   // flags: [0, 256) the per-XCD ticket counters (one per 128 bytes), then ne x ntile panel flags
   const int ntile = (nb + 15) / 16, maxt = (ntile + CL_W - 1) / CL_W;
-  (void)hipMemsetAsync(flags, 0, sizeof(int) * (256 + (size_t)ne * ntile), stream);
   int* tickets = flags;
   flags += 256;
   const dim3 grid(8 * ((ne + 7) / 8) * G), block(64 * CL_W);
@@ -2218,7 +2335,7 @@ static void lu_npvt_coop(hipStream_t stream, int nb, int ne, int G, double* De, 
     hipLaunchKernelGGL(lu_npvt_coop_kernel<5>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
   else
     hipLaunchKernelGGL(lu_npvt_coop_kernel<6>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
-  hipLaunchKernelGGL(lu_npvt_done_kernel, dim3(1), dim3(64), 0, stream, (const int*)flags, ne, ntile, sing_flag);
+  hipLaunchKernelGGL(lu_npvt_done_kernel, dim3(1), dim3(64), 0, stream, tickets, flags, ne, ntile, sing_flag);
 }
 
 // y_e -= A_e x_e for a batch of dense n x n blocks (column-major): the right-hand-side updates of the reduction levels and the
@@ -2310,8 +2427,16 @@ static int block_solve_bcr(FemBE* fb) {
         constexpr int NF = decltype(nfc)::value;
         hipLaunchKernelGGL(row_factor_kernel<NF>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st, ne,
                            fb->fac);
-        hipLaunchKernelGGL(row_solve_kernel<NF>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re,
-                           st, sv);
+        static const bool tiled = [] {
+          const char* v = getenv("PFHIP_FEM_ROWSOLVE");   // A/B: "simple" = one thread per column straight from memory
+          return !(v && std::string(v) == "simple");
+        }();
+        if (tiled)
+          hipLaunchKernelGGL(row_solve_tiled_kernel<NF>, dim3((2 * nb + 1 + 63) / 64, ne), dim3(256), 0, fb->stream, nb, n1,
+                             (const double*)fb->fac, Le, Ue, re, st, sv);
+        else
+          hipLaunchKernelGGL(row_solve_kernel<NF>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re,
+                             st, sv);
       });
       FB_HIP(hipGetLastError());
     }
