@@ -2047,7 +2047,8 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
 template <int MAXT>
 __global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* __restrict__ Aall, int64_t stride, int ne, int G,
                                                                  double* __restrict__ dinv_all, int* __restrict__ flags_all,
-                                                                 int* __restrict__ tickets, double* __restrict__ sing_flag) {
+                                                                 int* __restrict__ tickets, double* __restrict__ sing_flag,
+                                                                 int spin_limit) {
   __shared__ double T[16][17];   // the factored diagonal tile
   __shared__ double IU[4][64];   // inv(U_kk) as B operand: k-step r, lane (k = q, n = c) -> element [q + 4 r][c]
   __shared__ int s_bad, s_ticket;
@@ -2226,7 +2227,7 @@ __global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's panel stores are in L2 ...
     __syncthreads();                                      // ... and every other wave's
     if (threadIdx.x == 0) {
-      if (s_bad) *sing_flag = 1.0;
+      if (s_bad == 1 && *sing_flag == 0.0) *sing_flag = 1.0;
       __hip_atomic_store(&flags[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
@@ -2283,8 +2284,8 @@ __global__ __launch_bounds__(64 * CL_W) void lu_npvt_coop_kernel(int n, double* 
         int spins = 0;
         while (__hip_atomic_load(&flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > CL_SPIN) {
-            *sing_flag = 1.0;   // a lost partner: report the solve as failed rather than hang
+          if (++spins > spin_limit) {
+            *sing_flag = 2.0;   // a lost partner: report the solve as failed rather than hang (2 = scheduling, not numerics)
             s_bad = 2;
             break;
           }
@@ -2314,7 +2315,7 @@ __global__ void lu_npvt_done_kernel(int* __restrict__ tickets, int* __restrict__
                                     double* __restrict__ sing_flag) {
   bool bad = false;
   for (int e = threadIdx.x; e < ne; e += 64) bad = bad || flags[(int64_t)e * ntile + ntile - 1] != 1;
-  if (__any(bad) && threadIdx.x == 0) *sing_flag = 1.0;
+  if (__any(bad) && threadIdx.x == 0) *sing_flag = 2.0;
   __syncthreads();
   for (int i = threadIdx.x; i < 256; i += 64) tickets[i] = 0;
   for (int i = threadIdx.x; i < ne * ntile; i += 64) flags[i] = 0;
@@ -2326,15 +2327,20 @@ static void lu_npvt_coop(hipStream_t stream, int nb, int ne, int G, double* De, 
   const int ntile = (nb + 15) / 16, maxt = (ntile + CL_W - 1) / CL_W;
   int* tickets = flags;
   flags += 256;
-  const dim3 grid(8 * ((ne + 7) / 8) * G), block(64 * CL_W);
+  // TEST ONLY (PFHIP_FEM_TEST_LU_STARVE=1): launch half of the workgroups, so that matrices are left without partners --
+  // what a part with another XCD count or CU share would do to the ticket scheme; short spins so that the test is quick
+  const char* sv_env = getenv("PFHIP_FEM_TEST_LU_STARVE");   // (read per call: the tests switch it between handles)
+  const bool starve = sv_env && sv_env[0] == '1';
+  const int spin_limit = starve ? 1 << 12 : CL_SPIN;
+  const dim3 grid(starve ? 8 * ((ne + 7) / 8) * G / 2 : 8 * ((ne + 7) / 8) * G), block(64 * CL_W);
   if (maxt <= 2)
-    hipLaunchKernelGGL(lu_npvt_coop_kernel<2>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<2>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag, spin_limit);
   else if (maxt <= 4)
-    hipLaunchKernelGGL(lu_npvt_coop_kernel<4>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<4>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag, spin_limit);
   else if (maxt <= 5)
-    hipLaunchKernelGGL(lu_npvt_coop_kernel<5>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<5>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag, spin_limit);
   else
-    hipLaunchKernelGGL(lu_npvt_coop_kernel<6>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag);
+    hipLaunchKernelGGL(lu_npvt_coop_kernel<6>, grid, block, 0, stream, nb, De, st, ne, G, dinv, flags, tickets, sing_flag, spin_limit);
   hipLaunchKernelGGL(lu_npvt_done_kernel, dim3(1), dim3(64), 0, stream, tickets, flags, ne, ntile, sing_flag);
 }
 
@@ -2711,8 +2717,16 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
     int rc = residual_norm(fb, inv_dt, &nrm);
     if (rc) return rc;
     if (fb->verbose) fprintf(stderr, "[fem_be] dt %.6g newton %d ||R|| %.6e\n", dt, it, nrm);
+    if (fb->scal_host[3] != 0.0) {  // an un-pivoted factorisation met a zero pivot: the direction is garbage
+      if (fb->scal_host[3] == 2.0 && fb->own_getrf) {
+        // ... or the cooperative LU did not get its workgroups (another XCD count / CU share than its ticket scheme
+        // assumes): not a property of the matrices -- leave it off for this handle instead of failing every solve once
+        fb->own_getrf = false;
+        if (fb->verbose) fprintf(stderr, "[fem_be] cooperative LU switched off: a matrix was left without its workgroups\n");
+      }
+      break;
+    }
     if (!(nrm == nrm)) break;  // NaN
-    if (fb->scal_host[3] != 0.0) break;  // an un-pivoted factorisation met a zero pivot: the direction is garbage
     if (nrm < fb->atol) {
       *converged = 1;
       break;

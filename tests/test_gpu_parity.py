@@ -1247,6 +1247,34 @@ def test_fem_be_own_dense_kernels_match_the_library_path(lib, monkeypatch, model
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
 
 
+def test_fem_be_cooperative_lu_without_its_workgroups_is_reported_and_switched_off(lib, monkeypatch):
+    """lu_npvt_coop_kernel needs G resident workgroups per matrix on one XCD (tickets by HW_REG_XCC_ID).  On a part whose XCD
+    count or CU share breaks that, matrices are left without partners: the kernel must neither hang (bounded spins) nor return
+    a half-factored matrix silently.  PFHIP_FEM_TEST_LU_STARVE=1 (test-only) launches half of the workgroups: the first Newton
+    solve fails with the 'not my matrices' code, is repeated with row exchanges on the library path (two attempts, correct
+    result), the handle switches the cooperative kernel off, and the following steps take one attempt each on rocSOLVER's
+    un-pivoted LU -- same fields as an undisturbed handle to 1e-10.  (dolfin/bench2.py:126-158 is the solve this stands for.)"""
+    dts = (0.01, 0.02, 0.04)
+    ref = []
+    with PhaseFieldSolver(**_bm23("bm2")) as s:
+        s.set_ic_bm2()
+        for dt in dts:
+            ok, _, _ = s.step(dt, 1, check=True)
+            assert ok and s.stat(L.PF_STAT_FEM_ATTEMPTS) == 1
+            ref.append((s.last_iters, s.get_field("c"), s.get_field("eta3")))
+    monkeypatch.setenv("PFHIP_FEM_TEST_LU_STARVE", "1")
+    with PhaseFieldSolver(**_bm23("bm2")) as s:
+        s.set_ic_bm2()
+        for k, dt in enumerate(dts):
+            ok, _, _ = s.step(dt, 1, check=True)
+            assert ok
+            assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == (2 if k == 0 else 1), k
+            assert (s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0) == (k == 0), k      # the repeat pivots everywhere; later: library npvt
+            assert s.last_iters == ref[k][0]
+            for a, b in zip((s.get_field("c"), s.get_field("eta3")), ref[k][1:]):
+                assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+
+
 def test_fem_be_failed_unpivoted_solve_is_repeated_with_row_exchanges(lib, monkeypatch):
     """fembe_step's safety net, reached on purpose: PFHIP_FEM_TEST_POISON_NPVT=1 (test-only switch) spoils the first Newton
     direction of any attempt that contained an un-pivoted factorisation.  The step must then (i) restore the state,
