@@ -71,7 +71,10 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
       g->zwrap = 0;
       return PF_OK;
     }
-    if (g->mirror) {
+    // the spectral scheme with mirror bc keeps the even extension along z too (like the single-GPU path): the slabs form a
+    // ring over the 2 (nz - 1) lattice planes and the slab FFT sees a periodic box
+    const bool fft_mirror = g->mirror && cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->model == PF_MODEL_BM1;
+    if (g->mirror && !fft_mirror) {
       // a line of slabs over the PHYSICAL planes: no even extension along z, the two wall ranks mirror their own planes
       // into the ghost layers (launch_reflect_ghosts) instead of receiving them
       g->nzg = g->np[2];
@@ -538,8 +541,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                 "PF_SCHEME_FEM_BE: 2-D, PF_BC_MIRROR (natural no-flux), square mesh, one GPU");
   const bool slab_fft = (cfg->nranks > 1 || cfg->force_slab == 1) &&
                         (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
-  if (slab_fft && g.mirror)
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "mirror bc in slab mode: FD scheme, BM1 only");
+  if (slab_fft && g.mirror && !(cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->model == PF_MODEL_BM1))
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "mirror bc in slab mode: BM1 only (FD scheme: line of slabs; spectral: ring over the even extension)");
   if (slab_fft && slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks) < 0)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "slab FFT modes need ny and nz divisible by nranks");
   if ((cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI) &&
@@ -882,7 +885,9 @@ int pf_set_field(pf_handle* h, int field, const double* host, size_t n) {
     std::vector<double> ext((size_t)(g.plane * g.nz));
     auto refl = [](int i, int np) { return i < np ? i : 2 * (np - 1) - i; };
     for (int z = 0; z < g.nz; ++z) {
-      const int zs = h->cfg.dim == 3 ? (g.zline ? z : refl(z, g.np[2])) : 0;
+      // (z-line: the rank's own physical planes; else the whole physical box, of which this rank keeps lattice planes
+      //  z0 .. z0 + nz - 1 of the even extension -- z0 = 0, nz = all of them on one GPU)
+      const int zs = h->cfg.dim == 3 ? (g.zline ? z : refl(g.z0 + z, g.np[2])) : 0;
       for (int y = 0; y < g.ny; ++y) {
         const int ys = refl(y, g.np[1]);
         const double* src = host + ((int64_t)zs * g.np[1] + ys) * g.np[0];
@@ -933,7 +938,9 @@ int pf_get_field(pf_handle* h, int field, double* host, size_t n) {
     PF_HIP(h, hipMemcpyAsync(host, src, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
   } else {
-    const int npz = g.zline ? g.nz : g.np[2];
+    // z-line: the rank's physical planes; ring over the even extension (spectral slabs): the rank's LATTICE planes, the
+    // caller keeps the first np[2] of the gathered stack; one GPU: the physical planes
+    const int npz = (g.zline || g.ghost != 0) ? g.nz : g.np[2];
     if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * npz)
       return fail(h, PF_ERR_INVALID, "pf_get_field: wrong element count (mirror: nodes of the physical domain)");
     std::vector<double> ext((size_t)(g.plane * g.nz));

@@ -683,7 +683,9 @@ class SlabSolver:
             raise ValueError("gather_field needs equal slabs (nz divisible by the number of ranks)")
         parts = [torch.empty((s,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device) for s in sizes]
         self.dist.all_gather(parts, loc, group=self.group)
-        return torch.cat(parts, 0).cpu().numpy()
+        full = torch.cat(parts, 0).cpu().numpy()
+        nzp = getattr(self.engine, "nz_physical", None)      # ring over the even extension: the physical planes come first
+        return full[:nzp] if nzp is not None and getattr(self.engine, "bc", "") == "mirror" and nzp < full.shape[0] else full
 
 
 class HipMultiFieldSlabEngine:
@@ -864,7 +866,10 @@ class HipFFTSlabEngine(HipSlabEngine):
     (model="bm6": Poisson solve by slab FFT + coupled FD step).  Adds the two all-to-all buffers (and the ghosted phi
     buffer for BM6) as torch tensors so that torch.distributed can run the exchanges the library asks for."""
 
-    def __init__(self, n, h, nranks, rank, device, scheme="fd", model="bm1", eliminate_phi=False, **params):
+    def __init__(self, n, h, nranks, rank, device, scheme="fd", model="bm1", eliminate_phi=False, bc="periodic", **params):
+        """bc="mirror" (spectral scheme, BM1): the reference's no-flux box on its even extension along all three axes, as on
+        one GPU -- the slabs form a ring over the 2 (nz - 1) lattice planes; n = nodes of the physical box; set_global takes
+        the whole physical field, get_local returns this rank's lattice planes (physical x, y), gather_field the physical box"""
         import torch
         self.torch = torch
         self.eliminate_phi = bool(eliminate_phi)
@@ -875,6 +880,7 @@ class HipFFTSlabEngine(HipSlabEngine):
         cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
         cfg.scheme = {"fd": _lib.PF_SCHEME_FD_EXPLICIT, "spectral": _lib.PF_SCHEME_SPECTRAL_SI}[scheme]
         cfg.model = {"bm1": _lib.PF_MODEL_BM1, "bm6": _lib.PF_MODEL_BM6}[model]
+        cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
         cfg.force_slab = 1
         if eliminate_phi:
             cfg.flags |= _lib.PF_FLAG_BM6_ELIMINATE_PHI
@@ -882,11 +888,14 @@ class HipFFTSlabEngine(HipSlabEngine):
             setattr(cfg, k, float(v))
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.z0, self.nz = slab_partition(nz, nranks, rank)
-        self.nx, self.ny, self.nz_global = nx, ny, nz
+        self.bc = bc
+        self.nz_physical = nz
+        lx, ly, lz = (2 * (nx - 1), 2 * (ny - 1), 2 * (nz - 1)) if bc == "mirror" else (nx, ny, nz)
+        self.z0, self.nz = slab_partition(lz, nranks, rank)
+        self.nx, self.ny, self.nz_global = nx, ny, lz          # nz_global: lattice planes along the slab axis
         self.h = float(h)
         mk = lambda shape: torch.zeros(shape, dtype=torch.float64, device=self.device)  # noqa: E731
-        self._block, views = _placed_buffers(torch, self._lib, cfg, (self.nz + 2 * self.ghost, ny, nx), self.device,
+        self._block, views = _placed_buffers(torch, self._lib, cfg, (self.nz + 2 * self.ghost, ly, lx), self.device,
                                              with_phi=(model == "bm6"))
         self.buffers = views[:2]
         self.stream = torch.cuda.Stream(device=self.device)
@@ -912,6 +921,13 @@ class HipFFTSlabEngine(HipSlabEngine):
 
     def set_ic_bm6(self, c0=0.5, c1=0.04):
         self._ck(self._lib.pf_set_ic_bm6(self._h, c0, c1))
+
+    def set_global(self, arr):
+        """bc="mirror": the WHOLE physical field (nz, ny, nx) on every rank; the rank keeps its lattice planes of the even
+        extension"""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        assert self.bc == "mirror" and a.shape == (self.nz_physical, self.ny, self.nx)
+        self._ck(self._lib.pf_set_field(self._h, _lib.PF_FIELD_C, a.ctypes.data_as(C.c_void_p), a.size))
 
     def set_mean_c(self, mean_c):
         self._ck(self._lib.pf_set_mean_c(self._h, float(mean_c)))

@@ -20,12 +20,16 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scheme, model, dt, elim = {"spectral": ("spectral", "bm1", 1e-2, False), "bm6": ("fd", "bm6", 1e-3, False),
-                               "bm6_elim": ("fd", "bm6", 1e-3, True)}[mode]
-    n = (128, 32, 24)
+                               "bm6_elim": ("fd", "bm6", 1e-3, True), "spectral_mirror": ("spectral", "bm1", 1e-2, False)}[mode]
+    bc = "mirror" if mode.endswith("mirror") else "periodic"
+    n = (65, 17, 13) if bc == "mirror" else (128, 32, 24)      # mirror: nodes of the no-flux box -> lattice 128 x 32 x 24
     rng = np.random.default_rng(19)
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
-    eng = HipFFTSlabEngine(n, 1.0, world, rank, 0, scheme=scheme, model=model, eliminate_phi=elim)
-    eng.set_local(full[eng.z0:eng.z0 + eng.nz])
+    eng = HipFFTSlabEngine(n, 1.0, world, rank, 0, scheme=scheme, model=model, eliminate_phi=elim, bc=bc)
+    if bc == "mirror":
+        eng.set_global(full)
+    else:
+        eng.set_local(full[eng.z0:eng.z0 + eng.nz])
     s = FFTSlabSolver(eng)
     d0 = s.diagnostics()
     s.step(dt, 4)
@@ -34,7 +38,7 @@ def main():
     eng.sync()
     field = s.gather_field()
     if rank == 0:
-        with PhaseFieldSolver(dim=3, n=n, h=1.0, scheme=scheme, model=model, eliminate_phi=elim) as ref:
+        with PhaseFieldSolver(dim=3, n=n, h=1.0, scheme=scheme, model=model, eliminate_phi=elim, bc=bc) as ref:
             ref.set_c(full)
             r0 = ref.diagnostics()
             ref.step(dt, 4)

@@ -1598,7 +1598,7 @@ def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, w
     np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
 
 
-@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim"])
+@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim", "spectral_mirror"])
 def test_multi_process_fft_slab_modes_on_one_gpu(lib, mode):
     """the slab-FFT modes with TWO ranks as separate processes sharing the GPU: real engines, the library's request
     protocol (pf_dist_begin / pf_dist_advance) served by gloo collectives on the GPU tensors (all_to_all_single + ghost
