@@ -249,7 +249,9 @@ int pf_sync(pf_handle* h);
  * planes described by pf_halo_layout on its own stream and makes the handle's stream wait for it ->
  * finish (boundary planes + buffer swap). */
 int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
-/* BM2 / BM3 explicit FD in slab mode (PF_SCHEME_FD_EXPLICIT, nranks > 1 or force_slab, dim 3, periodic box): the ghost planes
+/* BM2 / BM3 explicit FD in slab mode (PF_SCHEME_FD_EXPLICIT, nranks > 1 or force_slab, dim 3; PF_BC_MIRROR: the ring runs over
+ * the lattice planes of the even extension, pf_set_field takes the whole physical box, pf_get_field returns the rank's lattice
+ * planes in physical x, y nodes): the ghost planes
  * of field `field` (0 .. nf-1: BM2 c, eta1..4; BM3 U, phi -- dolfin/bench2.py:76-113, bench3.py:63-97 are the equations) in
  * the CURRENT time level, ghost = 2 (BM2: c reaches through mu) or 1 (BM3) per side, the slabs a ring.  Protocol per step:
  * refresh the ghost planes of EVERY field from the two ring neighbours, then pf_step(h, dt, 1, info); the layout moves to

@@ -60,11 +60,9 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
     const bool mfd = cfg->scheme == PF_SCHEME_FD_EXPLICIT && (cfg->model == PF_MODEL_BM2 || cfg->model == PF_MODEL_BM3);
     if (mfd) {
       // BM2 / BM3 explicit FD: a ring of slabs, every field with `ghost` planes per side that the caller refreshes before
-      // each step (pf_field_halo_layout); ghost = the step's reach along z: 2 for BM2 (c through mu), 1 for BM3
-      if (g->mirror) {
-        if (err) *err = "BM2 / BM3 explicit FD in slab mode: periodic boxes only";
-        return (int)PF_ERR_UNSUPPORTED;
-      }
+      // each step (pf_field_halo_layout); ghost = the step's reach along z: 2 for BM2 (c through mu), 1 for BM3.
+      // (mirror bc: the no-flux box on its even extension along all three axes, as on one GPU -- the ring runs over the
+      //  2 (nz - 1) lattice planes)
       g->ghost = cfg->model == PF_MODEL_BM2 ? 2 : 1;
       if (g->nzg < 2 * g->ghost * cfg->nranks) return bad("need >= 2 x ghost planes per rank");
       pf_slab_partition(g->nzg, cfg->nranks, cfg->rank, &g->z0, &g->nz);
@@ -783,7 +781,7 @@ static int lattice_put(pf_handle* h, double* dst, const double* host, size_t n) 
   std::vector<double> ext((size_t)(g.plane * g.nz));
   auto refl = [](int i, int np) { return i < np ? i : 2 * (np - 1) - i; };
   for (int z = 0; z < g.nz; ++z) {
-    const int zs = h->cfg.dim == 3 ? refl(z, g.np[2]) : 0;
+    const int zs = h->cfg.dim == 3 ? refl(g.z0 + z, g.np[2]) : 0;   // (slab mode: this rank's lattice planes of the whole box)
     for (int y = 0; y < g.ny; ++y) {
       const double* src = host + ((int64_t)zs * g.np[1] + refl(y, g.np[1])) * g.np[0];
       double* d = ext.data() + ((int64_t)z * g.ny + y) * g.nx;
@@ -803,12 +801,14 @@ static int lattice_get(pf_handle* h, const double* src, double* host, size_t n) 
     PF_HIP(h, hipStreamSynchronize(h->stream));
     return PF_OK;
   }
-  if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * g.np[2])
+  // one GPU: the physical box; slab mode (ring over the even extension): this rank's lattice planes in physical x, y nodes
+  const int npz = g.ghost != 0 ? g.nz : (h->cfg.dim == 3 ? g.np[2] : 1);
+  if ((int64_t)n != (int64_t)g.np[0] * g.np[1] * npz)
     return fail(h, PF_ERR_INVALID, "wrong element count (mirror: nodes of the physical domain)");
   std::vector<double> ext((size_t)(g.plane * g.nz));
   PF_HIP(h, hipMemcpyAsync(ext.data(), src, sizeof(double) * ext.size(), hipMemcpyDeviceToHost, h->stream));
   PF_HIP(h, hipStreamSynchronize(h->stream));
-  for (int z = 0; z < g.np[2]; ++z)
+  for (int z = 0; z < npz; ++z)
     for (int y = 0; y < g.np[1]; ++y)
       std::memcpy(host + ((int64_t)z * g.np[1] + y) * g.np[0], ext.data() + ((int64_t)z * g.ny + y) * g.nx,
                   sizeof(double) * g.np[0]);

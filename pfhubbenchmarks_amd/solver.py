@@ -695,7 +695,10 @@ class HipMultiFieldSlabEngine:
     planes in place; ghost = 2 (BM2: c reaches through mu) or 1 (BM3).  Every step needs fresh ghosts of every field
     (pf_field_halo_layout); MultiFieldSlabSolver does that."""
 
-    def __init__(self, model, n, h, nranks, rank, device, **params):
+    def __init__(self, model, n, h, nranks, rank, device, bc="periodic", **params):
+        """bc="mirror": n = nodes of the no-flux box, which lives on its even extension along all three axes as on one GPU;
+        the ring runs over the 2 (nz - 1) lattice planes and the buffers / set_local / get_local speak LATTICE planes
+        (self.nx, self.ny = lattice sizes; the physical nodes are the leading [:nz_p, :ny_p, :nx_p] corner of the stack)"""
         import torch
         self.torch = torch
         self._lib = _lib.load()
@@ -704,7 +707,11 @@ class HipMultiFieldSlabEngine:
         cfg.n[0], cfg.n[1], cfg.n[2] = int(nx), int(ny), int(nz)
         cfg.nranks, cfg.rank, cfg.device = int(nranks), int(rank), int(device)
         cfg.force_slab = 1
-        cfg.bc = _lib.PF_BC_PERIODIC
+        cfg.bc = {"periodic": _lib.PF_BC_PERIODIC, "mirror": _lib.PF_BC_MIRROR}[bc]
+        self.bc = bc
+        self.physical = (nx, ny, nz)
+        if bc == "mirror":
+            nx, ny, nz = 2 * (nx - 1), 2 * (ny - 1), 2 * (nz - 1)
         cfg.scheme = _lib.PF_SCHEME_FD_EXPLICIT
         cfg.model = {"bm2": _lib.PF_MODEL_BM2, "bm3": _lib.PF_MODEL_BM3}[model]
         _lib.check(self._lib.pf_config_model_defaults(C.byref(cfg), cfg.model))

@@ -1106,6 +1106,55 @@ def test_multifield_fd_slabs_bit_exact_vs_single_box(lib, model, shape, nranks):
             e.close()
 
 
+@pytest.mark.parametrize("model,n,nranks", [("bm2", (9, 7, 9), 2), ("bm3", (65, 9, 7), 2), ("bm2", (65, 9, 7), 3), ("bm3", (6, 5, 13), 4)])
+def test_multifield_fd_mirror_slabs_match_the_single_gpu_box(lib, model, n, nranks):
+    """BM2 / BM3 explicit FD, the reference's no-flux boxes (dolfin/bench2.py:66-69, bench3.py:59-61: natural boundary
+    conditions) on several slabs: as on one GPU the box lives on its even extension along all three axes, the ring of slab
+    handles runs over the 2 (nz - 1) lattice planes.  Same initial condition (pf_set_ic_bm2 / bm3), five steps: the
+    physical-node corner of the gathered lattice stack equals the single-GPU handle's fields BIT for bit; summed local
+    diagnostics = the single handle's to 1e-13."""
+    import torch
+    from pfhubbenchmarks_amd.solver import HipMultiFieldSlabEngine
+    nx, ny, nz = n
+    names = ("c", "eta1", "eta2", "eta3", "eta4") if model == "bm2" else ("U", "phi")
+    dt, h = (2e-3, 1.3) if model == "bm2" else (5e-3, 0.9)
+    engines = [HipMultiFieldSlabEngine(model, n, h, nranks, r, 0, bc="mirror") for r in range(nranks)]
+    try:
+        for e in engines:
+            e.set_ic()
+
+        def exchange():
+            for e in engines:
+                e.sync()
+            for e in engines:
+                g, m = e.ghost, e.nz
+                lo, hi = engines[e.rank_lo], engines[e.rank_hi]
+                b = e.buffers[e.cur]
+                b[:, 0:g].copy_(lo.buffers[lo.cur][:, lo.nz:lo.nz + g])
+                b[:, m + g:m + 2 * g].copy_(hi.buffers[hi.cur][:, hi.ghost:2 * hi.ghost])
+            torch.cuda.synchronize()
+
+        with PhaseFieldSolver(dim=3, n=n, h=h, bc="mirror", scheme="fd", model=model) as s:
+            (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+            for k in range(5):
+                exchange()
+                for e in engines:
+                    e.step_local(dt)
+                s.step(dt, 1)
+            for name in names:
+                stack = np.concatenate([e.get_local(name) for e in engines], axis=0)
+                assert stack.shape == (2 * (nz - 1), 2 * (ny - 1), 2 * (nx - 1))
+                np.testing.assert_array_equal(stack[:nz, :ny, :nx], s.get_field(name), err_msg=name)
+                np.testing.assert_array_equal(stack[nz:, :ny, :nx], s.get_field(name)[nz - 2:0:-1], err_msg=name + " (mirror image)")
+            exchange()
+            tot = sum(e.diag_local() for e in engines)
+            F, C, _ = s.diagnostics()
+            assert abs(tot[0] - F) <= 1e-13 * abs(F) and abs(tot[1] - C) <= 1e-13 * abs(C)
+    finally:
+        for e in engines:
+            e.close()
+
+
 @pytest.mark.parametrize("model", ["bm2", "bm3"])
 def test_multifield_fd_no_flux_box_is_the_even_extension(lib, model):
     """PF_BC_MIRROR (the reference's natural boundary condition, bench2.py:113, bench3.py:100) for the multi-field FD
