@@ -2021,6 +2021,64 @@ static void lu_solve_level(hipStream_t stream, int nb, int ne, const double* De,
 #undef PF_LU_SOLVE
 }
 
+// C = beta C + alpha Lb X for the block-tridiagonal Lb of the first reduction level (dense column-major storage, zeros
+// outside the band: nonzeros of row r in columns [(r / NF - 1) NF, (r / NF + 2) NF)), on fp64 MFMA tiles: a wave takes one
+// 16-row tile of C and a strip of column tiles; the k range of a row tile is at most 15 + 3 NF columns wide, i.e. <= 4
+// aligned 16-wide k tiles (their zeros cost nothing worth counting), whose A operands stay in registers for the strip.
+// The one-thread-per-(row, 8 columns) kernel issued a load per multiply-add through L1: 384 us (BM2) / 744 us (BM3) per
+// call, 11 % / 7 % of the step, for ~0.3 GB of unavoidable traffic.
+template <int NF>
+__global__ __launch_bounds__(256) void band_gemm_mfma_kernel(int nb, const double* __restrict__ Lb, int64_t strideL,
+                                                             const double* __restrict__ X, int64_t strideX, double* C,
+                                                             int64_t strideC, double alpha, double beta, int strip) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), q = lane >> 4, c = lane & 15;
+  const int ntile = (nb + 15) / 16;
+  const int ti = blockIdx.x * 4 + w, m = blockIdx.z;
+  if (ti >= ntile) return;
+  const double* Lm = Lb + (int64_t)m * strideL;
+  const double* Xm = X + (int64_t)m * strideX;
+  double* Cm = C + (int64_t)m * strideC;
+  const int r0 = 16 * ti, r1 = min(16 * ti + 15, nb - 1);
+  const int kmin = max(0, (r0 / NF - 1) * NF), kmax = min(nb - 1, (r1 / NF + 2) * NF - 1);
+  const int kt0 = kmin >> 4, nkt = (kmax >> 4) - kt0 + 1;   // <= 4
+  double a[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + c, col = 16 * (kt0 + t) + q + 4 * r;
+      a[t][r] = (t < nkt && row < nb && col < nb) ? alpha * Lm[row + (int64_t)col * nb] : 0.0;
+    }
+  }
+  const int j0 = blockIdx.y * strip, j1 = min(j0 + strip, ntile);
+  for (int tj = j0; tj < j1; ++tj) {
+    v4f64 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + q + 4 * r, col = 16 * tj + c;
+      acc[r] = (beta != 0.0 && row < nb && col < nb) ? beta * Cm[row + (int64_t)col * nb] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < nkt) {
+        double b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * (kt0 + t) + q + 4 * r, col = 16 * tj + c;
+          b[r] = (row < nb && col < nb) ? Xm[row + (int64_t)col * nb] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][r], b[r], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + q + 4 * r, col = 16 * tj + c;
+      if (row < nb && col < nb) Cm[row + (int64_t)col * nb] = acc[r];
+    }
+  }
+}
+
 // ---- LU without row exchanges of a batch of dense blocks: G cooperating workgroups per matrix, ONE launch -------------------
 // rocSOLVER's getrf_npvt on 606 / 702 unknowns is 57 panel / trsm / gemm launches of 10-45 us whatever the batch size (<= 25):
 // ~1.2 ms per reduction level, 40 % of the BM2 step once the substitutions are own kernels.  Here a matrix is factored by G
@@ -2618,11 +2676,22 @@ static int block_solve_bcr(FemBE* fb) {
                                            count);
     };
     if (banded) {
+      static const bool band_mfma = [] {
+        const char* v = getenv("PFHIP_FEM_BANDGEMM");   // A/B: "simple" = one thread per (row, 8 columns) through L1
+        return !(v && std::string(v) == "simple");
+      }();
       auto band_gemm = [&](const double* Lb, const double* X, double* C, double beta, int count) {
-        const dim3 g((nb + 255) / 256, (nb + 7) / 8, count);
         with_nf(fb->gen_nf, [&](auto nfc) {
           constexpr int NF = decltype(nfc)::value;
-          hipLaunchKernelGGL(band_gemm_kernel<NF>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+          if (band_mfma && NF <= 6) {   // (15 + 3 NF columns of a row tile's band fit 4 k tiles)
+            const int ntile = (nb + 15) / 16, strip = 8;
+            const dim3 g((ntile + 3) / 4, (ntile + strip - 1) / strip, count);
+            hipLaunchKernelGGL(band_gemm_mfma_kernel<NF>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta,
+                               strip);
+          } else {
+            const dim3 g((nb + 255) / 256, (nb + 7) / 8, count);
+            hipLaunchKernelGGL(band_gemm_kernel<NF>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta);
+          }
         });
       };
       if (nl > 0) {
