@@ -1063,6 +1063,34 @@ __global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, 
   if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// a . b in two stages (256 blocks over contiguous chunks, then one wave over the 256 partial sums; fixed order ->
+// deterministic): the single-block forms above take 109 us (BM2, 1.2e5 entries) / 442 us (BM3, 4.9e5) per residual norm
+__global__ __launch_bounds__(256) void dot_stage1_kernel(const double* __restrict__ a, const double* __restrict__ b, int n,
+                                                         double* __restrict__ partials) {
+  __shared__ double sh[4];
+  const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x, i0 = blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+  double acc = 0.0;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) acc += a[i] * b[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(64) void dot_stage2_kernel(const double* __restrict__ partials, int np, double* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += 64) acc += partials[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+// (partials: 256 doubles at `scratch`; out: one double)
+static void dot_two_stage(hipStream_t stream, const double* a, const double* b, int n, double* scratch, double* out) {
+  const int nblk = n >= 256 * 256 ? 256 : (n + 255) / 256;
+  hipLaunchKernelGGL(dot_stage1_kernel, dim3(nblk), dim3(256), 0, stream, a, b, n, scratch);
+  hipLaunchKernelGGL(dot_stage2_kernel, dim3(1), dim3(64), 0, stream, (const double*)scratch, nblk, out);
+}
+
 // diagnostics: out = {total free energy, int u_second (BM2: c; BM3: (phi + 1) / 2), 0} as per-block partials
 template <int NF>
 __global__ __launch_bounds__(256) void gen_diag_kernel(const FemParams p, const GenModel m, const int* __restrict__ tri,
@@ -1202,6 +1230,7 @@ struct FemBE {
                                            // pivoted retry of a failed Newton solve; PFHIP_FEM_PIVOT=1: always, =0: never
   bool force_pivot = false;                // set for the retry
   bool own_trsm = true;                    // D^-1 [L | U | r] of the dense levels by lu_solve_mfma_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS trsm / rocSOLVER getrs)
+  bool two_stage_dots = true;              // residual norm / line-search dot products in two stages (PFHIP_FEM_DOTS=single: one block)
   bool own_getrf = true;                   // un-pivoted LU of the dense levels by lu_npvt_coop_kernel (PFHIP_FEM_GETRF=rocsolver: getrf_npvt)
   int* tflags = nullptr;                   // its panel flags: (ng / 2 + 1) x ceil(nb / 16)
   bool own_gemv = true;                    // y -= A x of the levels by gemv_sub_kernel (PFHIP_FEM_GEMV=rocblas: rocBLAS)
@@ -1386,6 +1415,8 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       const char* ts = getenv("PFHIP_FEM_TRSM");
       fb->own_trsm = !(ts && std::string(ts) == "rocblas");
       fb->own_getrs = !(ts && std::string(ts) == "npvt");
+      const char* dd = getenv("PFHIP_FEM_DOTS");
+      fb->two_stage_dots = !(dd && std::string(dd) == "single");
       const char* gf = getenv("PFHIP_FEM_GETRF");
       fb->own_getrf = !(gf && std::string(gf) == "rocsolver");
       const char* gv = getenv("PFHIP_FEM_GEMV");
@@ -1660,7 +1691,10 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
   hipLaunchKernelGGL(fem_residual_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->ell_col, fb->ell_K,
                      fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
                      fb->rhs);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, (int)fb->vec_len, fb->scal);
+  if (fb->two_stage_dots)
+    dot_two_stage(fb->stream, fb->rhs, fb->rhs, (int)fb->vec_len, fb->partials, fb->scal);
+  else
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, (int)fb->vec_len, fb->scal);
   FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));  // [3]: info flag
   FB_HIP(hipStreamSynchronize(fb->stream));
   *nrm = std::sqrt(fb->scal_host[0]);
@@ -2857,10 +2891,15 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
         double n1 = 0.0;
         rc = residual_norm(fb, inv_dt, &n1, fb->rhs1);  // -R(u + d)
         if (rc) return rc;
+        if (fb->two_stage_dots) {
+          dot_two_stage(fb->stream, fb->rhs0, fb->rhs, ntot, fb->partials, fb->scal);
+          dot_two_stage(fb->stream, fb->rhs1, fb->rhs, ntot, fb->partials + 256, fb->scal + 1);
+        } else {
         hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs0, (const double*)fb->rhs,
                            ntot, fb->scal);
         hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs1, (const double*)fb->rhs,
                            ntot, fb->scal + 1);
+        }
         FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));
         FB_HIP(hipStreamSynchronize(fb->stream));
         // PETSc's variables (W = X - lambda Y with Y = J^-1 F = -d): fty = F(W) . Y = -(R . d)
