@@ -18,11 +18,23 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n = (16, 12, 8) if world <= 4 else (16, 2 * world, 2 * world)    # slab FFT: ny and nz divisible by the ranks
-    eng = OracleFFTSlabEngine(n, 1.0, world, rank, scheme="spectral" if mode == "spectral" else "fd",
+    mirror = mode == "spectral_mirror"
+    eng = OracleFFTSlabEngine(n, 1.0, world, rank, scheme="spectral" if mode.startswith("spectral") else "fd",
                               model="bm6" if mode.startswith("bm6") else "bm1", eliminate_phi=mode == "bm6_elim")
     rng = np.random.default_rng(4)
-    full = 0.5 + 0.05 * rng.standard_normal((n[2], n[1], n[0]))
+    if mirror:
+        # the no-flux box of (9, 7, 5) nodes on its even extension = the 16 x 12 x 8 lattice: the slabs form a ring over the
+        # lattice planes, the physical planes are the first 5 of the gathered stack (HipFFTSlabEngine(bc="mirror") does this)
+        from oracle.multi_fd import even_extend
+        phys = 0.5 + 0.05 * rng.standard_normal((n[2] // 2 + 1, n[1] // 2 + 1, n[0] // 2 + 1))
+        full = even_extend(phys)                                   # x and y
+        full = np.concatenate([full, full[-2:0:-1]], axis=0)       # and z
+        assert full.shape == (n[2], n[1], n[0])
+    else:
+        full = 0.5 + 0.05 * rng.standard_normal((n[2], n[1], n[0]))
     eng.set_local(full[eng.z0:eng.z0 + eng.nz])
+    if mirror:                                                     # (what gather_field looks at)
+        eng.bc, eng.nz_physical = "mirror", phys.shape[0]
     s = FFTSlabSolver(eng)
     dt = 1e-2 if mode == "spectral" else 1e-3
     d0 = s.diagnostics()
