@@ -28,8 +28,10 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
 Why config 3 and not config 2 is the default: BASELINE.json's metric is "cell-updates/s at 512^2 and 512^3, 1/2/4/8
 GPUs" and its roofline target is the fused stencil.  Config 2 (512^2 spectral) is a 14 us, launch-latency-bound step
 that does not shard (replicas only, DESIGN.md section 4), so the N = 1, 2, 4, 8 series is run on the 512^3 stencil;
-the same default run also times both 512^2 workloads, the 1024^3 stencil (north_star's roofline target) and the
-BE-parity mode with its CPU restatement, and reports them under "also" in the same JSON line.
+the same default run also times both 512^2 workloads, the 1024^3 stencil (north_star's roofline target), the 512^3
+spectral step, BM6 at 512^3, BM2 / BM3 and the BE-parity mode with its CPU restatement, and reports them under "also" in
+the same JSON line -- a COMPACT line (<= 6 KB; the driver keeps the last 8 KB of stdout), the BASELINE-config entries last;
+--verbose restores every timed block, pf_status_string and the notes.  CPU legs run after all GPU legs.
 Timed region (DESIGN.md section 6 "power transient"): the chip answers an HBM-heavy load that starts from
 idle (>= 3-10 ms without work) by dropping its shader clock from 2.4 to ~1.7 GHz for ~25 ms (tools/ramp_probe.py,
 profiles/r02/ramp_probe_512.log), which a 20-step / 9 ms timed region sits entirely inside.  So the run first does a
@@ -92,23 +94,17 @@ def cpu_baseline_spectral(n, dt, steps):
                                                                                              steps, el)}
 
 
-def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
-    """config 1 (reference's own discretisation): accepted backward-Euler steps on the committed time grid.
-    Returns the JSON dict (the caller prints it, or nests it under `also`)."""
-    steps = a.steps if steps is None else steps
-    warmup = a.warmup if warmup is None else warmup
-    import importlib.util
-    import numpy as np
+def _fem_timed_rows(s, set_ic, times, warmup, steps):
+    """The timed region of the BE-parity workloads.  One UNTIMED pass over the same rows first (declared pre-heat: the first
+    solves of a handle pay rocBLAS / code-object initialisation, and a GPU that idled during another workload's CPU leg
+    starts at a reduced shader clock, DESIGN 6.1 -- round 3's driver line read 20.6 ms per BM1 step where the steady state
+    is 9.4), then the state is reset to the initial condition and rows [warmup, warmup + steps) are timed.
+    -> (seconds, Newton iterations, t_end, preheat_ms)"""
     import torch
-    from pfhubbenchmarks_amd.drivers import report_times
-    from pfhubbenchmarks_amd.solver import PhaseFieldSolver
-    if world != 1:
-        sys.exit("bm1_fem_be is a single-GPU workload")
-    times = report_times("bench1")
-    steps = min(steps, len(times) - warmup)
-    nodes = 20201
-    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", max_newton=100) as s:
-        s.set_ic_bm1()
+    el = its = tprev = pre_ms = None
+    for timed in (False, True):
+        t_pass = time.perf_counter()
+        set_ic()
         tprev, its = 0.0, 0
         for i in range(warmup):
             s.step(times[i] - tprev, 1, check=True)
@@ -122,21 +118,46 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
             tprev = times[i]
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        if not timed:
+            pre_ms = (time.perf_counter() - t_pass) * 1e3
+    return el, its, tprev, pre_ms
+
+
+def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
+    """config 1 (reference's own discretisation): accepted backward-Euler steps on the committed time grid.
+    Returns the JSON dict (the caller prints it, or nests it under `also`); out["_cpu"] (when the CPU leg is wanted) is a
+    callable that times oracle/fem_be.py on the same rows and fills out["cpu_baseline"] -- the caller runs it AFTER every
+    GPU leg, so that no GPU measurement starts from a GPU that sat idle behind a CPU leg."""
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
+    import importlib.util
+    from pfhubbenchmarks_amd.drivers import report_times
+    from pfhubbenchmarks_amd.solver import PhaseFieldSolver
+    if world != 1:
+        sys.exit("bm1_fem_be is a single-GPU workload")
+    times = report_times("bench1")
+    steps = min(steps, len(times) - warmup)
+    nodes = 20201
+    with PhaseFieldSolver(dim=2, n=101, h=2.0, bc="mirror", scheme="fem_be", max_newton=100) as s:
+        el, its, tprev, pre_ms = _fem_timed_rows(s, s.set_ic_bm1, times, warmup, steps)
         F, C, _ = s.diagnostics()
+        status = getattr(s, "status", "")
     out = {"metric": "node-updates/sec on PFHub BM1, reference algorithm (P1 crossed mesh, backward Euler, Newton)",
            "value": nodes * steps / el, "unit": "node-updates/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic",
+           "dtype": "f64", "data": "synthetic", "preheat_ms": pre_ms,
            "config": {"workload": "bm1_fem_be", "mesh": "100x100 crossed, 20201 nodes, 40402 dofs",
                       "time_grid": "rows %d..%d of results/bench1_out.csv" % (warmup, warmup + steps - 1),
-                      "newton_iterations": its, "linear_solver": "cell-centre unknowns condensed out, banded first reduction level, "
-                                       "then block cyclic reduction on strided-batched rocSOLVER/rocBLAS"},
+                      "newton_iterations": its, "preheat": "one untimed pass over the same rows, then reset to the IC",
+                      "linear_solver": "cell-centre unknowns condensed out, banded first reduction level, then block "
+                                       "cyclic reduction on own LU / substitution kernels", "status": status},
            "roofline": None,
            "check": {"t": float(tprev), "F": F, "C": C},
            # (this repo has its own dolfin/ directory of command-line shims, so probe FEniCS's dependencies instead)
            "fenics_on_host": all(importlib.util.find_spec(m) is not None for m in ("ufl", "ffc", "petsc4py"))}
-    if not a.no_cpu_baseline:
-        from oracle import fem_be
+
+    def cpu_leg():
+        from oracle import ch_fd, fem_be
         o = fem_be.FemBE("bm1", newton_max=100)
         tp = 0.0
         for i in range(warmup):
@@ -148,23 +169,22 @@ def bench_fem_be(a, world, steps=None, warmup=None, ncpu_max=6):
             o.step(times[i] - tp)
             tp = times[i]
         elc = time.perf_counter() - t0
-        from oracle import ch_fd
         out["cpu_baseline"] = {"value": nodes * ncpu / elc, "unit": "node-updates/s", "cores": ch_fd.host_cores(),
                                "kind": "port", "sample": "%d accepted BE steps (rows %d..%d), oracle/fem_be.py "
                                "(scipy SuperLU), %.1f s; FEniCS itself: %s" % (
                                    ncpu, warmup, warmup + ncpu - 1, elc,
                                    "present" if out["fenics_on_host"] else "unavailable on host")}
+    if not a.no_cpu_baseline:
+        out["_cpu"] = cpu_leg
     return out
 
 
 def bench_fem_multi(a, model, steps=6, warmup=2, cpu=True):
     """BM2 / BM3 in the BE-parity mode: accepted backward-Euler steps of the reference's own
     discretisation (dolfin/bench2.py:76-113 on the 100 x 100 crossed mesh, 6 fields; bench3.py:63-97 on 350 x 350, 2
-    fields) on the committed time grid; node-updates/s.  CPU leg: ONE Newton iteration of oracle/fem_multi.py (scipy
-    SuperLU; a whole step costs it 100-200 s here), extrapolated to the iterations the timed steps took -- for BM3 on a
-    120 x 120 mesh, scaled by nodes."""
-    import numpy as np
-    import torch
+    fields) on the committed time grid; node-updates/s.  CPU leg (deferred like bench_fem_be's): ONE Newton iteration of
+    oracle/fem_multi.py (scipy SuperLU; a whole step costs it 100-200 s here), extrapolated to the iterations the timed
+    steps took -- for BM3 on a 120 x 120 mesh, scaled by nodes; kind = "port-extrapolated"."""
     from pfhubbenchmarks_amd.drivers import report_times
     from pfhubbenchmarks_amd.solver import PhaseFieldSolver
     bench = "bench2" if model == "bm2" else "bench3"
@@ -173,31 +193,21 @@ def bench_fem_multi(a, model, steps=6, warmup=2, cpu=True):
     nodes = (N + 1) ** 2 + N * N
     nf = 6 if model == "bm2" else 2
     with PhaseFieldSolver(dim=2, n=N + 1, h=L_dom / N, bc="mirror", scheme="fem_be", model=model, max_newton=100) as s:
-        (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
-        tprev, its = 0.0, 0
-        for i in range(warmup):
-            s.step(times[i] - tprev, 1, check=True)
-            tprev = times[i]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(warmup, warmup + steps):
-            ok, _, _ = s.step(times[i] - tprev, 1, check=True)
-            assert ok
-            its += s.last_iters
-            tprev = times[i]
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        el, its, tprev, pre_ms = _fem_timed_rows(s, s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3, times, warmup, steps)
         F, C, _ = s.diagnostics()
+        status = getattr(s, "status", "")
     ref_wall = {"bm2": "22 s on 32 cores for the whole 120-row run (dolfin/bench2.py:140 comment)",
                 "bm3": "27 s on 128 cores for the whole 46-row run (dolfin/bench3.py:125 comment)"}[model]
     out = {"metric": "node-updates/sec on PFHub %s, reference algorithm (P1 crossed mesh, backward Euler, Newton)" % model.upper(),
            "value": nodes * steps / el, "unit": "node-updates/s", "ms_per_step": el / steps * 1e3, "steps": steps,
-           "warmup": warmup, "dtype": "f64",
+           "warmup": warmup, "dtype": "f64", "preheat_ms": pre_ms,
            "config": {"workload": "%s_fem_be" % model, "mesh": "%dx%d crossed, %d nodes x %d fields = %d dofs" % (N, N, nodes, nf, nodes * nf),
                       "time_grid": "rows %d..%d of results/%s_out.csv" % (warmup, warmup + steps - 1, bench),
-                      "newton_iterations": its, "reference_wall_time": ref_wall},
+                      "newton_iterations": its, "reference_wall_time": ref_wall,
+                      "preheat": "one untimed pass over the same rows, then reset to the IC", "status": status},
            "check": {"t": float(tprev), "F": F, "second_column": C}}
-    if cpu:
+
+    def cpu_leg():
         from oracle import ch_fd, fem_multi
         Ns = N if model == "bm2" else 120
         o = fem_multi.MultiFieldBE(model, N=Ns, newton_max=1)
@@ -206,11 +216,21 @@ def bench_fem_multi(a, model, steps=6, warmup=2, cpu=True):
         t_it = time.perf_counter() - t0
         nodes_s = (Ns + 1) ** 2 + Ns * Ns
         out["cpu_baseline"] = {"value": nodes_s * steps / (t_it * its), "unit": "node-updates/s", "cores": ch_fd.host_cores(),
-                               "kind": "port",
+                               "kind": "port-extrapolated",
                                "sample": "1 Newton iteration (%.1f s) of oracle/fem_multi.py (scipy SuperLU) on the %dx%d "
                                          "crossed mesh, extrapolated to the %d iterations of the %d timed steps" % (
                                              t_it, Ns, Ns, its, steps)}
+    if cpu:
+        out["_cpu"] = cpu_leg
     return out
+
+
+def run_cpu_legs(*outs):
+    """Run the deferred CPU legs (after every GPU measurement of the process) and drop the callables."""
+    for o in outs:
+        leg = o.pop("_cpu", None)
+        if leg is not None:
+            leg()
 
 
 def measured_traffic(workload, variant):
@@ -241,6 +261,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed K-step blocks (median reported); 0 = as many as needed for 0.25 s of timed work, <= 25")
     ap.add_argument("--no-also", action="store_true", help="default workload only: skip the side measurements")
+    ap.add_argument("--verbose", action="store_true",
+                    help="keep the bulky bookkeeping in the JSON line (every timed block, pf_status_string, notes, the sources "
+                         "of the traffic figures).  The default line is compact (<= 6 KB) so that the driver's 8 KB tail of "
+                         "stdout holds ALL of it: round 3's 15 KB line lost five side measurements that way")
     ap.add_argument("--halo", default="wide", choices=["wide", "narrow"],
                     help="FD slab path (N > 1 or --slab): 'wide' = PF_FLAG_WIDE_HALO, 4 ghost planes exchanged every second "
                          "step (half the hand-offs, 8 instead of 12 redundant plane reads per step); 'narrow' = 2 ghost "
@@ -305,14 +329,17 @@ def main():
         lib.pfk_set_tuning(7, a.push_wgs)
 
     if a.workload == "bm1_fem_be":
-        print(json.dumps(bench_fem_be(a, world)), flush=True)
+        o = bench_fem_be(a, world)
+        run_cpu_legs(o)
+        print(json.dumps(o if a.verbose else compact_line(o)), flush=True)
         return
     if a.workload in ("bm2_fem_be", "bm3_fem_be"):
         if world != 1:
             sys.exit("%s is a single-GPU workload" % a.workload)
         o = bench_fem_multi(a, a.workload[:3], steps=min(a.steps, 40), warmup=min(a.warmup, 4), cpu=not a.no_cpu_baseline)
         o.update(n_gpus=1, higher_is_better=True, scaling="weak", vs_baseline=None, data="synthetic", roofline=None)
-        print(json.dumps(o), flush=True)
+        run_cpu_legs(o)
+        print(json.dumps(o if a.verbose else compact_line(o)), flush=True)
         return
 
     dist = None
@@ -329,25 +356,86 @@ def main():
     out = bench_grid(a, a.workload, ctx, a.steps, a.warmup, cpu=not a.no_cpu_baseline, copy_ceiling=True)
     if rank == 0 and world == 1 and a.workload == "bm1_fd_512c" and not a.no_also:
         out["also"] = side_measurements(a, ctx)
+    # every GPU measurement is done: now the CPU legs (oracle timed on the host cores), headline first
+    run_cpu_legs(out, *out.get("also", {}).values())
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out if a.verbose else compact_line(out)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process and return its exit code."""
-    import socket
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --standalone --nnodes=1
+    --nproc-per-node N --local-addr 127.0.0.1 bench.py <same arguments>` as a child process and return its exit code.
+    --standalone lets the launcher bind its own free rendezvous port (a port probed here and passed on could be taken by
+    another process in between)."""
     import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", str(n),
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench.py] --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
     return subprocess.call(cmd)
+
+
+# ---- the compact JSON line -------------------------------------------------------------------------------------------
+# The driver keeps the last 8 KB of stdout.  Everything a reader needs to check a number stays (value, time per step,
+# steps, steady, roofline {frac, achieved, traffic, bytes per cell update}, check, workload); the bookkeeping (every timed
+# block, pf_status_string, notes, provenance strings) is --verbose only.
+_ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_cell_update", "kernel_ms_per_step",
+              "frac_hip_events")
+
+
+def _r(x, sig=6):
+    """floats at `sig` significant digits (the line is a report, not a checkpoint)"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_entry(e, main=False):
+    """one workload's dict -> its compact form (the main line keeps the contract keys, an `also` entry only what differs)"""
+    keep = ["value", "unit", "ms_per_step", "us_per_step", "steps", "steady"]   # (an `also` entry)
+    if main:
+        keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "steady", "repeats", "preheat_ms", "fenics_on_host"]
+    out = {k: e[k] for k in keep if k in e}
+    cfg = e.get("config", {})
+    ck = ("workload", "grid", "parallelism", "newton_iterations", "time_grid", "field_store", "transforms") if main else \
+         ("workload", "newton_iterations", "transforms")
+    out["config"] = {k: cfg[k] for k in ck if k in cfg}
+    rf = e.get("roofline")
+    if rf is not None or main:
+        out["roofline"] = None if rf is None else {k: rf[k] for k in (_ROOF_KEEP if main else _ROOF_KEEP[1:2] + _ROOF_KEEP[4:7])
+                                                   if k in rf}
+        if rf is not None and main and "device_copy" in rf:
+            out["roofline"]["device_copy_GBps"] = rf["device_copy"]["achieved"]
+    if "check" in e:
+        out["check"] = _r(e["check"], 12)
+    if "cpu_baseline" in e:
+        cb = e["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb[k] for k in (("value", "unit", "cores", "kind", "sample") if main else
+                                                  ("value", "cores", "kind"))}
+    if "ranks" in e and main:
+        rk = e["ranks"]
+        out["ranks"] = rk if rk["world_size"] > 1 else {"world_size": 1, "backend": rk["backend"],
+                                                        "device_name": rk.get("device_name")}
+    return out
+
+
+def compact_line(out):
+    line = _r(compact_entry(out, main=True), 7)
+    if "check" in out:
+        line["check"] = _r(out["check"], 12)
+    if "also" in out:
+        line["also"] = {k: _r(compact_entry(v), 6) for k, v in out["also"].items()}
+        for k, v in out["also"].items():
+            if "check" in v:
+                line["also"][k]["check"] = _r(v["check"], 10)
+    return line
 
 
 def workload_table(workload, world):
@@ -613,15 +701,16 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
                                           "kernel": "pfk_stream_copy (one 16-byte element per thread), %d doubles, 20 launches"
                                                     % local_cells}
         out["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
+    # CPU leg (the oracle on the host cores) is DEFERRED: the caller runs out["_cpu"] after every GPU measurement
     if model in ("bm6", "bm2", "bm3") or not cpu:
         pass          # no CPU leg for the BM6 box (the BM6 oracle is a test checker, minutes per step at this size)
     elif rank == 0 and world == 1 and scheme == "spectral":
-        out["cpu_baseline"] = cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8)
+        out["_cpu"] = lambda: out.__setitem__("cpu_baseline", cpu_baseline_spectral(gn[:dim], dt, 300 if dim == 2 else 8))
     elif rank == 0 and world == 1:
         if dim == 3:
-            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 64, dt, 400)
+            out["_cpu"] = lambda: out.__setitem__("cpu_baseline", cpu_baseline(gn[0], gn[1], 64, dt, 400))
         else:
-            out["cpu_baseline"] = cpu_baseline(gn[0], gn[1], 1, dt, 4000)
+            out["_cpu"] = lambda: out.__setitem__("cpu_baseline", cpu_baseline(gn[0], gn[1], 1, dt, 4000))
     if not slab:
         solver.close()
     torch.cuda.empty_cache()
@@ -631,10 +720,13 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
 def side_measurements(a, ctx):
     """Same run, same process, rank 0 of an N = 1 default run: the other configurations BASELINE.json's metric and
     north_star name -- the two 512^2 workloads (wall clock incl. launches), the 1024^3 stencil (north_star's roofline
-    target; own pre-heat, timed blocks, per-launch events), the 512^3 spectral step, and config 1 = the reference's own algorithm on the GPU with
-    its CPU restatement (oracle/fem_be.py) timed beside it and whether FEniCS itself is on the host."""
+    target; own pre-heat, timed blocks, per-launch events), the 512^3 spectral step, BM6 at 512^3 in both forms, BM2 / BM3
+    on the stencil design, and the reference's own algorithm on the GPU (BM1 = config 1, BM2, BM3) with its CPU restatement
+    timed beside it (deferred CPU legs: main() runs them after every GPU leg).
+    Order of the returned dict = order in the JSON line: the BASELINE-config lines come LAST, so that a reader who keeps
+    only the tail of the line keeps them."""
     from pfhubbenchmarks_amd.solver import PhaseFieldSolver
-    also = {}
+    res = {}
     for name, sch, nst, dts in (("bm1_spectral_512s", "spectral", 300, 1e-2), ("bm1_fd_512s", "fd", 4001, 1e-3)):
         with PhaseFieldSolver(dim=2, n=512, h=1.0, scheme=sch, device=ctx["local_rank"]) as s2:
             s2.set_ic_bm1(0.5, 0.05)
@@ -649,41 +741,41 @@ def side_measurements(a, ctx):
                 s2.sync()
                 reps.append(time.perf_counter() - t0)
             e2 = sorted(reps)[2]
-        also[name] = {"value": 512 * 512 * nst / e2, "unit": "cell-updates/s", "us_per_step": e2 / nst * 1e6,
-                      "steps": nst, "repeats": 5}
-    sp3 = bench_grid(a, "bm1_spectral_512c", ctx, max(10, min(a.steps, 50)), min(a.warmup, 10), cpu=False)
-    also["bm1_spectral_512c"] = {k: sp3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "preheat_ms", "repeats",
-                                                     "block_ms_per_step", "steady", "roofline", "check")}
-    also["bm1_spectral_512c"]["config"] = dict(sp3["config"], note="semi-implicit spectral scheme on the 512^3 box: four "
-                                               "hand-written LDS-FFT passes per step; roofline at the 72 B/cell-update idealisation")
-    big = bench_grid(a, "bm1_fd_1024c", ctx, max(10, min(a.steps, 50)), min(a.warmup, 10), cpu=False)
-    also["bm1_fd_1024c"] = {k: big[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "preheat_ms", "repeats",
-                                                "block_ms_per_step", "steady", "roofline", "check")}
-    also["bm1_fd_1024c"]["config"] = {"workload": "bm1_fd_1024c", "grid": big["config"]["grid"],
-                                      "note": "BASELINE.json config 4 on ONE GPU (16 GiB of state); north_star roofline target"}
-    keys = ("value", "unit", "ms_per_step", "steps", "warmup", "preheat_ms", "repeats", "block_ms_per_step", "steady",
-            "roofline", "check")
-    for name, note in (("bm6_fd_512c", "BASELINE.json config 5 on ONE GPU, periodic box: FFT Poisson solve (hand-written passes) + "
-                                       "coupled fused FD step per step; roofline at 72 B/cell-update (CH 16 + phi 8 + Poisson 48)"),
-                       ("bm6_fd_512c_elim", "the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c)): the "
-                                            "fused kernel alone, 16 B/cell-update")):
-        b6 = bench_grid(a, name, ctx, max(10, min(a.steps, 40)), min(a.warmup, 10), cpu=False)
-        also[name] = {k: b6[k] for k in keys}
-        also[name]["config"] = dict(b6["config"], note=note)
-    for name, note in (("bm2_fd_512c", "SURVEY 8f next-4 on the stencil design: BM2 (c + 4 order parameters) explicit FD, one-pass "
-                                       "LDS-tiled kernel; roofline at 80 B/cell-update (5 fields read once, written once)"),
-                       ("bm3_fd_512c", "BM3 (U, phi) explicit FD, streaming LDS-tiled kernel; roofline at 32 B/cell-update")):
-        bm = bench_grid(a, name, ctx, max(10, min(a.steps, 40)), min(a.warmup, 10), cpu=False)
-        also[name] = {k: bm[k] for k in keys if k != "check"}
-        also[name]["check"] = {"F_before": bm["check"]["F_before"], "F_after": bm["check"]["F_after"]}
-        also[name]["config"] = dict(bm["config"], note=note)
+            F2, C2, _ = s2.diagnostics()
+        bpc = 72.0 if sch == "spectral" else BYTES_PER_CELL_UPDATE
+        res[name] = {"value": 512 * 512 * nst / e2, "unit": "cell-updates/s", "us_per_step": e2 / nst * 1e6,
+                     "steps": nst, "repeats": 5, "steady": (max(reps) - min(reps)) <= 0.03 * e2,
+                     "config": {"workload": name, "grid": [512, 512, 1],
+                                "note": "launch-latency bound 2-D step (a 2 MiB problem): wall clock incl. launches"},
+                     "roofline": {"bound": "hbm", "achieved": bpc * 512 * 512 * nst / e2 / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": bpc * 512 * 512 * nst / e2 / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "bytes_per_cell_update": bpc},
+                     "check": {"F_after": F2, "C": C2}}
+    notes = {"bm1_spectral_512c": "semi-implicit spectral scheme on the 512^3 box: four hand-written LDS-FFT passes per step; "
+                                  "roofline at the 72 B/cell-update idealisation",
+             "bm1_fd_1024c": "BASELINE.json config 4 on ONE GPU (16 GiB of state); north_star roofline target",
+             "bm6_fd_512c": "BASELINE.json config 5 on ONE GPU, periodic box: FFT Poisson solve (hand-written passes) + coupled "
+                            "fused FD step per step; roofline at 72 B/cell-update (CH 16 + phi 8 + Poisson 48)",
+             "bm6_fd_512c_elim": "the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c)): the fused "
+                                 "kernel alone, 16 B/cell-update",
+             "bm2_fd_512c": "SURVEY 8f next-4 on the stencil design: BM2 (c + 4 order parameters) explicit FD, one-pass LDS-tiled "
+                            "kernel; roofline at 80 B/cell-update (5 fields read once, written once)",
+             "bm3_fd_512c": "BM3 (U, phi) explicit FD, streaming LDS-tiled kernel; roofline at 32 B/cell-update"}
+    for name in ("bm1_spectral_512c", "bm1_fd_1024c", "bm6_fd_512c", "bm6_fd_512c_elim", "bm2_fd_512c", "bm3_fd_512c"):
+        b = bench_grid(a, name, ctx, max(10, min(a.steps, 50 if name.startswith("bm1") else 40)), min(a.warmup, 10), cpu=False)
+        b["config"]["note"] = notes[name]
+        for k in ("metric", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "ranks"):
+            b.pop(k, None)
+        res[name] = b
     for model in ("bm2", "bm3"):
-        also["%s_fem_be" % model] = bench_fem_multi(a, model, steps=6, warmup=2, cpu=not a.no_cpu_baseline)
-    if not a.no_cpu_baseline:
-        fb = bench_fem_be(a, 1, steps=8, warmup=2, ncpu_max=3)
-        also["bm1_fem_be"] = {k: fb[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "check",
-                                                 "fenics_on_host", "cpu_baseline") if k in fb}
-    return also
+        res["%s_fem_be" % model] = bench_fem_multi(a, model, steps=6, warmup=2, cpu=not a.no_cpu_baseline)
+    fb = bench_fem_be(a, 1, steps=8, warmup=2, ncpu_max=3)
+    for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "roofline"):
+        fb.pop(k, None)
+    res["bm1_fem_be"] = fb
+    order = ("bm2_fem_be", "bm3_fem_be", "bm1_fem_be", "bm2_fd_512c", "bm3_fd_512c", "bm6_fd_512c_elim", "bm1_fd_512s",
+             "bm1_spectral_512s", "bm6_fd_512c", "bm1_fd_1024c", "bm1_spectral_512c")
+    return {k: res[k] for k in order}
 
 
 if __name__ == "__main__":

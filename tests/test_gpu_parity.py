@@ -1740,7 +1740,7 @@ def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scali
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", str(world), "--workload", workload, "--steps", "4", "--warmup", "2",
-                        "--preheat-s", "0.05", "--repeats", "2"],
+                        "--preheat-s", "0.05", "--repeats", "2", "--verbose"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -1809,11 +1809,18 @@ def test_bench_fem_be_workloads_standalone(workload):
     if p is not None:       # the documented defaults (100 steps are capped by the 73-row grid; warm-up 10)
         assert p.returncode == 0, p.stderr[-3000:]
         d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
-        assert d["warmup"] == 10 and d["steps"] == 63 and "cpu_baseline" in d
+        assert d["warmup"] == 10 and d["steps"] == 63 and d["cpu_baseline"]["kind"] == "port" and d["preheat_ms"] > 0
+
+
+ALSO_KEYS = ("bm2_fem_be", "bm3_fem_be", "bm1_fem_be", "bm2_fd_512c", "bm3_fd_512c", "bm6_fd_512c_elim", "bm1_fd_512s",
+             "bm1_spectral_512s", "bm6_fd_512c", "bm1_fd_1024c", "bm1_spectral_512c")
 
 
 def test_bench_contract_json_line():
-    """bench.py prints exactly one JSON line with the fields the driver reads (short run of the default workload)"""
+    """bench.py prints exactly one JSON line with the fields the driver reads (short run of the default workload), and the
+    line is COMPACT: the driver keeps the last 8 KB of stdout, round 3's 15 KB line lost five of its eleven side
+    measurements that way -- <= 6000 characters, every `also` entry recoverable from the last 6000 characters of stdout,
+    the BASELINE-config entries last."""
     import json
     import os
     import subprocess
@@ -1824,51 +1831,78 @@ def test_bench_contract_json_line():
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout
-    d = json.loads(lines[0])
+    assert len(lines[0]) <= 6000, len(lines[0])
+    tail = p.stdout[-6000:]
+    d = json.loads(tail[tail.index("{"):])                 # the whole line sits inside the tail a reader keeps
+    assert tuple(d["also"].keys()) == ALSO_KEYS            # ... with the BASELINE-config lines at its end
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "cell-updates/s" and d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f64"
     assert d["config"]["workload"] == "bm1_fd_512c" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["config"]["grid"] == [512, 512, 512]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and 0.2 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 2.0e9          # HBM bytes per launch >= algorithmic 2.15 GB
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "cell-updates/s" and cb["cores"] >= 1 and cb["value"] > 0
-    assert abs(d["value"] - 512 ** 3 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 512 ** 3 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-5 * d["value"]
     assert d["check"]["C_rel_drift"] < 1e-12
-    # timed-region bookkeeping: declared pre-heat, repeated K-step blocks, the reported block is the median one
-    assert d["preheat_ms"] >= 500.0 and d["preheat_steps"] > 100 and d["repeats"] == len(d["block_ms_per_step"]) == 25
-    assert sorted(d["block_ms_per_step"])[12] == d["ms_per_step"]
+    # timed-region bookkeeping: declared pre-heat, repeated K-step blocks (the blocks themselves are --verbose only)
+    assert d["preheat_ms"] >= 500.0 and d["repeats"] == 25 and "block_ms_per_step" not in d
+    # every side entry: value, time per step, steps, steady, roofline {frac, achieved, traffic, bytes}, check, workload
+    for k in ALSO_KEYS:
+        e = d["also"][k]
+        assert e["value"] > 0 and e["steps"] > 0 and ("ms_per_step" in e or "us_per_step" in e) and e["config"]["workload"] == k
+        assert "check" in e
+        if not k.endswith("_fem_be"):
+            assert set(e["roofline"]) == {"achieved", "frac", "traffic", "bytes_per_cell_update"} and "steady" in e
     # north_star's target configuration and the reference's own algorithm ride in the same line
     big = d["also"]["bm1_fd_1024c"]
-    assert big["config"]["grid"] == [1024, 1024, 1024] and 0.2 < big["roofline"]["frac"] < 1.0
-    assert abs(big["value"] - 1024 ** 3 / (big["ms_per_step"] * 1e-3)) < 1e-6 * big["value"]
+    assert 0.2 < big["roofline"]["frac"] < 1.0
+    assert abs(big["value"] - 1024 ** 3 / (big["ms_per_step"] * 1e-3)) < 1e-5 * big["value"]
     assert big["check"]["C_rel_drift"] < 1e-12 and big["check"]["F_after"] < big["check"]["F_before"]
     sp3 = d["also"]["bm1_spectral_512c"]
-    assert sp3["config"]["grid"] == [512, 512, 512] and sp3["roofline"]["bytes_per_cell_update"] == 72.0
+    assert sp3["roofline"]["bytes_per_cell_update"] == 72.0
     assert 0.1 < sp3["roofline"]["frac"] < 1.0 and sp3["check"]["C_rel_drift"] < 1e-12
-    assert sp3["config"]["field_store"] == "last two steps of each pf_step call"
     fb = d["also"]["bm1_fem_be"]
-    assert fb["unit"] == "node-updates/s" and fb["cpu_baseline"]["kind"] == "port" and fb["fenics_on_host"] in (True, False)
+    assert fb["unit"] == "node-updates/s" and fb["cpu_baseline"]["kind"] == "port"
     assert abs(fb["check"]["F"] - 190.1699) < 1e-3      # row t = 11.1 of the reference's bench1_out.csv
     # BASELINE.json config 5 (BM6 at 512^3, one GPU's share) in both forms, and the two extra models of SURVEY 8f next-4
     b6, b6e = d["also"]["bm6_fd_512c"], d["also"]["bm6_fd_512c_elim"]
     assert b6["roofline"]["bytes_per_cell_update"] == 72.0 and b6e["roofline"]["bytes_per_cell_update"] == 16.0
-    assert b6["config"]["grid"] == [512, 512, 512] and 0.05 < b6["roofline"]["frac"] < 1.0 and 0.2 < b6e["roofline"]["frac"] < 1.0
+    assert 0.05 < b6["roofline"]["frac"] < 1.0 and 0.2 < b6e["roofline"]["frac"] < 1.0
     assert b6["check"]["C_rel_drift"] < 1e-12 and b6e["check"]["C_rel_drift"] < 1e-12
     for m, nodes in (("bm2", 20201), ("bm3", 245701)):
         fm = d["also"]["%s_fem_be" % m]
-        assert fm["unit"] == "node-updates/s" and abs(fm["value"] - nodes * fm["steps"] / (fm["ms_per_step"] * 1e-3 * fm["steps"])) < 1e-6 * fm["value"]
-        assert fm["cpu_baseline"]["kind"] == "port" and fm["cpu_baseline"]["value"] > 0 and "reference_wall_time" in fm["config"]
+        assert fm["unit"] == "node-updates/s" and abs(fm["value"] - nodes / (fm["ms_per_step"] * 1e-3)) < 1e-5 * fm["value"]
+        assert fm["cpu_baseline"]["kind"] == "port-extrapolated" and fm["cpu_baseline"]["value"] > 0
     assert abs(d["also"]["bm2_fem_be"]["check"]["F"] - 3621.6143739566) < 1e-5       # row t = 0.63 of bench2_out.csv
     for nm, bpc in (("bm2_fd_512c", 80.0), ("bm3_fd_512c", 32.0)):                   # the same models on the stencil design
         fd = d["also"][nm]
         assert fd["roofline"]["bytes_per_cell_update"] == bpc and 0.3 < fd["roofline"]["frac"] < 1.0
-        assert "streaming" in fd["config"]["status"] and fd["config"]["grid"] == [512, 512, 512]
-    assert abs(r["frac"] - d["value"] * 16.0 / 1e9 / 8000.0) < 1e-9                  # the wall-clock figure IS the headline
+    assert abs(r["frac"] - d["value"] * 16.0 / 1e9 / 8000.0) < 1e-6                  # the wall-clock figure IS the headline
     assert r["frac_hip_events"] >= r["frac"] * 0.98 and d["ranks"]["world_size"] == 1
+
+
+def test_bench_verbose_line_keeps_the_bookkeeping():
+    """--verbose restores what the compact line drops: every timed block (the reported one is the median), the pre-heat step
+    count, pf_status_string, the spectral scheme's field-store mode, notes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "bm1_spectral_256c", "--steps", "4",
+                        "--warmup", "1", "--verbose", "--no-cpu-baseline", "--repeats", "5"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert d["repeats"] == len(d["block_ms_per_step"]) == 5 and sorted(d["block_ms_per_step"])[2] == d["ms_per_step"]
+    assert d["preheat_ms"] >= 500.0 and d["preheat_steps"] > 100
+    assert d["config"]["field_store"] == "last two steps of each pf_step call" and d["config"]["status"]
+    assert d["config"]["grid"] == [256, 256, 256] and "traffic_source" in d["roofline"]
 
 
 def test_b13d_driver_3d_extrusion_invariants(lib, tmp_path):
