@@ -128,14 +128,14 @@ constexpr int SX = 128, SPITCH = 132;   // tile width; LDS row pitch (own cells 
 template <int PASS>
 struct PassTraits;
 template <>
-struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 4; };   // stencilled fields, pointwise inputs, rows per thread
+struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 4, MINW = 3; };   // stencilled fields, pointwise inputs, rows per thread, waves per SIMD asked of the register allocator
 template <>
-struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2; };
+struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2, MINW = 1; };
 template <>
-struct PassTraits<21> { static constexpr int NS = 5, NPW = 1, RPT = 1; };
+struct PassTraits<21> { static constexpr int NS = 5, NPW = 1, RPT = 1, MINW = 1; };
 
 template <int PASS>
-__global__ __launch_bounds__(256) void mfd_stream_kernel(const MfdParams p, const double* __restrict__ u,
+__global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel(const MfdParams p, const double* __restrict__ u,
                                                          const double* __restrict__ mu_in, double* __restrict__ out,
                                                          double dt, int zchunk) {
   using T = PassTraits<PASS>;
@@ -169,22 +169,31 @@ __global__ __launch_bounds__(256) void mfd_stream_kernel(const MfdParams p, cons
   }
   MFD_LOAD_OWN(zm, zb - 1)
   MFD_LOAD_OWN(zc, zb)
+  // halo of a plane: rows y0 - 1 and y0 + TY (waves 0 and 1), columns x0 - 1 and x0 + 128 (wave 2), periodic wrap
+  // (every wave forms both addresses -- clamped to something valid -- and loads under a predicate: arrays that are
+  // written in one branch only end up in scratch memory).  The halo of plane z + 1 is requested TOGETHER with the own
+  // cells of plane z + 1, one iteration before it is used: a halo row is an own row of the y-neighbour tile, which
+  // requests it for ITS plane z + 1 at that moment, so the two requests meet in the XCD's L2.  Requested one plane later
+  // (with the own cells of z + 2, the round-3 form) the line had already left the 4 MiB L2 -- one plane step of an XCD's
+  // 128 tiles is 4 MB -- and came from HBM a second time: 1.52x the input bytes (profiles/r03/summary_bm3_fd_512c.json).
+  const bool do_row = wave < 2, do_col = wave == 2 && lane < 2 * TY;
+  const int yh = wrapm(wave == 0 ? y0 - 1 : y0 + TY, p.ny);
+  const int yy = y0 + (do_col ? (lane >> 1) : 0), xh = wrapm((lane & 1) ? x0 + SX : x0 - 1, p.nx);
+  const int64_t arow0 = (int64_t)yh * row + xo, acol0 = (int64_t)yy * row + xh;
+  double2 hrow[NS], hrow_n[NS];
+  double hcol[NS], hcol_n[NS];
+#define MFD_LOAD_HALO(HR, HC, Z)                                                                                 \
+  {                                                                                                              \
+    const int64_t zo_ = (int64_t)wrapm((Z), p.nz) * plane;                                                       \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                             \
+      HR[s] = do_row ? *reinterpret_cast<const double2*>(sfield(s) + zo_ + arow0) : make_double2(0.0, 0.0);      \
+      HC[s] = do_col ? sfield(s)[zo_ + acol0] : 0.0;                                                             \
+    }                                                                                                            \
+  }
+  MFD_LOAD_HALO(hrow, hcol, zb)
   for (int z = zb; z < ze; ++z) {
     MFD_LOAD_OWN(zp, z + 1)
-    // halo of plane z: rows y0 - 1 and y0 + TY (waves 0 and 1), columns x0 - 1 and x0 + 128 (wave 2), periodic wrap
-    // (every wave forms both addresses -- clamped to something valid -- and loads under a predicate: arrays that are
-    // written in one branch only end up in scratch memory)
-    const bool do_row = wave < 2, do_col = wave == 2 && lane < 2 * TY;
-    const int yh = wrapm(wave == 0 ? y0 - 1 : y0 + TY, p.ny);
-    const int yy = y0 + (do_col ? (lane >> 1) : 0), xh = wrapm((lane & 1) ? x0 + SX : x0 - 1, p.nx);
-    const int64_t arow = z * plane + (int64_t)yh * row + xo, acol = z * plane + (int64_t)yy * row + xh;
-    double2 hrow[NS];
-    double hcol[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      hrow[s] = do_row ? *reinterpret_cast<const double2*>(sfield(s) + arow) : make_double2(0.0, 0.0);
-      hcol[s] = do_col ? sfield(s)[acol] : 0.0;
-    }
+    MFD_LOAD_HALO(hrow_n, hcol_n, z + 1)
     double2 pw[NPW > 0 ? NPW : 1][RPT];
 #pragma unroll
     for (int k = 0; k < NPW; ++k)
@@ -294,14 +303,18 @@ __global__ __launch_bounds__(256) void mfd_stream_kernel(const MfdParams p, cons
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         zm[s][r] = zc[s][r];
         zc[s][r] = zp[s][r];
       }
+      hrow[s] = hrow_n[s];
+      hcol[s] = hcol_n[s];
+    }
   }
 #undef MFD_LOAD_OWN
+#undef MFD_LOAD_HALO
 }
 
 // =====================================================================================================================

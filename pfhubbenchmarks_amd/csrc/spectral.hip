@@ -330,7 +330,8 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   int rc = ensure_chat(sp, c_in);
   if (rc) return rc;
   if (sp->fast) {
-    if (fused2d_step(sp->fast, c_in, store_field ? c_out : nullptr, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho,
+    static const bool inplace = getenv("PFHIP_SPEC_INPLACE") && getenv("PFHIP_SPEC_INPLACE")[0] == '1';  // EXPERIMENT
+    if (fused2d_step(sp->fast, c_in, store_field ? c_out : nullptr, sp->chat, sp->ghat, (inplace && sp->nz > 1) ? sp->ghat : sp->scratch, dt, M, kappa, ca, cb, two_rho,
                      dt * M * sp->gq) != 0) {
       sp->err = "fused2d_step launch failed";
       return -3;

@@ -1541,6 +1541,11 @@ struct Fused2D {
   unsigned* pctl_host = nullptr;
   bool persist = false;       // 2-D 512 x 512: steps that store no field run many-per-launch on one XCD (PFHIP_SPECTRAL_PERSIST)
   int* queues = nullptr;  // 2 sets x 8 per-XCD heads (XcdQueue), zero-initialised; launch n uses set n & 1
+  // z-chunked middle of the step (y inverse -> x -> y forward per chunk of planes, see fused2d_step): planes per chunk
+  // (0 = whole box, one launch per pass) and the side streams the chunks are dealt to
+  int chunk = 0, nside = 0;
+  hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable unsigned qepoch = 0;
   int ncu = 256;
 };
@@ -1709,6 +1714,19 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       f->ncu = prop.multiProcessorCount;
   }
+  if (f->cube512) {
+    if (const char* e = getenv("PFHIP_FFT3D_CHUNK")) f->chunk = std::atoi(e);
+    int ns = 0;
+    if (const char* e = getenv("PFHIP_FFT3D_CHUNK_STREAMS")) ns = std::atoi(e);
+    if (f->chunk > 0 && ns > 1) {
+      f->nside = ns > 4 ? 4 : ns;
+      if (hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
+      for (int k = 0; k < f->nside; ++k)
+        if (hipStreamCreateWithFlags(&f->side[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&f->ev_join[k], hipEventDisableTiming) != hipSuccess)
+          return -3;
+    }
+  }
   if (const char* cg = getenv("PFHIP_FFT3D_CWG")) {
     const int c = std::atoi(cg);
     g_cwg = (c == 4 || c == 8) ? c : 0;
@@ -1788,6 +1806,11 @@ void fused2d_destroy(Fused2D* f) {
   if (f->tw8b) (void)hipFree(f->tw8b);
   if (f->sym) (void)hipFree(f->sym);
   if (f->queues) (void)hipFree(f->queues);
+  for (int k = 0; k < 4; ++k) {
+    if (f->side[k]) (void)hipStreamDestroy(f->side[k]);
+    if (f->ev_join[k]) (void)hipEventDestroy(f->ev_join[k]);
+  }
+  if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
   if (f->pctl) (void)hipFree(f->pctl);
   if (f->pctl_host) (void)hipHostFree(f->pctl_host);
   delete f;
@@ -2250,6 +2273,34 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
       launch_col3<0>(f, a, G, nullptr, nullptr, 1);
     }
     launch_col3<2>(f, a, G, chat, H, 2);        // z: forward, k-space update of chat, inverse -> H
+    if (f->chunk > 0 && f->chunk < a.nz && a.zb == 0 && a.nyp == a.ny) {
+      // y inverse -> x -> y forward, chunk of planes by chunk of planes: the three passes only couple points of one
+      // z-plane, and a chunk (planes x 2.06 MB per array) that fits the 256 MiB Infinity Cache is still on the die when the
+      // next pass reads it
+      const int64_t plane = (int64_t)a.ny * a.pitch;
+      if (f->nside > 0) {
+        if (hipEventRecord(f->ev_fork, f->stream) != hipSuccess) return -3;
+        for (int k = 0; k < f->nside; ++k)
+          if (hipStreamWaitEvent(f->side[k], f->ev_fork, 0) != hipSuccess) return -3;
+      }
+      int k = 0;
+      for (int z0 = 0; z0 < a.nz; z0 += f->chunk, ++k) {
+        F2Args ac = a;
+        ac.nz = a.nz - z0 < f->chunk ? a.nz - z0 : f->chunk;
+        Fused2D fs = *f;  // (launch descriptor only: the launchers read geometry, tables and the stream from it)
+        if (f->nside > 0) fs.stream = f->side[k % f->nside];
+        double2 *Hc = H + z0 * plane, *Gc = G + z0 * plane;
+        launch_col3<1>(&fs, ac, Hc, nullptr, nullptr, 1);
+        launch_row3(&fs, ac, Hc, nullptr, c_out ? c_out + (int64_t)z0 * a.ny * a.nx : nullptr, Gc, 1, 1);
+        launch_col3<0>(&fs, ac, Gc, nullptr, nullptr, 1);
+      }
+      for (int j = 0; j < f->nside; ++j)
+        if (hipEventRecord(f->ev_join[j], f->side[j]) != hipSuccess ||
+            hipStreamWaitEvent(f->stream, f->ev_join[j], 0) != hipSuccess)
+          return -3;
+      f->g_valid = true;
+      return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     launch_col3<1>(f, a, H, nullptr, nullptr, 1);  // y: inverse, in place
     launch_row3(f, a, H, nullptr, c_out, G, 1, 1);  // x: inverse -> c_out, f'(c_out), forward -> G
     launch_col3<0>(f, a, G, nullptr, nullptr, 1);  // y: forward, in place (ready for the next step's z pass)
