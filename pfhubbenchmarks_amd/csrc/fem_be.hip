@@ -220,17 +220,6 @@ __global__ __launch_bounds__(256) void fem_update_kernel(const FemParams p, cons
   if (p.nf == 3) phi[n] += s[2];
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
-  // single block, fixed order -> deterministic; n is ~1e5
-  __shared__ double sh[4];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += v[i] * v[i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
 
 // diagnostics: per-triangle contributions, reduced per block then by a final block
 __global__ __launch_bounds__(256) void fem_diag_kernel(const FemParams p, const int* __restrict__ tri,
@@ -840,61 +829,6 @@ __global__ __launch_bounds__(64) void row_factor_kernel(int nb, int n1, const do
   }
 }
 
-// one thread per (matrix, right-hand-side column): columns 0..nb-1 of L_e, nb..2nb-1 of U_e, 2nb = r_e; in place
-template <int NF>
-__global__ __launch_bounds__(256) void row_solve_kernel(int nb, int n1, const double* __restrict__ fac, double* Lm,
-                                                        double* Um, double* rv, int64_t stride_mat,
-                                                        int64_t stride_vec) {
-  const int j = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
-  if (j > 2 * nb) return;
-  double* col = j < nb ? Lm + (int64_t)m * stride_mat + (int64_t)j * nb
-                       : (j < 2 * nb ? Um + (int64_t)m * stride_mat + (int64_t)(j - nb) * nb : rv + (int64_t)m * stride_vec);
-  const double* F = fac + (int64_t)m * n1 * 3 * NF * NF;
-  // a coupling column is zero above corner (its own corner - 1): the forward sweep starts there
-  const int l0 = j < 2 * nb ? max(0, (j % nb) / NF - 1) : 0;
-  double y[NF];
-#pragma unroll
-  for (int a = 0; a < NF; ++a) y[a] = 0.0;
-  // (unrolled so that the column loads of the next corners are in flight while this one's recurrence is evaluated)
-#pragma unroll 4
-  for (int l = l0; l < n1; ++l) {
-    const double* Fl = F + (int64_t)l * 3 * NF * NF;
-    double t[NF];
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      double acc = col[l * NF + a];
-#pragma unroll
-      for (int b = 0; b < NF; ++b) acc -= Fl[2 * NF * NF + a * NF + b] * y[b];
-      t[a] = acc;
-    }
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      double acc = 0.0;
-#pragma unroll
-      for (int b = 0; b < NF; ++b) acc += Fl[a * NF + b] * t[b];
-      y[a] = acc;
-    }
-#pragma unroll
-    for (int a = 0; a < NF; ++a) col[l * NF + a] = y[a];
-  }
-#pragma unroll 4
-  for (int l = n1 - 2; l >= 0; --l) {  // y holds x_(l+1)
-    const double* Fl = F + (int64_t)l * 3 * NF * NF;
-    double x[NF];
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      double acc = col[l * NF + a];
-#pragma unroll
-      for (int b = 0; b < NF; ++b) acc -= Fl[NF * NF + a * NF + b] * y[b];
-      x[a] = acc;
-    }
-#pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      col[l * NF + a] = x[a];
-      y[a] = x[a];
-    }
-  }
-}
 
 // The same sweeps with the columns staged through LDS (round 3): one thread per column walking down its column reads one
 // 8 NF-byte piece per lane and step from 64 different cache lines (row_solve_kernel: 4.0 ms per BM3 call, 8 % of its step).
@@ -1051,17 +985,6 @@ __global__ __launch_bounds__(256) void gen_update_kernel(const FemParams p, cons
   for (int f = 0; f < NF; ++f) u.u[f][n] += scale * s[f];
 }
 
-__global__ __launch_bounds__(256) void dot_kernel(const double* __restrict__ a, const double* __restrict__ b, int n,
-                                                  double* __restrict__ out) {
-  __shared__ double sh[4];  // single block, fixed order -> deterministic
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += a[i] * b[i];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
 
 // a . b in two stages (256 blocks over contiguous chunks, then one wave over the 256 partial sums; fixed order ->
 // deterministic): the single-block forms above take 109 us (BM2, 1.2e5 entries) / 442 us (BM3, 4.9e5) per residual norm
@@ -1230,10 +1153,11 @@ struct FemBE {
                                            // pivoted retry of a failed Newton solve; PFHIP_FEM_PIVOT=1: always, =0: never
   bool force_pivot = false;                // set for the retry
   bool own_trsm = true;                    // D^-1 [L | U | r] of the dense levels by lu_solve_mfma_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS trsm / rocSOLVER getrs)
-  bool two_stage_dots = true;              // residual norm / line-search dot products in two stages (PFHIP_FEM_DOTS=single: one block)
   bool own_getrf = true;                   // un-pivoted LU of the dense levels by lu_npvt_coop_kernel (PFHIP_FEM_GETRF=rocsolver: getrf_npvt)
   int* tflags = nullptr;                   // its panel flags: (ng / 2 + 1) x ceil(nb / 16)
-  bool own_gemv = true;                    // y -= A x of the levels by gemv_sub_kernel (PFHIP_FEM_GEMV=rocblas: rocBLAS)
+  bool getrf_check = false;                // PFHIP_FEM_GETRF=check (DEBUG): own LU and rocSOLVER's, compared entry by entry on the host
+  bool test_starve = false;                // PFHIP_FEM_TEST_LU_STARVE=1 (TEST ONLY): the cooperative LU is launched with half of its workgroups
+  bool own_gemv = true;                    // y -= A x of the levels by gemv_sub_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS, with the substitutions)
   bool own_getrs = true;                   // ... and of the pivoted levels of 400+ unknowns (PFHIP_FEM_TRSM=npvt: only the un-pivoted)
   int* tperm = nullptr;                    // gather maps of the row exchanges: (ng / 2 + 1) x nb
   double* tinv = nullptr;                  // its inverted 16 x 16 diagonal blocks: (ng / 2) matrices x ceil(nb / 16) blocks x 2 x 256
@@ -1415,14 +1339,14 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       const char* ts = getenv("PFHIP_FEM_TRSM");
       fb->own_trsm = !(ts && std::string(ts) == "rocblas");
       fb->own_getrs = !(ts && std::string(ts) == "npvt");
-      const char* dd = getenv("PFHIP_FEM_DOTS");
-      fb->two_stage_dots = !(dd && std::string(dd) == "single");
       const char* gf = getenv("PFHIP_FEM_GETRF");
       fb->own_getrf = !(gf && std::string(gf) == "rocsolver");
-      const char* gv = getenv("PFHIP_FEM_GEMV");
-      fb->own_gemv = !(gv && std::string(gv) == "rocblas");
+      fb->own_gemv = fb->own_trsm;
+      fb->getrf_check = gf && std::string(gf) == "check";
       const char* tp = getenv("PFHIP_FEM_TEST_POISON_NPVT");
       fb->test_poison = tp && tp[0] == '1';
+      const char* sv = getenv("PFHIP_FEM_TEST_LU_STARVE");
+      fb->test_starve = sv && sv[0] == '1';
       const char* v = getenv("PFHIP_FEM_VERBOSE");
       fb->verbose = v && v[0] == '1';
     }
@@ -1691,10 +1615,7 @@ static int residual_norm(FemBE* fb, double inv_dt, double* nrm, double* out = nu
   hipLaunchKernelGGL(fem_residual_kernel, dim3((p.nn + 255) / 256), dim3(256), 0, fb->stream, p, fb->ell_col, fb->ell_K,
                      fb->ell_M, fb->nt_ptr, fb->nt_tri, fb->nt_loc, fb->tri, fb->c, fb->mu, fb->phi, fb->c0, inv_dt,
                      fb->rhs);
-  if (fb->two_stage_dots)
-    dot_two_stage(fb->stream, fb->rhs, fb->rhs, (int)fb->vec_len, fb->partials, fb->scal);
-  else
-    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs, (int)fb->vec_len, fb->scal);
+  dot_two_stage(fb->stream, fb->rhs, fb->rhs, (int)fb->vec_len, fb->partials, fb->scal);
   FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));  // [3]: info flag
   FB_HIP(hipStreamSynchronize(fb->stream));
   *nrm = std::sqrt(fb->scal_host[0]);
@@ -2025,10 +1946,7 @@ __global__ __launch_bounds__(64 * TS_W) void lu_solve_mfma_kernel(int n, const d
 static void lu_solve_level(hipStream_t stream, int nb, int ne, const double* De, int64_t st, const rocblas_int* piv,
                            int64_t piv_stride, double* tinv, int* perm, double* Xu, double* Xl, double* xr, int64_t sv,
                            bool rhs_only = false) {
-  static const int warm = [] {
-    const char* v = getenv("PFHIP_FEM_TRSM_WARM");   // A/B: 0 = no L2 warm-up of the factors
-    return v ? atoi(v) : 1;
-  }();
+  const int warm = 1;   // each pass first touches its triangle once per 128-byte line (L2 warm-up of the factors)
   const int ntile = (nb + TS_NB - 1) / TS_NB, npan = rhs_only ? 0 : (nb + TS_NC - 1) / TS_NC;   // rhs_only: the column xr alone
   hipLaunchKernelGGL(lu_diag_inv_kernel, dim3(ntile, ne), dim3(64), 0, stream, nb, De, st, tinv);
   if (piv) hipLaunchKernelGGL(piv_to_perm_kernel, dim3(ne), dim3(64), 0, stream, nb, piv, piv_stride, perm);
@@ -2414,15 +2332,13 @@ __global__ void lu_npvt_done_kernel(int* __restrict__ tickets, int* __restrict__
 }
 
 static void lu_npvt_coop(hipStream_t stream, int nb, int ne, int G, double* De, int64_t st, double* dinv, int* flags,
-                         double* sing_flag) {
+                         double* sing_flag, bool starve) {
   // flags: [0, 256) the per-XCD ticket counters (one per 128 bytes), then ne x ntile panel flags
   const int ntile = (nb + 15) / 16, maxt = (ntile + CL_W - 1) / CL_W;
   int* tickets = flags;
   flags += 256;
   // TEST ONLY (PFHIP_FEM_TEST_LU_STARVE=1): launch half of the workgroups, so that matrices are left without partners --
   // what a part with another XCD count or CU share would do to the ticket scheme; short spins so that the test is quick
-  const char* sv_env = getenv("PFHIP_FEM_TEST_LU_STARVE");   // (read per call: the tests switch it between handles)
-  const bool starve = sv_env && sv_env[0] == '1';
   const int spin_limit = starve ? 1 << 12 : CL_SPIN;
   const dim3 grid(starve ? 8 * ((ne + 7) / 8) * G / 2 : 8 * ((ne + 7) / 8) * G), block(64 * CL_W);
   if (maxt <= 2)
@@ -2520,21 +2436,12 @@ static int block_solve_bcr(FemBE* fb) {
       double* Le = Lc + (int64_t)s * bs;
       double* Ue = Uc + (int64_t)s * bs;
       double* re = fb->rhs + (int64_t)s * nb;
-      const dim3 gs((2 * nb + 1 + 255) / 256, ne);
       with_nf(fb->gen_nf, [&](auto nfc) {
         constexpr int NF = decltype(nfc)::value;
         hipLaunchKernelGGL(row_factor_kernel<NF>, dim3(ne), dim3(64), 0, fb->stream, nb, n1, (const double*)De, st, ne,
                            fb->fac);
-        static const bool tiled = [] {
-          const char* v = getenv("PFHIP_FEM_ROWSOLVE");   // A/B: "simple" = one thread per column straight from memory
-          return !(v && std::string(v) == "simple");
-        }();
-        if (tiled)
-          hipLaunchKernelGGL(row_solve_tiled_kernel<NF>, dim3((2 * nb + 1 + 63) / 64, ne), dim3(256), 0, fb->stream, nb, n1,
-                             (const double*)fb->fac, Le, Ue, re, st, sv);
-        else
-          hipLaunchKernelGGL(row_solve_kernel<NF>, gs, dim3(256), 0, fb->stream, nb, n1, (const double*)fb->fac, Le, Ue, re,
-                             st, sv);
+        hipLaunchKernelGGL(row_solve_tiled_kernel<NF>, dim3((2 * nb + 1 + 63) / 64, ne), dim3(256), 0, fb->stream, nb, n1,
+                           (const double*)fb->fac, Le, Ue, re, st, sv);
       });
       FB_HIP(hipGetLastError());
     }
@@ -2579,17 +2486,9 @@ static int block_solve_bcr(FemBE* fb) {
       ++fb->npvt_levels;
       if (fb->own_getrf && nb <= TS_NMAX) {
         // G cooperating workgroups per matrix, all resident: 8 * ceil(ne / 8) * G <= 256; larger batches 32 matrices at a time
-        static const int g_over = [] {
-          const char* v = getenv("PFHIP_FEM_LU_G");   // A/B: workgroups per matrix (<= 256 / (8 ceil(ne / 8)))
-          return v ? atoi(v) : 0;
-        }();
         const int ne_launch = ne < 32 ? ne : 32;
-        int G = ne_launch <= 16 ? 16 : 8;   // (32 per matrix for ne <= 8 is slower: more pollers of the same flags)
-        if (g_over > 0 && g_over < G) G = g_over;
-        static const bool check = [] {
-          const char* v = getenv("PFHIP_FEM_GETRF");
-          return v && std::string(v) == "check";
-        }();
+        const int G = ne_launch <= 16 ? 16 : 8;   // (32 per matrix for ne <= 8 is slower: more pollers of the same flags)
+        const bool check = fb->getrf_check;
         std::vector<double> ref, mine;
         if (check) {   // DEBUG: the same batch through rocSOLVER, compared entry by entry on the host
           double* tmp = nullptr;
@@ -2606,7 +2505,7 @@ static int block_solve_bcr(FemBE* fb) {
           const int nn = ne - e0 < 32 ? ne - e0 : 32;
           const int GG = nn <= 16 ? (G > 16 ? 16 : G) : (G > 8 ? 8 : G);
           lu_npvt_coop(fb->stream, nb, nn, GG < (nb + 15) / 16 ? GG : (nb + 15) / 16, De + (int64_t)e0 * st, st, fb->tinv,
-                       fb->tflags, fb->scal + 3);
+                       fb->tflags, fb->scal + 3, fb->test_starve);
         }
         FB_HIP(hipGetLastError());
         if (check) {
@@ -2710,14 +2609,10 @@ static int block_solve_bcr(FemBE* fb) {
                                            count);
     };
     if (banded) {
-      static const bool band_mfma = [] {
-        const char* v = getenv("PFHIP_FEM_BANDGEMM");   // A/B: "simple" = one thread per (row, 8 columns) through L1
-        return !(v && std::string(v) == "simple");
-      }();
       auto band_gemm = [&](const double* Lb, const double* X, double* C, double beta, int count) {
         with_nf(fb->gen_nf, [&](auto nfc) {
           constexpr int NF = decltype(nfc)::value;
-          if (band_mfma && NF <= 6) {   // (15 + 3 NF columns of a row tile's band fit 4 k tiles)
+          if (NF <= 6) {   // (15 + 3 NF columns of a row tile's band fit 4 k tiles)
             const int ntile = (nb + 15) / 16, strip = 8;
             const dim3 g((ntile + 3) / 4, (ntile + strip - 1) / strip, count);
             hipLaunchKernelGGL(band_gemm_mfma_kernel<NF>, g, dim3(256), 0, fb->stream, nb, Lb, st, X, st, C, st, -1.0, beta,
@@ -2764,7 +2659,8 @@ static int block_solve_bcr(FemBE* fb) {
   if (fb->pivot_mode == 2 && !fb->force_pivot && fb->own_getrf && fb->own_trsm && nb <= TS_NMAX) {
     // the last block under the optimistic policy: like the small batches before it (36 panel launches of 45 us otherwise)
     fb->used_npvt = true;
-    lu_npvt_coop(fb->stream, nb, 1, 16 < (nb + 15) / 16 ? 16 : (nb + 15) / 16, fb->D, bs, fb->tinv, fb->tflags, fb->scal + 3);
+    lu_npvt_coop(fb->stream, nb, 1, 16 < (nb + 15) / 16 ? 16 : (nb + 15) / 16, fb->D, bs, fb->tinv, fb->tflags, fb->scal + 3,
+                 fb->test_starve);
     lu_solve_level(fb->stream, nb, 1, fb->D, bs, nullptr, 0, fb->tinv, nullptr, nullptr, nullptr, fb->rhs, nb, true);
     FB_HIP(hipGetLastError());
   } else if (fb->pivot_mode != 0) {  // the last block: with row exchanges unless they are switched off altogether
@@ -2891,15 +2787,8 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
         double n1 = 0.0;
         rc = residual_norm(fb, inv_dt, &n1, fb->rhs1);  // -R(u + d)
         if (rc) return rc;
-        if (fb->two_stage_dots) {
-          dot_two_stage(fb->stream, fb->rhs0, fb->rhs, ntot, fb->partials, fb->scal);
-          dot_two_stage(fb->stream, fb->rhs1, fb->rhs, ntot, fb->partials + 256, fb->scal + 1);
-        } else {
-        hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs0, (const double*)fb->rhs,
-                           ntot, fb->scal);
-        hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, fb->stream, (const double*)fb->rhs1, (const double*)fb->rhs,
-                           ntot, fb->scal + 1);
-        }
+        dot_two_stage(fb->stream, fb->rhs0, fb->rhs, ntot, fb->partials, fb->scal);
+        dot_two_stage(fb->stream, fb->rhs1, fb->rhs, ntot, fb->partials + 256, fb->scal + 1);
         FB_HIP(hipMemcpyAsync(fb->scal_host, fb->scal, 2 * sizeof(double), hipMemcpyDeviceToHost, fb->stream));
         FB_HIP(hipStreamSynchronize(fb->stream));
         // PETSc's variables (W = X - lambda Y with Y = J^-1 F = -d): fty = F(W) . Y = -(R . d)

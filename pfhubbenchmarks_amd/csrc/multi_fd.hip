@@ -681,6 +681,8 @@ struct MultiFD {
   bool have_prev = false;
   bool own_u = true;
   hipStream_t stream = nullptr;
+  bool use_stream = true;  // PFHIP_MFD_STREAM=0 (read at create): one-thread-per-cell kernels everywhere (A/B)
+  bool bm2_fused = true;   // PFHIP_BM2_FUSED=0: BM2 by the two streaming passes (mu through HBM) instead of the one-pass kernel
   std::string err;
 };
 
@@ -709,6 +711,8 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, dou
   p.nz = nz;
   p.gz = gz;
   p.inv_h2 = 1.0 / (h * h);
+  if (const char* e = getenv("PFHIP_MFD_STREAM")) mf->use_stream = e[0] != '0';
+  if (const char* e = getenv("PFHIP_BM2_FUSED")) mf->bm2_fused = e[0] != '0';
   for (double& q : p.q) q = 0.0;
   if (model == 2) {
     for (int i = 0; i < 9; ++i) p.q[i] = mp[i];
@@ -776,8 +780,6 @@ double* multifd_field_ptr(MultiFD* mf, int f) {   // the owned planes
 void multifd_touch(MultiFD* mf) { mf->have_prev = false; }
 
 namespace {
-int g_mfd_stream = 1;  // PFHIP_MFD_STREAM=0: one-thread-per-cell kernels everywhere (A/B)
-int g_bm2_fused = 1;   // PFHIP_BM2_FUSED=0: BM2 by the two streaming passes (mu through HBM) instead of the one-pass kernel
 // z-chunks so that the grid holds about 4 workgroups per CU
 template <int PASS>
 void launch_stream(const MultiFD* mf, const double* u, const double* mu, double* out, double dt) {
@@ -795,20 +797,18 @@ void launch_stream(const MultiFD* mf, const double* u, const double* mu, double*
 // which kernels multifd_step uses on this box: 1 = the streaming LDS-tiled forms, 0 = one thread per cell
 int multifd_streaming(const MultiFD* mf) {
   const MfdParams& p = mf->p;
-  return g_mfd_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 16 == 0;   // tile heights: 16 (BM3), 8 / 4 (BM2 passes), 8 (one-pass BM2)
+  return mf->use_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 16 == 0;   // tile heights: 16 (BM3), 8 / 4 (BM2 passes), 8 (one-pass BM2)
 }
 
 int multifd_step(MultiFD* mf, double dt, int nsteps) {
   const MfdParams& p = mf->p;
   const unsigned nb = (unsigned)((mf->cells + 255) / 256);
-  if (const char* e = getenv("PFHIP_MFD_STREAM")) g_mfd_stream = e[0] != '0';
-  if (const char* e = getenv("PFHIP_BM2_FUSED")) g_bm2_fused = e[0] != '0';
   const bool stream = multifd_streaming(mf) != 0;
   for (int s = 0; s < nsteps; ++s) {
     const double* u = mf->u[mf->cur];
     double* un = mf->u[1 - mf->cur];
     if (stream) {
-      if (p.model == 2 && g_bm2_fused) {
+      if (p.model == 2 && mf->bm2_fused) {
         const int tiles = (p.nx / SX) * (p.ny / B2TY);
         int nchunk = (256 + tiles - 1) / tiles;   // one workgroup per CU
         if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;

@@ -589,7 +589,11 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
   }
   const int64_t elems = g.plane * (int64_t)(g.nz + 2 * g.ghost);
   const bool mfd = multi && cfg->scheme == PF_SCHEME_FD_EXPLICIT;
-  if (cfg->ext_c[0] && !mfd) {
+  if (mfd) {
+    // BM2 / BM3 explicit FD: the state is nf fields x 2 time levels inside the MultiFD object (or the caller's ext_c buffers);
+    // the single-field block below would be ~2 GB per 512^3 slab that nothing reads (h->c stays null: every entry point
+    // branches on h->mf first, the slab entry points of the single-field path reject such handles)
+  } else if (cfg->ext_c[0]) {
     h->c[0] = cfg->ext_c[0];
     h->c[1] = cfg->ext_c[1];
   } else {
@@ -601,8 +605,10 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->c[1] = h->c[0] + placed_offset_bytes(elems, 1) / (int64_t)sizeof(double);
     if (with_phi) h->phi = h->c[0] + placed_offset_bytes(elems, 2) / (int64_t)sizeof(double);
   }
-  PF_HIP_C(hipMemsetAsync(h->c[0], 0, sizeof(double) * elems, h->stream));
-  PF_HIP_C(hipMemsetAsync(h->c[1], 0, sizeof(double) * elems, h->stream));
+  if (h->c[0]) {
+    PF_HIP_C(hipMemsetAsync(h->c[0], 0, sizeof(double) * elems, h->stream));
+    PF_HIP_C(hipMemsetAsync(h->c[1], 0, sizeof(double) * elems, h->stream));
+  }
   PF_HIP_C(hipMalloc(&h->partials, sizeof(double) * diag_partials_elems()));
   PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 8));
   PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 8, hipHostMallocDefault));
@@ -682,7 +688,7 @@ const char* pf_status_string(const pf_handle* h) {
     m->status = "fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction";
   } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
     m->status = "spectral: semi-implicit Fourier";
-    if (h->sp && spectral_probe_log(h->sp)[0]) m->status += std::string("; ") + spectral_probe_log(h->sp);
+    if (h->sp) m->status += std::string("; ") + spectral_path(h->sp);
   } else {
     FdArgs a = make_args(h, 1.0, 0, h->g.nz);
     const bool fused = c.kernel != PF_KERNEL_TWOPASS && ch_fd_fused_supported(a);
@@ -695,7 +701,7 @@ const char* pf_status_string(const pf_handle* h) {
       m->status = "WARNING fd: nx is odd (or a buffer is not 16-byte aligned), so the fused kernel cannot run -- two-pass "
                   "kernels, 40 B per cell update instead of 16 (about 6x slower); pad nx to an even number";
   }
-  if (h->po && poisson_probe_log(h->po)[0]) m->status += std::string("; Poisson work array: ") + poisson_probe_log(h->po);
+  if (h->po) m->status += std::string("; Poisson solve: ") + poisson_path(h->po);
   return m->status.c_str();
 }
 
@@ -1000,17 +1006,6 @@ int pf_step(pf_handle* h, double dt, int nsteps, pf_step_info* info) {
   }
   for (int s = 0; s < nsteps;) {
     const int left = nsteps - s;
-    if (h->sp && left > 2 && h->g.ghost == 0) {
-      // 512^2 with PFHIP_SPECTRAL_PERSIST=1: all but the last two steps of the call (the ones that store no field) in ONE
-      // launch on one XCD; "not available" (first step after the field was replaced, other sizes) falls through
-      const pf_config& c = h->cfg;
-      const int prc = spectral_steps_persistent(h->sp, left - 2, dt, c.M, c.kappa, c.c_alpha, c.c_beta, 2.0 * c.rho_s);
-      if (prc < 0) return fail(h, PF_ERR_HIP, spectral_error(h->sp));
-      if (prc == 0) {
-        s += left - 2;
-        continue;
-      }
-    }
     // spectral scheme: the state is the resident spectrum; the real-space field is written by the last two steps of the
     // call only -- what the caller can observe afterwards and what pf_rollback returns to (the same rule as the 2-D FD
     // multi-step launches below).  PFHIP_SPECTRAL_STORE_EVERY_STEP=1 writes it every step (A/B).
@@ -1076,6 +1071,7 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out) {
   if (!h || !out) return PF_ERR_INVALID;
   const Geometry& g = h->g;
   if (g.ghost == 0) return fail(h, PF_ERR_STATE, "no ghost planes (nranks == 1)");
+  if (h->mf) return fail(h, PF_ERR_STATE, "pf_halo_layout_get: BM2 / BM3 handles describe their fields through pf_field_halo_layout");
   out->base = h->c[h->cur];
   out->plane_elems = g.plane;
   out->ghost = g.ghost;
@@ -1117,6 +1113,7 @@ int pf_step_begin(pf_handle* h, double dt) {
   if (!h) return PF_ERR_INVALID;
   if (!(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step_begin: need dt > 0");
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_begin: not in slab mode");
+  if (h->mf) return fail(h, PF_ERR_STATE, "pf_step_begin: BM2 / BM3 slabs step through pf_step (ghost planes of every field refreshed first)");
   if (h->sf && !h->elim)
     return fail(h, PF_ERR_STATE, "pf_step_begin: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
@@ -1194,6 +1191,7 @@ int pf_step_slab_fused(pf_handle* h, double dt, const int64_t* flag_lo, const in
   if (!h) return PF_ERR_INVALID;
   if (!(dt > 0.0) || seq <= 0 || !timeout) return fail(h, PF_ERR_INVALID, "pf_step_slab_fused: need dt > 0, seq > 0, timeout");
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: not in slab mode");
+  if (h->mf) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: single-field FD path only");
   if (h->sf && !h->elim) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_slab_fused: a begin / finish step is open");
   const int g = h->g.ghost, nz = h->g.nz;
@@ -1223,6 +1221,7 @@ int64_t pf_a2a_buffer_doubles(const pf_config* cfg) {
 int pf_dist_begin(pf_handle* h, int op, double dt) {
   if (!h) return PF_ERR_INVALID;
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_dist_begin: not in slab mode (nranks == 1)");
+  if (h->mf) return fail(h, PF_ERR_STATE, "pf_dist_begin: BM2 / BM3 slabs need no distributed operation (pf_field_halo_layout + pf_step)");
   if (op != PF_DIST_OP_STEP && op != PF_DIST_OP_REFRESH) return fail(h, PF_ERR_INVALID, "pf_dist_begin: bad op");
   if (op == PF_DIST_OP_STEP && !(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_dist_begin: need dt > 0");
   if (h->step_open || h->d_op) return fail(h, PF_ERR_STATE, "pf_dist_begin: another distributed operation is open");

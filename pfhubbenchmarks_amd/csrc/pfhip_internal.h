@@ -4,7 +4,6 @@
 
 #include <cstdint>
 #include <cstdio>
-#include <functional>
 #include <string>
 
 #include "pfhip.h"
@@ -81,10 +80,9 @@ void spectral_invalidate(Spectral* sp);
 void spectral_set_screening(Spectral* sp, double gq);  // BM6: gq = k^2 / eps; the step then treats -M gq (c - mean) implicitly  // call whenever the real-space field changed behind the scheme's back
 int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, double M, double kappa, double ca,
                   double cb, double two_rho, hipStream_t stream, bool store_field = true);
-int spectral_steps_persistent(Spectral* sp, int nsteps, double dt, double M, double kappa, double ca, double cb, double two_rho);
 int spectral_grad_energy(Spectral* sp, const double* c, double* out_dev, hipStream_t stream);
 const char* spectral_error(const Spectral* sp);
-const char* spectral_probe_log(const Spectral* sp);  // "" or what the placement probe measured at create
+const char* spectral_path(const Spectral* sp);  // which transform kernels this handle runs
 
 // rocFFT through its native API (fftplan.hip): the library fallback for sizes the hand-written passes do not cover
 struct FftPlan;
@@ -97,8 +95,8 @@ void fftplan_destroy(FftPlan* p);
 // fused LDS-FFT spectral step for 2-D power-of-two grids (spectral2d_fused.hip); same spectrum layout as rocFFT D2Z
 struct Fused2D;
 bool fused2d_supported(int dim, int nx, int ny, int nz);
-struct SpecLayout {  // where row (z, y) of a half-spectrum array of the hand-written passes lives (spectral2d_fused.hip spec_row)
-  int pitch, zb, nyp, bp;
+struct SpecLayout {  // a half-spectrum array of the hand-written passes: [z][y][pitch] complex elements
+  int pitch;
   int64_t rows;      // rows to allocate (pitch complex elements each)
 };
 SpecLayout fused_spectrum_layout(int dim, int nx, int ny, int nz);
@@ -120,13 +118,9 @@ int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out,
 int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa);
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2);
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G);
-int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H);  // the 4 passes of a 3-D step, for timing only
-int fused3d_probe_poisson(Fused2D* f, double2* W);                           // the 3 column passes of the Poisson solve
-int place_block_by_probe(size_t bytes, unsigned char* first, hipStream_t stream, const std::function<int(unsigned char*)>& run,
-                         unsigned char** kept, std::string* log);
+const char* fused2d_describe(const Fused2D* f);  // one line: which kernels serve this box
 int fused2d_persistent_steps(Fused2D* f, double2* chat, double2* G, double2* H, int nsteps, double dt, double M, double kappa,
                              double ca, double cb, double two_rho, double gam);  // 0 done, 1 not available, -3 error
-int fused2d_persistent_participants(const Fused2D* f);
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
                  double M, double kappa, double ca, double cb, double two_rho, double gam);
 
@@ -138,7 +132,7 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
 void poisson_destroy(Poisson* po);
 int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream);
 const char* poisson_error(const Poisson* po);
-const char* poisson_probe_log(const Poisson* po);
+const char* poisson_path(const Poisson* po);  // which transform kernels the solve runs
 
 // slab-decomposed FFT building blocks (slabfft.hip)
 struct SlabFFT;

@@ -103,7 +103,6 @@ struct Poisson {
   bool dirichlet_fast = false;  // reference BCs by the sine / cosine passes on the physical nodes (fused_poisson_dirichlet)
   double* S = nullptr;          // their work array
   std::string err;
-  std::string probe_log;  // what the placement probe of poisson_create saw (empty: none)
 };
 
 #define PO_HIP(expr)                                                       \
@@ -120,7 +119,8 @@ struct Poisson {
   } while (0)
 
 const char* poisson_error(const Poisson* po) { return po->err.c_str(); }
-const char* poisson_probe_log(const Poisson* po) { return po->probe_log.c_str(); }
+// which transforms run (for pf_status_string)
+const char* poisson_path(const Poisson* po) { return po->fast ? fused2d_describe(po->fast) : "rocFFT (native API) + pointwise kernels"; }
 
 // npx, npy > 0 selects DIRICHLET_X on the even extension of an npx x npy(-node) domain; 0 = PERIODIC
 int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int npy, double h, double k, double eps,
@@ -162,21 +162,6 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
     if (fast && fused2d_create(&po->fast, nx, ny, a.nz, h, stream, fast_dir ? 1 : 0) != 0) {
       po->err = "fused2d_create failed";
       return -3;
-    }
-    if (fast && !fast_dir && dim == 3 && po->n >= (int64_t)256 * 256 * 256) {
-      // the work array of the periodic 3-D solve is walked with plane strides like the spectral step's arrays: choose its
-      // allocation by the same placement probe (spectral2d_fused.hip place_block_by_probe)
-      const SpecLayout lay = fused_spectrum_layout(dim, nx, ny, a.nz);
-      const size_t bytes = sizeof(double2) * (size_t)lay.pitch * lay.rows;
-      unsigned char* kept = nullptr;
-      if (place_block_by_probe(bytes, reinterpret_cast<unsigned char*>(po->ph), stream,
-                               [&](unsigned char* blk) { return fused3d_probe_poisson(po->fast, reinterpret_cast<double2*>(blk)); },
-                               &kept, &po->probe_log) != 0) {
-        po->err = "placement probe failed";
-        return -3;
-      }
-      po->ph = reinterpret_cast<double2*>(kept);
-      PO_HIP(hipMemsetAsync(po->ph, 0, bytes, stream));
     }
     return 0;
   };

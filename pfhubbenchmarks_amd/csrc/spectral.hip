@@ -46,7 +46,6 @@ __global__ __launch_bounds__(256) void dfdc_kernel(const double* __restrict__ c,
 struct KsArgs {
   int nxh, ny, nz;   // half-spectrum extents (x fastest)
   int pitch;         // complex elements per k_x row in memory (nxh, or 264 on the hand-written 512^3 path)
-  int zb = 0, nyp = 0, bp = 1;  // hand-written 3-D path: row (z, y) = ((z >> zb) nyp + y) bp + (z & (2^zb - 1)), SpecLayout
   int nx;            // full x extent
   double kx0, ky0, kz0;  // 2 pi / (n h) per axis
   double dtM, dtMkappa, inv_n;
@@ -91,8 +90,7 @@ __global__ __launch_bounds__(256) void kspace_grad_energy_kernel(const double2* 
     const int mx = (int)(i % a.nxh);
     const double w = (mx == 0 || 2 * mx == a.nx) ? 1.0 : 2.0;
     const int64_t row = i / a.nxh;                         // i runs over the logical half spectrum: row = z ny + y
-    const int z = (int)(row / a.ny), y = (int)(row % a.ny);
-    const double2 ch = chat[((((int64_t)(z >> a.zb) * a.nyp + y) * a.bp) + (z & ((1 << a.zb) - 1))) * a.pitch + mx];
+    const double2 ch = chat[row * a.pitch + mx];
     const double k2 = ksq(a, i), m2 = ch.x * ch.x + ch.y * ch.y;
     acc += w * k2 * m2;
     if (k2 > 0.0) acc2 += w * m2 / k2;
@@ -158,7 +156,6 @@ struct Spectral {
   Fused2D* fast = nullptr;  // 2-D power-of-two grids: hand-written LDS FFT path (2 launches per step)
   KsArgs ks;
   std::string err;
-  std::string probe_log;  // what the placement probe of spectral_create saw (empty: no probe)
 };
 
 #define SP_HIP(expr)                                                       \
@@ -175,7 +172,8 @@ struct Spectral {
   } while (0)
 
 const char* spectral_error(const Spectral* sp) { return sp->err.c_str(); }
-const char* spectral_probe_log(const Spectral* sp) { return sp->probe_log.c_str(); }
+// which transforms run (for pf_status_string)
+const char* spectral_path(const Spectral* sp) { return sp->fast ? fused2d_describe(sp->fast) : "rocFFT (native API) + pointwise k-space kernels"; }
 
 int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, hipStream_t stream, std::string* err) {
   Spectral* sp = new Spectral();
@@ -189,12 +187,9 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
   sp->nh = (int64_t)nxh * ny * sp->nz;
   const char* e3 = getenv("PFHIP_SPECTRAL_2D");
   const bool want_fast = fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e3 && std::string(e3) == "rocfft");
-  SpecLayout lay{nxh, 0, ny, 1, (int64_t)ny * sp->nz};
+  SpecLayout lay{nxh, (int64_t)ny * sp->nz};
   if (want_fast) lay = fused_spectrum_layout(dim, nx, ny, sp->nz);
   sp->ks.pitch = lay.pitch;
-  sp->ks.zb = lay.zb;
-  sp->ks.nyp = lay.nyp;
-  sp->ks.bp = lay.bp;
   const int64_t nh_alloc = (int64_t)lay.pitch * lay.rows;
   sp->ks.nxh = nxh;
   sp->ks.ny = ny;
@@ -214,40 +209,30 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
       SP_FFT(fftplan_real(&sp->fwd, dim, nn, 1, true, stream, &sp->err));
       SP_FFT(fftplan_real(&sp->inv, dim, nn, 1, false, stream, &sp->err));
     }
-    // The three half-spectrum arrays come from ONE allocation (three separate hipMallocs land wherever the allocator puts
-    // them).  PFHIP_SPEC_PLACE="g_kb,h_kb": extra distance of ghat / scratch behind the array before it, in KB;
-    // PFHIP_SPEC_ALIGN_MB / PFHIP_SPEC_BASE_MB: start of the block rounded up to / shifted by that many MiB (A/B only: none
-    // of these moved the step time by more than 0.5 %, profiles/r03/spectral_512c_base_offset_sweep.log).
-    size_t off_g = 0, off_h = 0, align = 0, shift = 0;
-    if (const char* e = getenv("PFHIP_SPEC_PLACE")) {
-      long a = 0, b = 0;
-      if (sscanf(e, "%ld,%ld", &a, &b) == 2 && a >= 0 && b >= 0 && a <= 4096 && b <= 4096) {
-        off_g = (size_t)a * 1024;
-        off_h = (size_t)b * 1024;
-      }
-    }
-    if (const char* e = getenv("PFHIP_SPEC_ALIGN_MB")) align = (size_t)std::atol(e) << 20;
-    if (const char* e = getenv("PFHIP_SPEC_BASE_MB")) shift = (size_t)std::atol(e) << 20;
+    // The half-spectrum arrays come from ONE allocation (separate hipMallocs land wherever the allocator puts them).
+    // Hand-written 3-D passes: the resident spectrum and ONE work array -- every pass of a step is in place on it (a column
+    // or a row pair has exactly one owning workgroup / wave), so what a pass leaves in the Infinity Cache is what the next
+    // one reads, and a dead intermediate is overwritten while still on the die instead of being written back (see
+    // fused2d_step).  Library path and the 2-D kernels: spectrum, ghat and the inverse transform's input.
+    const bool one_work = want_fast && dim == 3 && !getenv("PFHIP_SPEC_TWOARRAYS");  // EXPERIMENT
     const size_t bytes = sizeof(double2) * nh_alloc, slot = (bytes + 255) / 256 * 256;
-    const size_t block_bytes = 3 * slot + off_g + off_h + align + shift;
-    auto carve = [&](unsigned char* block) {
-      unsigned char* base = block;
-      if (align) base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(base) + align - 1) / align * align);
-      base += shift;
-      sp->block = block;
-      sp->chat = reinterpret_cast<double2*>(base);
-      sp->ghat = reinterpret_cast<double2*>(base + slot + off_g);
-      sp->scratch = reinterpret_cast<double2*>(base + 2 * slot + off_g + off_h);
-    };
     {
       unsigned char* blk = nullptr;
-      SP_HIP(hipMalloc(&blk, block_bytes));
-      carve(blk);
+      static const bool contig = getenv("PFHIP_SPEC_CONTIG") != nullptr;  // EXPERIMENT
+      if (!(contig && hipExtMallocWithFlags(reinterpret_cast<void**>(&blk), (one_work ? 2 : 3) * slot, hipDeviceMallocContiguous) == hipSuccess)) {
+        (void)hipGetLastError();
+        if (contig) fprintf(stderr, "[spectral] contiguous allocation refused, plain hipMalloc\n");
+        SP_HIP(hipMalloc(&blk, (one_work ? 2 : 3) * slot));
+      }
+      sp->block = blk;
+      sp->chat = reinterpret_cast<double2*>(blk);
+      sp->ghat = reinterpret_cast<double2*>(blk + slot);
+      sp->scratch = one_work ? sp->ghat : reinterpret_cast<double2*>(blk + 2 * slot);
     }
     if (nh_alloc != sp->nh) {  // padded rows: the pad columns are never written by the passes; keep them defined
       SP_HIP(hipMemsetAsync(sp->chat, 0, sizeof(double2) * nh_alloc, stream));
       SP_HIP(hipMemsetAsync(sp->ghat, 0, sizeof(double2) * nh_alloc, stream));
-      SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
+      if (sp->scratch != sp->ghat) SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
     }
     if (!want_fast) SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
     SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 4096));
@@ -256,33 +241,6 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
         sp->err = "fused2d_create failed";
         return -3;
       }
-    }
-    // PLACEMENT PROBE (large 3-D boxes on the hand-written passes).  The step time is a property of the ALLOCATION the
-    // spectrum lives in: six handles created side by side in one process ran 2.43 / 2.43 / 2.44 and 2.61 / 2.63 / 2.66 ms
-    // per 512^3 step, the same on every repetition (profiles/r03/spectral_512c_allocation_probe.log) -- physical placement
-    // (which HBM channels / banks the column passes' 2 MB strides fall on), not the virtual address: relative offsets,
-    // alignment and base shifts inside one allocation change nothing.  User code cannot ask for a placement, but it can
-    // look: up to PFHIP_SPEC_PROBE candidate blocks (default 12; 0 or 1 = off) are allocated (all held until the choice is made), the four passes of a step are
-    // timed on each (zero-filled arrays, 3 repetitions), the fastest block is kept and the others are freed.  The search
-    // stops early once two candidates differ by more than 3.5 % (both kinds seen).  Costs ~10 ms per candidate at 512^3.
-    if (sp->fast && dim == 3 && sp->n >= (int64_t)256 * 256 * 256) {
-      unsigned char* kept = nullptr;
-      const int prc = place_block_by_probe(
-          block_bytes, sp->block, stream,
-          [&](unsigned char* blk) {
-            carve(blk);
-            return fused3d_probe_step(sp->fast, sp->chat, sp->ghat, sp->scratch);
-          },
-          &kept, &sp->probe_log);
-      if (prc != 0) {
-        sp->err = "placement probe failed";
-        return -3;
-      }
-      carve(kept);
-      SP_HIP(hipMemsetAsync(sp->block, 0, block_bytes, stream));
-      spectral_invalidate(sp);
-      if (getenv("PFHIP_SPECTRAL_VERBOSE") && !sp->probe_log.empty())
-        fprintf(stderr, "[spectral] %s (block %p)\n", sp->probe_log.c_str(), (void*)sp->block);
     }
     return 0;
   };
@@ -330,8 +288,7 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   int rc = ensure_chat(sp, c_in);
   if (rc) return rc;
   if (sp->fast) {
-    static const bool inplace = getenv("PFHIP_SPEC_INPLACE") && getenv("PFHIP_SPEC_INPLACE")[0] == '1';  // EXPERIMENT
-    if (fused2d_step(sp->fast, c_in, store_field ? c_out : nullptr, sp->chat, sp->ghat, (inplace && sp->nz > 1) ? sp->ghat : sp->scratch, dt, M, kappa, ca, cb, two_rho,
+    if (fused2d_step(sp->fast, c_in, store_field ? c_out : nullptr, sp->chat, sp->ghat, sp->scratch, dt, M, kappa, ca, cb, two_rho,
                      dt * M * sp->gq) != 0) {
       sp->err = "fused2d_step launch failed";
       return -3;
@@ -349,17 +306,6 @@ int spectral_step(Spectral* sp, const double* c_in, double* c_out, double dt, do
   SP_FFT(fftplan_exec(sp->inv, sp->scratch, c_out, &sp->err));
   SP_HIP(hipGetLastError());
   return 0;
-}
-
-// 512^2 on the hand-written path with PFHIP_SPECTRAL_PERSIST=1: `nsteps` steps that store no real-space field in one
-// launch (fused2d_persistent_steps).  0 = done; 1 = not available right now (the caller steps the ordinary way); < 0 error.
-int spectral_steps_persistent(Spectral* sp, int nsteps, double dt, double M, double kappa, double ca, double cb,
-                              double two_rho) {
-  if (!sp->fast || !sp->chat_valid) return 1;
-  const int rc = fused2d_persistent_steps(sp->fast, sp->chat, sp->ghat, sp->scratch, nsteps, dt, M, kappa, ca, cb, two_rho,
-                                          dt * M * sp->gq);
-  if (rc < 0) sp->err = "the single-XCD multi-step kernel failed (launch error or a barrier gave up)";
-  return rc;
 }
 
 // sum_k w_k k^2 |c_k|^2  (= N sum over the lattice of |grad c|^2 by Parseval) -> out_dev[0];

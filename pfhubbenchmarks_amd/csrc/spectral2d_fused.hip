@@ -19,7 +19,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include <functional>
 #include <string>
 #include <vector>
 
@@ -46,43 +45,16 @@ struct F2Args {
   double kz0 = 0.0;
   double gam = 0.0;  // BM6: dt M k_c^2 / eps added to the implicit denominator for k != 0
   int yoff = 0;      // slab-decomposed z pass: global k_y index of the first local y-row
-  // single-GPU 3-D boxes: row (z, y) of a half-spectrum array, see spec_row() / SpecLayout
-  int zb = 0;        // log2 of the z-block (0: planes are not blocked)
-  int nyp = 0;       // rows reserved per plane (ny + pad rows; 0 = ny)
-  int bp = 1;        // rows reserved per (y, z-block) group (2^zb + pad rows)
-  int nt = 0;        // 512-point 3-D passes: bit 0 = non-temporal stores of the pass outputs (PFHIP_FFT3D_NT, A/B)
 };
-__device__ __forceinline__ void st2(double2* p, double2 v, int nt) {
-  if (nt) {
-    __builtin_nontemporal_store(v.x, &p->x);
-    __builtin_nontemporal_store(v.y, &p->y);
-  } else {
-    *p = v;
-  }
-}
 
-// Row (z, y) of a half-spectrum array starts at spec_row() complex elements:
-//   row = ((z >> zb) nyp + y) bp + (z & (2^zb - 1)),   element = row pitch + kx.
-// Default: zb = 0, bp = 1, nyp = ny: the plain [z][y][kx] order.  The other forms exist for A/B and are OFF because they
-// measured no better (profiles/r03/spectral_512c_layouts.md).  The question they answer: the same column kernel runs
-// 30-45 % slower per byte along z (stride one plane = 2.06 MB) than along y (stride one row = 4224 B).  Not the TLB and
-// not the stride's length: a z-BLOCKED layout (PFHIP_FFT3D_ZBLOCK=4: [z / 16][y][z % 16][kx], z stride 4224 B inside a
-// block) took the z pass from 1050 to 1008 us but the y passes, now at stride 16 rows, from 446 to 557 us (460 with one
-// pad row per 16-row group) -- no net gain; pad rows per plane (PFHIP_FFT3D_PLANEPAD = 1, 2, 3, 5, 9, 33: plane strides
-// of every residue) changed nothing within +-0.5 % in one process.
-__host__ __device__ __forceinline__ int64_t spec_row(const F2Args& a, int z, int y) {
-  return ((((int64_t)(z >> a.zb) * a.nyp + y) * a.bp) + (z & ((1 << a.zb) - 1))) * a.pitch;
-}
-// the same from the flattened row index z ny + y (2-D: z = 0)
-__host__ __device__ __forceinline__ int64_t spec_row_flat(const F2Args& a, int row) {
-  if (!(a.zb || a.nyp != a.ny)) return (int64_t)row * a.pitch;
-  const int z = a.lgy >= 0 ? row >> a.lgy : row / a.ny;  // ny a power of two except on the mixed-radix path
-  return spec_row(a, z, row - z * a.ny);
-}
+// Row (z, y) of a half-spectrum array [z][y][pitch] starts at (z ny + y) pitch complex elements; `row` = the flattened index
+// z ny + y (2-D: z = 0).  (Round 3 tried z-blocked and plane-padded layouts against the slower z pass -- no net gain,
+// profiles/r03/spectral_512c_variants_{zblock,planepad}.md -- and they are gone.)
+__host__ __device__ __forceinline__ int64_t spec_row_flat(const F2Args& a, int row) { return (int64_t)row * a.pitch; }
 
 // Where element r of the column of batch b lives (complex elements, k_x added by the caller):
 //   (r >> lr) rchunk + (r & (2^lr - 1)) rstride + (b >> lb) bchunk + (b & (2^lb - 1)) bstride        (lr / lb = 31: no split)
-// covers the plain layout, the z-blocked layout of spec_row() for both column directions, and the all-to-all layout
+// covers the plain layout for both column directions and the all-to-all layout
 // [row / split][batch][row % split][kx] that the column passes of the slab-decomposed transforms (csrc/slabfft.hip) read /
 // write on the fly.  A pass gets two maps: `mn` for its natural side and `ms` for the other side when spon != 0
 // (spon = 1: the store side of a MODE 0 pass goes to H through ms; spon = 2: the load side of a MODE 1 pass comes from A
@@ -209,9 +181,9 @@ __device__ __forceinline__ double fp2(double c, const F2Args& a) {
 //   use_fprime:    the forward transform is applied to f'(c) (a step) or to c itself (spectrum initialisation)
 //   G[y][k] <- forward real FFT along x
 constexpr int RT = 256;  // threads per row pair
-__global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double2* __restrict__ H,
+__global__ __launch_bounds__(RT) void f2_row_kernel(const F2Args a, const double2* H,  // (H == G allowed)
                                                     const double* __restrict__ c_in, double* __restrict__ c_out,
-                                                    double2* __restrict__ G, const double2* __restrict__ twx_g,
+                                                    double2* G, const double2* __restrict__ twx_g,
                                                     int from_spectrum, int use_fprime) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double2* X = reinterpret_cast<double2*>(smem_raw);
@@ -346,9 +318,9 @@ constexpr int RW = 1;  // row pairs (waves) per workgroup
 // LAZY: twiddles fetched right before each use (fft512_wave_tw) instead of held in 84 VGPRs -- the 512^3 pass streams
 // from HBM and wants occupancy; the latency-bound 2-D step keeps them resident (loaded beside the data at kernel entry).
 template <bool LAZY>
-__global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, const double2* __restrict__ H,
+__global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, const double2* H,  // (H == G allowed)
                                                             const double* __restrict__ c_in,
-                                                            double* __restrict__ c_out, double2* __restrict__ G,
+                                                            double* __restrict__ c_out, double2* G,
                                                             const double2* __restrict__ twA_g,
                                                             const double2* __restrict__ twB_g, int from_spectrum,
                                                             int use_fprime) {
@@ -422,163 +394,9 @@ __global__ __launch_bounds__(64 * RW) void f2_row512_kernel(const F2Args a, cons
     if (k <= N / 2) {
       const int km = (N - k) & (N - 1);
       const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-      st2(&G[spec_row_flat(a, y0) + k], make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y)), a.nt);
-      st2(&G[spec_row_flat(a, y1) + k], make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x)), a.nt);
+      G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+      G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
     }
-  }
-}
-
-// =====================================================================================================================
-// 512^2: MANY time steps in ONE launch, on ONE XCD (round 3).  The two-launch step above is bound by
-// the dependent-launch floor (~3 us per launch of a 12.8 us step); a chip-wide grid barrier costs more than a launch
-// (7-8 us: the eight L2s are not coherent with each other), but a barrier among the workgroups of ONE XCD does not need an
-// L2 write-back at all -- 0.8 us measured (pfk_xcd_barrier_probe, profiles/r03/xcd_barrier_probe.log).  So: the grid is
-// launched chip-wide, every workgroup registers the XCD it landed on (HW_REG_XCC_ID), the ones on XCD `target` stay (the
-// census tells them how many they are: whatever the dispatcher did, the work is split over exactly those), the others leave
-// at once.  The three 2 MiB arrays live in that XCD's 4 MiB L2 (+ the Infinity Cache); a phase hands its output to the next
-// one through L2: plain stores, vmcnt(0), barrier, and loads that bypass the per-CU L1 (8-byte relaxed agent-scope loads =
-// global_load_dwordx2 sc1).  The resident spectrum column of a wave is only ever touched by that wave: plain accesses.
-// One wave per column / per row pair, 8 waves per workgroup, the same transforms, twiddles and k-space arithmetic as
-// f2_col512_direct_kernel / f2_row512_kernel<false> -- bit-identical fields.  Every spin is bounded; a barrier that gives up
-// raises ctl[128] and every workgroup leaves (the host then reports an error instead of hanging the GPU).
-// ctl: [0] registered workgroups, [32 + x] census of XCD x, [64] / [65] arrival counters of the two barriers of a step,
-// [128] gave up, [160] participants.
-__device__ __forceinline__ double2 ld_l2(const double2* p) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_double2(__longlong_as_double((long long)a), __longlong_as_double((long long)b));
-}
-
-__global__ __launch_bounds__(512) void f2_persist512_kernel(const F2Args a, double2* __restrict__ G, double2* __restrict__ chat,
-                                                           double2* __restrict__ H, const double2* __restrict__ twA_g,
-                                                           const double2* __restrict__ twB_g, int nsteps,
-                                                           unsigned* __restrict__ ctl, int target) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ int s_me, s_n, s_bad;
-  double2* Lall = reinterpret_cast<double2*>(smem_raw);
-  constexpr int N = 512;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double2* L = Lall + wave * W8;
-  int id;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-  const int xcc = id & 7;
-  if (threadIdx.x == 0) {
-    s_bad = 0;
-    s_me = (int)__hip_atomic_fetch_add(ctl + 32 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (xcc == target) {  // the census of this XCD is final once every workgroup of the grid has registered
-      int spins = 0;
-      while (__hip_atomic_load(ctl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) {
-          s_bad = 1;
-          break;
-        }
-      }
-      s_n = (int)__hip_atomic_load(ctl + 32 + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
-  if (xcc != target) return;
-  const int me = s_me, n = s_n, gw = me * 8 + wave, W = 8 * n;
-  if (threadIdx.x == 0 && me == 0) ctl[160] = (unsigned)n;
-  if (s_bad) {
-    if (threadIdx.x == 0) ctl[128] = 1;
-    return;
-  }
-  // one barrier among the participants: arrive on counter c, wait until round * n have arrived
-  auto xcd_barrier = [&](unsigned* c, unsigned round) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned want = round * (unsigned)n;
-      int spins = 0;
-      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (__hip_atomic_load(ctl + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > (1 << 23)) {
-          __hip_atomic_store(ctl + 128, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_bad = 1;
-          break;
-        }
-      }
-    }
-    __syncthreads();
-    return s_bad != 0;
-  };
-  const int T = (lane >> 3) + 8 * (lane & 7);
-  double2 twN[7], twT[7], twB[7];
-  load_tw(twN, twA_g, lane);
-  load_tw(twT, twA_g, T);
-  load_tw(twB, twB_g, lane & 7);
-  for (int step = 1; step <= nsteps; ++step) {
-    // ---- columns: forward y-FFT of G -> k-space update of the resident spectrum -> inverse y-FFT -> H ----
-    for (int kx = gw; kx < a.nxh; kx += W) {
-      double2 v[8], ch[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = ld_l2(&G[(int64_t)(lane + 64 * j) * a.pitch + kx]);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) ch[t] = chat[(int64_t)(T + 64 * t) * a.pitch + kx];
-      fft512_wave<-1>(v, L, lane, twN, twB, lane);
-      const double kxv = a.kx0 * kx;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int ky = T + 64 * t;
-        const int my = 2 * ky > N ? ky - N : ky;
-        const double kyv = a.ky0 * my;
-        const double k2 = (kxv * kxv + kyv * kyv) + 0.0;
-        const double num = a.dtM * k2;
-        const double den = 1.0 / fma(a.dtMkappa, k2 * k2, 1.0 + (k2 > 0.0 ? a.gam : 0.0));
-        double2 r;
-        r.x = fma(-num, v[t].x, ch[t].x) * den;
-        r.y = fma(-num, v[t].y, ch[t].y) * den;
-        chat[(int64_t)ky * a.pitch + kx] = r;
-        v[t] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
-      }
-      wave_lds_sync();
-      fft512_wave<+1>(v, L, T, twT, twB, lane);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) H[(int64_t)(T + 64 * t) * a.pitch + kx] = v[t];
-      wave_lds_sync();
-    }
-    if (xcd_barrier(ctl + 64, (unsigned)step)) return;
-    // ---- rows: inverse x-FFT of H (two rows per transform) -> f'(c) -> forward x-FFT -> G ----
-    for (int pair = gw; pair < a.ny / 2; pair += W) {
-      const int y0 = 2 * pair, y1 = y0 + 1;
-      double2 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = lane + 64 * j;
-        const bool upper = k > N / 2;
-        const int kk = upper ? N - k : k;
-        const double2 p = ld_l2(&H[(int64_t)y0 * a.pitch + kk]), q = ld_l2(&H[(int64_t)y1 * a.pitch + kk]);
-        v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
-      }
-      fft512_wave<+1>(v, L, lane, twN, twB, lane);
-      wave_lds_sync();
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
-      fft512_wave<-1>(v, L, T, twT, twB, lane);
-      wave_lds_sync();
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int k = T + 64 * t;
-        L[k + (k >> 3)] = v[t];
-      }
-      wave_lds_sync();
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int k = lane + 64 * t;
-        if (k <= N / 2) {
-          const int km = (N - k) & (N - 1);
-          const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-          G[(int64_t)y0 * a.pitch + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
-          G[(int64_t)y1 * a.pitch + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
-        }
-      }
-      wave_lds_sync();
-    }
-    if (xcd_barrier(ctl + 65, (unsigned)step)) return;
   }
 }
 
@@ -710,98 +528,13 @@ struct XcdQueue {
   }
 };
 
-// Row pass of the 3-D boxes (nx == 512), experimental forms of f2_row512_kernel<true>: RWT row pairs (waves) per
-// workgroup, MINW waves per SIMD asked of the register allocator, PERSIST: persistent waves fed by the per-XCD queues
-// (each wave pops its own row pairs; no workgroup barrier anywhere: every LDS region is private to its wave).
-template <int RWT, int MINW, bool PERSIST>
-__global__ __launch_bounds__(64 * RWT, MINW) void f3_row512_kernel(const F2Args a, const double2* __restrict__ H,
-                                                                   const double* __restrict__ c_in,
-                                                                   double* __restrict__ c_out, double2* __restrict__ G,
-                                                                   const double2* __restrict__ twA_g,
-                                                                   const double2* __restrict__ twB_g, int from_spectrum,
-                                                                   int use_fprime, int npairs, int* __restrict__ qset,
-                                                                   int* __restrict__ qother) {
-  __shared__ __attribute__((aligned(16))) double2 Lall[RWT * W8];
-  constexpr int N = 512;
-  int pair = blockIdx.x * RWT + (threadIdx.x >> 6);
-  XcdQueue xq;
-  if (PERSIST) {
-    xq.init(qset, qother, npairs);
-    pair = xq.pop_wave();
-  }
-  while (pair < npairs) {
-    asm volatile("" : "+s"(twA_g), "+s"(twB_g));
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    double2* L = Lall + (tid >> 6) * W8;
-    const int y0 = 2 * pair, y1 = y0 + 1;
-    const int T = (lane >> 3) + 8 * (lane & 7);
-    double2 v[8];
-    int m = lane;
-    bool done = false;
-    if (from_spectrum) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = lane + 64 * j;
-        const bool upper = k > N / 2;
-        const int kk = upper ? N - k : k;
-        const double2 p = H[spec_row_flat(a, y0) + kk], q = H[spec_row_flat(a, y1) + kk];
-        v[j] = upper ? make_double2(p.x + q.y, q.x - p.y) : make_double2(p.x - q.y, p.y + q.x);
-      }
-      fft512_wave_tw<+1>(v, L, lane, twA_g, twB_g, lane);
-      if (c_out) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          c_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
-          c_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
-        }
-      }
-      done = from_spectrum == 2;  // inverse only (Poisson solve)
-      m = T;
-      wave_lds_sync();
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = make_double2(c_in[(int64_t)y0 * N + lane + 64 * j], c_in[(int64_t)y1 * N + lane + 64 * j]);
-    }
-    if (!done) {
-      if (use_fprime) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = make_double2(fp2(v[j].x, a), fp2(v[j].y, a));
-      }
-      fft512_wave_tw<-1>(v, L, m, twA_g, twB_g, lane);
-      wave_lds_sync();
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int k = T + 64 * t;
-        L[k + (k >> 3)] = v[t];
-      }
-      wave_lds_sync();
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int k = lane + 64 * t;
-        if (k <= N / 2) {
-          const int km = (N - k) & (N - 1);
-          const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-          G[spec_row_flat(a, y0) + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
-          G[spec_row_flat(a, y1) + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
-        }
-      }
-    }
-    if (!PERSIST) break;
-    wave_lds_sync();
-    pair = xq.pop_wave();
-  }
-}
-
 // Row pass of a time step (inverse x -> c -> f'(c) -> forward x) with the NEXT row pair's half-spectrum rows already in
 // flight: one persistent wave per workgroup walks row pairs pair, pair + W, pair + 2 W, ...; right after a pair's 16 loads
 // have been combined into the transform's input, the loads of the wave's next pair are issued into the same registers and
 // stay in flight during the two transforms (16 KB per wave at all times; 3 waves per SIMD at <= 168 VGPRs).
 template <int MINW>
-__global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, const double2* __restrict__ H,
-                                                              double* __restrict__ c_out, double2* __restrict__ G,
+__global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, const double2* H,  // H == G allowed (in place)
+                                                              double* __restrict__ c_out, double2* G,
                                                               const double2* __restrict__ twA_g,
                                                               const double2* __restrict__ twB_g, int npairs) {
   __shared__ __attribute__((aligned(16))) double2 L[W8];
@@ -874,8 +607,8 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
       if (k <= N / 2) {
         const int km = (N - k) & (N - 1);
         const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
-        st2(&G[g0 + k], make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y)), a.nt);
-        st2(&G[g1 + k], make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x)), a.nt);
+        G[g0 + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+        G[g1 + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
       }
     }
     wave_lds_sync();
@@ -893,9 +626,9 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
 //   X: f2_row512_kernel over all ny*nz rows: inverse x-FFT -> c stored -> f'(c) -> forward x-FFT -> G
 //   Y: forward y-FFT of G in place                                                              (MODE 0)
 // MODE 3 = forward z-FFT stored as the resident spectrum (initialisation).
-template <int MODE, int CW3, bool EARLY = false>  // EARLY (MODE 2): request the resident spectrum before the forward FFT
-__global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, double2* __restrict__ A,
-                                                             double2* __restrict__ chat, double2* __restrict__ H,
+template <int MODE, int CW3>
+__global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, double2* A,  // (A == H allowed)
+                                                             double2* __restrict__ chat, double2* H,
                                                              const ColMap mn, const ColMap ms, int spon, int nblk,
                                                              int nitems, const double2* __restrict__ twA_g,
                                                              const double2* __restrict__ twB_g,
@@ -911,10 +644,8 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
   // One work item (batch b, block of CW3 k_x columns) per workgroup.  (A persistent, software-pipelined form -- next
   // item's loads in flight during the transforms -- was measured and is slower: 3.85 vs 3.25 ms per step; its extra 32
   // VGPRs cost a wave per SIMD, and short-lived workgroups already overlap through the dispatcher.)
-  // CW3 = 4: a 128-byte line holds two items' columns; items i and i + 8 are taken by workgroups on the same XCD back
-  // to back (round-robin dispatch), so give THEM the two halves of one line.
   // qset != null: persistent workgroups fed by the per-XCD queues above (items in natural order: neighbours in time and
-  // L2); null: one item per workgroup, blockIdx -> item with the static pair swizzle (kept for A/B)
+  // L2); null: one item per workgroup, blockIdx -> item
   XcdQueue xq;
   int item = blockIdx.x;
   if (qset) {
@@ -933,12 +664,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
     const int ci = tid % CW3;
     double2* Lc = Lall + ci * W8C + 4 * ci;
     double2 v[8], ch[PER];
-    int lb = item;
-    if (CW3 == 4 && !qset) {
-      const int grp = lb >> 4, r = lb & 15;
-      if ((grp << 4) + 16 <= nitems) lb = (grp << 4) + ((r & 7) << 1) + (r >> 3);  // ragged last group: identity
-    }
-    const int b = lb / nblk, kx = (lb % nblk) * CW3 + ci;
+    const int b = item / nblk, kx = (item % nblk) * CW3 + ci;
     const bool on = kx < a.nxh;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -948,14 +674,6 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) Lc[nat((tid + NT * i) / CW3)] = v[i];
-    if (MODE == 2 && EARLY) {  // the resident spectrum is requested now and consumed after the forward transform (its
-                               // HBM latency hides behind the FFT) -- 128 VGPRs with ~14 dwords of scratch
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int r = (tid + NT * i) / CW3;
-        ch[i] = on ? chat[col_addr(mn, b, r) + kx] : make_double2(0.0, 0.0);
-      }
-    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = L[nat(lane + 64 * j)];
@@ -966,7 +684,8 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 8; ++t) L[nat(T + 64 * t)] = v[t];
-    if (MODE == 2 && !EARLY) {  // fetched only now: 108 VGPRs, no scratch, but the load latency is exposed
+    if (MODE == 2) {  // the resident spectrum, fetched only now: 108 VGPRs (requesting it before the forward transform needs
+                      // scratch at the 128-VGPR budget of two workgroups per CU and measured no better)
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
@@ -1006,7 +725,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
         const int64_t di = col_addr((MODE == 0 && spon == 1) ? ms : mn, b, r) + kx;
-        if (on) st2(&dst[di], Lc[nat(r)], a.nt);
+        if (on) dst[di] = Lc[nat(r)];
       }
     } else {
       // MODE 2: this is the z pass -- b is the (local) y index, the row along the column is k_z
@@ -1025,7 +744,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
         double2 r;
         r.x = fma(-num, gh.x, ch[i].x) * den;
         r.y = fma(-num, gh.y, ch[i].y) * den;
-        if (on) st2(&chat[col_addr(mn, b, kz) + kx], r, a.nt);
+        if (on) chat[col_addr(mn, b, kz) + kx] = r;
         Lc[nat(kz)] = make_double2(r.x * a.inv_n, r.y * a.inv_n);
       }
       __syncthreads();
@@ -1039,7 +758,7 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int r = (tid + NT * i) / CW3;
-        if (on) st2(&H[col_addr(mn, b, r) + kx], Lc[nat(r)], a.nt);
+        if (on) H[col_addr(mn, b, r) + kx] = Lc[nat(r)];
       }
     }
     if (!qset) break;
@@ -1052,8 +771,8 @@ __global__ __launch_bounds__(64 * CW3, 4) void f3_col512_kernel(const F2Args a, 
 // that the kernels stay under 64 VGPRs and fill the CU: the first form, one wave per 1024-capable column, needed 162-178
 // VGPRs), CWG adjacent k_x columns per workgroup moved with the column index fastest.  Same MODEs as f3_col512_kernel.
 template <int MODE, int CWG, int G, int NMAX>  // G threads per column, axis length N <= NMAX
-__global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, double2* __restrict__ A,
-                                                          double2* __restrict__ chat, double2* __restrict__ H,
+__global__ __launch_bounds__(G * CWG, 8) void f3_col_kernel(const F2Args a, double2* A,  // (A == H allowed)
+                                                          double2* __restrict__ chat, double2* H,
                                                           const ColMap mn, const ColMap ms, int spon, int nblk, int nitems,
                                                           int N, int lg, const double2* __restrict__ tw_g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1234,9 +953,9 @@ __device__ __forceinline__ void fft_stockham(double2*& X, double2*& Y, const dou
 }
 
 // Row pass (x): 256 threads per pair of rows; contract of f2_row_kernel.  twx_g: nx entries e^{-2 pi i k / nx}.
-__global__ __launch_bounds__(RT) void mx_row_kernel(const F2Args a, const double2* __restrict__ H,
+__global__ __launch_bounds__(RT) void mx_row_kernel(const F2Args a, const double2* H,  // (H == G allowed)
                                                     const double* __restrict__ c_in, double* __restrict__ c_out,
-                                                    double2* __restrict__ G, const double2* __restrict__ twx_g,
+                                                    double2* G, const double2* __restrict__ twx_g,
                                                     int from_spectrum, int use_fprime, const Radices rx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = a.nx, lane = threadIdx.x;
@@ -1293,8 +1012,8 @@ __global__ __launch_bounds__(RT) void mx_row_kernel(const F2Args a, const double
 // maps of f3_col_kernel.  two_d: the column axis is y of a 2-D grid (the k-space arithmetic then has k_y = row, k_z = 0).
 constexpr int MXC = 4, MXG = 64;
 template <int MODE>
-__global__ __launch_bounds__(MXC * MXG) void mx_col_kernel(const F2Args a, double2* __restrict__ A,
-                                                            double2* __restrict__ chat, double2* __restrict__ H,
+__global__ __launch_bounds__(MXC * MXG) void mx_col_kernel(const F2Args a, double2* A,  // (A == H allowed)
+                                                            double2* __restrict__ chat, double2* H,
                                                             const ColMap mn, const ColMap ms, int spon, int nblk, int N,
                                                             const double2* __restrict__ tw_g, const Radices rd, int two_d,
                                                             int ext) {
@@ -1482,18 +1201,6 @@ __global__ __launch_bounds__(RT) void dst_row_inv_kernel(const F2Args a, const D
   }
 }
 
-int g_generic512 = 0;  // PFHIP_FFT3D_GENERIC512 = 1: 512-point columns by f3_col_kernel too (A/B against the radix-8 wave kernel)
-int g_cwg = 0;  // columns per workgroup of f3_col_kernel on 128- / 256-point axes: 0 = 8; PFHIP_FFT3D_CWG = 4 | 8
-int g_zearly = 0;  // z pass: request the resident spectrum before the forward FFT (PFHIP_FFT3D_ZEARLY = 0 | 1)
-int g_cw3 = 0;  // k_x columns per workgroup of the 3-D column passes: 0 = per pass (z: 4, y: 8), PFHIP_FFT3D_CW = 4 | 8 forces one
-int g_queue = 1;  // per-XCD work queues for the 512-point 3-D column passes: 0 = off, 1 = z passes (default), 2 = all (PFHIP_FFT3D_QUEUE)
-int g_row3 = 8;   // 3-D row pass form (PFHIP_FFT3D_ROWK): 0 = f2_row512_kernel<true>; 1 = <1,5>; 2 = <2,4>; 3 = <4,4>; 4 = persistent <1,4>;
-                  // 5 = persistent <1,5>; 6 = persistent <4,4>; 7 / 8 (default 8) = f3_row512p_kernel<3> / <2>: the step's row pass by
-                  // persistent waves with the next row pair's loads in flight (2.432-2.439 vs 2.440-2.453 ms per step, three A/B rounds)
-int g_cwy = 0;    // columns per workgroup of the y passes when set (PFHIP_FFT3D_CWY = 4 | 8)
-int g_qwgs = 0;   // persistent workgroups per CU in queue mode: 0 = what fits (PFHIP_FFT3D_QWGS)
-int g_cw512 = 1;  // columns per workgroup of the 2-D column kernel (PFHIP_FFT512_CW = 1 | 2 | 4): 13.05 / 14.3 / 17.5 us
-
 int ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;
@@ -1537,13 +1244,12 @@ struct Fused2D {
   size_t lds_row = 0, lds_col = 0;
   hipStream_t stream = nullptr;
   bool g_valid = false;  // G holds the row transform of f'(current c)
-  unsigned* pctl = nullptr;   // 512^2 persistent multi-step kernel: control words (f2_persist512_kernel)
-  unsigned* pctl_host = nullptr;
-  bool persist = false;       // 2-D 512 x 512: steps that store no field run many-per-launch on one XCD (PFHIP_SPECTRAL_PERSIST)
   int* queues = nullptr;  // 2 sets x 8 per-XCD heads (XcdQueue), zero-initialised; launch n uses set n & 1
-  // z-chunked middle of the step (y inverse -> x -> y forward per chunk of planes, see fused2d_step): planes per chunk
-  // (0 = whole box, one launch per pass) and the side streams the chunks are dealt to
+  // z-chunked groups of passes (run_chunked): planes per chunk (0 = whole box, one launch per pass) and the side streams
+  // the chunks are dealt to
   int chunk = 0, nside = 0;
+  int flip = 0;  // EXPERIMENT
+  char desc[256] = {0};  // fused2d_describe (a plain array: run_chunked copies the struct per chunk)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable unsigned qepoch = 0;
@@ -1584,38 +1290,15 @@ bool fused2d_supported(int dim, int nx, int ny, int nz) {
 // A pitch that is a multiple of 8 makes every (row, column-block) exactly one line.
 int fused_spectrum_pitch(int dim, int nx, int ny, int nz) {
   const int nxh = nx / 2 + 1;
-  if (dim == 3 && fused2d_supported(dim, nx, ny, nz)) {
-    const char* e = getenv("PFHIP_FFT3D_PITCH");  // "natural": keep nx/2 + 1 (A/B comparison)
-    if (!(e && std::string(e) == "natural")) return (nxh + 7) / 8 * 8;
-  }
+  if (dim == 3 && fused2d_supported(dim, nx, ny, nz)) return (nxh + 7) / 8 * 8;
   return nxh;
 }
 
-// Layout of every half-spectrum array handed to fused2d_* / fused3d_poisson (spec_row): pitch, z-block, pad rows, and
-// the number of rows to allocate.  2-D and the slab-decomposed passes: plain.  PFHIP_FFT3D_PLANEPAD = pad rows per plane
-// (default 1, 0 for A/B), PFHIP_FFT3D_ZBLOCK = log2 z-block (default 0; 1..6 for A/B, with one pad row per group).
+// Layout of every half-spectrum array handed to fused2d_* / fused3d_poisson: [z][y][pitch], and the rows to allocate.
 SpecLayout fused_spectrum_layout(int dim, int nx, int ny, int nz) {
   SpecLayout L;
   L.pitch = fused_spectrum_pitch(dim, nx, ny, nz);
-  L.zb = 0;
-  L.nyp = ny;
-  L.bp = 1;
-  if (dim == 3 && fused2d_supported(dim, nx, ny, nz)) {
-    int pad = 0;
-    if (const char* e = getenv("PFHIP_FFT3D_PLANEPAD")) {
-      const int v = std::atoi(e);
-      if (v >= 0 && v <= 64) pad = v;
-    }
-    if (const char* e = getenv("PFHIP_FFT3D_ZBLOCK")) {
-      const int v = std::atoi(e);
-      if (v >= 1 && v <= 6 && nz % (1 << v) == 0) L.zb = v;
-    }
-    if (L.zb)
-      L.bp = (1 << L.zb) + (pad ? 1 : 0);
-    else
-      L.nyp = ny + pad;
-  }
-  L.rows = dim == 3 ? (int64_t)(nz >> L.zb) * L.nyp * L.bp : (int64_t)ny;
+  L.rows = dim == 3 ? (int64_t)nz * ny : (int64_t)ny;
   return L;
 }
 
@@ -1631,12 +1314,6 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   a.ny = ny;
   a.nxh = nx / 2 + 1;
   a.pitch = fused_spectrum_pitch(nz > 1 ? 3 : 2, nx, ny, nz);
-  {
-    const SpecLayout L = fused_spectrum_layout(nz > 1 ? 3 : 2, nx, ny, nz);
-    a.zb = L.zb;
-    a.nyp = L.nyp;
-    a.bp = L.bp;
-  }
   a.lgx = ilog2(nx);
   a.lgy = ilog2(ny);
   a.kx0 = TWO_PI_F / (nx * h);
@@ -1657,7 +1334,6 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     f->lgz = ilog2(nz);
     if (table(nz, &f->twz) != hipSuccess) return -3;
   }
-  if (const char* e = getenv("PFHIP_FFT3D_NT")) a.nt = (nz > 1 && std::atoi(e) != 0) ? 1 : 0;
   f->mixed = fused_path(nz > 1 ? 3 : 2, nx, ny, nz) == 2;
   if (f->mixed || nz == 1 || want_mx) {  // (2-D power-of-two grids too: their Poisson solve runs on the mixed-radix column kernel)
     auto full = [&](int N, double2** dev) -> hipError_t {
@@ -1694,17 +1370,8 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
   const bool allow8 = !(e && std::string(e) == "radix2");
   f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
-  if (const char* rg = getenv("PFHIP_FFT3D_ROW"))  // "generic": 512-point rows of a 3-D box by f2_row_kernel (A/B)
-    if (f->cube512 && std::string(rg) == "generic") f->row512 = false;
   f->col512 = (allow8 || f->cube512) && (ny == 512 || nz == 512);  // (3-D: "some column pass needs the radix-8 tables")
   if (f->mixed) f->row512 = f->col512 = false;
-  if (const char* c3 = getenv("PFHIP_FFT3D_CW")) g_cw3 = std::atoi(c3) == 4 ? 4 : (std::atoi(c3) == 8 ? 8 : 0);  // 0: per pass
-  if (const char* ze = getenv("PFHIP_FFT3D_ZEARLY")) g_zearly = std::atoi(ze) != 0;
-  if (const char* gg = getenv("PFHIP_FFT3D_GENERIC512")) g_generic512 = std::atoi(gg) != 0;
-  if (const char* q = getenv("PFHIP_FFT3D_QUEUE")) g_queue = std::atoi(q);
-  if (const char* q = getenv("PFHIP_FFT3D_ROWK")) g_row3 = std::atoi(q);
-  if (const char* q = getenv("PFHIP_FFT3D_CWY")) g_cwy = std::atoi(q) == 4 ? 4 : (std::atoi(q) == 8 ? 8 : 0);
-  if (const char* q = getenv("PFHIP_FFT3D_QWGS")) g_qwgs = std::atoi(q);
   if (f->cube512) {
     if (hipMalloc(&f->queues, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess ||
         hipMemset(f->queues, 0, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess)
@@ -1715,9 +1382,25 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
       f->ncu = prop.multiProcessorCount;
   }
   if (f->cube512) {
-    if (const char* e = getenv("PFHIP_FFT3D_CHUNK")) f->chunk = std::atoi(e);
-    int ns = 0;
-    if (const char* e = getenv("PFHIP_FFT3D_CHUNK_STREAMS")) ns = std::atoi(e);
+    // Passes that only couple points of one z-plane (x rows, y columns) run chunk of planes by chunk of planes, one pass
+    // after the other on the same chunk (run_chunked): a chunk that fits the 256 MiB Infinity Cache is still on the die
+    // when the next pass reads it.  Default: chunks of ~64 MiB of half spectrum dealt to two streams (the tail of one
+    // chunk's launch overlaps the head of the next chunk's); a box whose whole array is below 96 MiB is not chunked.
+    // PFHIP_FFT3D_CHUNK="planes[,streams]" overrides (0 = whole box per launch): measured at 512^3 in one process,
+    // profiles/r04/spectral_512c_chunk_ab.log.
+    const double plane_mb = (double)ny * a.pitch * sizeof(double2) / (1024.0 * 1024.0);
+    int ns = 2;
+    if (plane_mb * nz > 96.0) {
+      f->chunk = (int)(64.0 / plane_mb + 0.5);
+      if (f->chunk < 2) f->chunk = 2;
+    }
+    if (const char* e = getenv("PFHIP_FFT3D_CHUNK")) {
+      int c = 0, n2 = ns;
+      const int got = sscanf(e, "%d,%d", &c, &n2);
+      if (got >= 1 && c >= 0) f->chunk = c;
+      if (got >= 2 && n2 >= 0) ns = n2;
+    }
+    if (f->chunk >= nz) f->chunk = 0;
     if (f->chunk > 0 && ns > 1) {
       f->nside = ns > 4 ? 4 : ns;
       if (hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
@@ -1726,15 +1409,6 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
             hipEventCreateWithFlags(&f->ev_join[k], hipEventDisableTiming) != hipSuccess)
           return -3;
     }
-  }
-  if (const char* cg = getenv("PFHIP_FFT3D_CWG")) {
-    const int c = std::atoi(cg);
-    g_cwg = (c == 4 || c == 8) ? c : 0;
-  }
-
-  if (const char* cw = getenv("PFHIP_FFT512_CW")) {
-    const int c = std::atoi(cw);
-    if (c == 1 || c == 2 || c == 4) g_cw512 = c;
   }
   if (f->row512 || f->col512) {
     std::vector<double2> ta(512), tb(64);
@@ -1754,20 +1428,19 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
         hipMemcpy(f->tw8b, tb.data(), sizeof(double2) * 64, hipMemcpyHostToDevice) != hipSuccess)
       return -3;
   }
-  if (nz == 1 && nx == 512 && ny == 512 && f->row512 && f->col512 && !f->mixed) {
-    const char* pe = getenv("PFHIP_SPECTRAL_PERSIST");
-    f->persist = pe && pe[0] == '1';
-    if (f->persist) {
-      if (hipMalloc(&f->pctl, sizeof(unsigned) * 256) != hipSuccess ||
-          hipHostMalloc(&f->pctl_host, sizeof(unsigned) * 256, hipHostMallocDefault) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(f2_persist512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double2) * 8 * W8)) != hipSuccess)
-        return -3;
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        f->ncu = prop.multiProcessorCount;
+  {
+    auto kind = [&](int n, bool is512) -> std::string {
+      if (f->mixed) return "mixed-radix Stockham (" + std::to_string(n) + ")";
+      return is512 ? "one-wave radix-8 (512)" : "radix-2^2 LDS (" + std::to_string(n) + ")";
+    };
+    std::string d = "hand-written LDS-FFT passes: x " + kind(nx, f->row512) + ", y " + kind(ny, ny == 512 && f->col512);
+    if (nz > 1) {
+      d += ", z " + kind(nz, nz == 512 && f->col512);
+      d += f->chunk > 0 ? "; plane-local passes in chunks of " + std::to_string(f->chunk) + " planes on " +
+                              std::to_string(f->nside > 0 ? f->nside : 1) + " stream(s)"
+                        : "; whole box per launch";
     }
+    snprintf(f->desc, sizeof f->desc, "%s", d.c_str());
   }
   f->lds_row = sizeof(double2) * (nx + nx / 32 + nx / 2);
   f->lds_col = sizeof(double2) * ((size_t)CW * (ny + ny / 32 + 1) + ny / 2);
@@ -1779,12 +1452,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     auto big = [](const void* k) {
       return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     };
-    if (!big(reinterpret_cast<const void*>(f3_col_kernel<0, 8, 128, 512>)) ||
-        !big(reinterpret_cast<const void*>(f3_col_kernel<1, 8, 128, 512>)) ||
-        !big(reinterpret_cast<const void*>(f3_col_kernel<2, 8, 128, 512>)) ||
-        !big(reinterpret_cast<const void*>(f3_col_kernel<3, 8, 128, 512>)) ||
-        !big(reinterpret_cast<const void*>(f3_col_kernel<4, 8, 128, 512>)) ||
-        !big(reinterpret_cast<const void*>(f3_col_kernel<0, 4, 256, 1024>)) ||
+    if (!big(reinterpret_cast<const void*>(f3_col_kernel<0, 4, 256, 1024>)) ||
         !big(reinterpret_cast<const void*>(f3_col_kernel<1, 4, 256, 1024>)) ||
         !big(reinterpret_cast<const void*>(f3_col_kernel<2, 4, 256, 1024>)) ||
         !big(reinterpret_cast<const void*>(f3_col_kernel<3, 4, 256, 1024>)) ||
@@ -1811,12 +1479,11 @@ void fused2d_destroy(Fused2D* f) {
     if (f->ev_join[k]) (void)hipEventDestroy(f->ev_join[k]);
   }
   if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
-  if (f->pctl) (void)hipFree(f->pctl);
-  if (f->pctl_host) (void)hipHostFree(f->pctl_host);
   delete f;
 }
 
 void fused2d_invalidate(Fused2D* f) { f->g_valid = false; }
+const char* fused2d_describe(const Fused2D* f) { return f->desc; }
 
 namespace {
 void launch_row(const Fused2D* f, const F2Args& a, const double2* H, const double* c_in, double* c_out, double2* G,
@@ -1849,13 +1516,7 @@ void launch_col(const Fused2D* f, const F2Args& a, const double2* G, double2* ch
       launch_mx_col2d<2>(f, a, const_cast<double2*>(G), chat, H);
     return;
   }
-  if (f->col512 && g_cw512 == 4)
-    hipLaunchKernelGGL(f2_col512_direct_kernel<4>, dim3((a.nxh + 3) / 4), dim3(256), 0, f->stream, a, G, chat, H,
-                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512 && g_cw512 == 2)
-    hipLaunchKernelGGL(f2_col512_direct_kernel<2>, dim3((a.nxh + 1) / 2), dim3(128), 0, f->stream, a, G, chat, H,
-                       (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
-  else if (f->col512)
+  if (f->col512)  // one column per workgroup: 13.05 us per 512^2 step (2 columns: 14.3, 4: 17.5 -- parallelism beats line sharing)
     hipLaunchKernelGGL(f2_col512_direct_kernel<1>, dim3(a.nxh), dim3(64), 0, f->stream, a, G, chat, H,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, init_only);
   else
@@ -1873,42 +1534,16 @@ void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const doub
                        (const double2*)f->twfx, from_spectrum, use_fprime, f->rx);
     return;
   }
-  if (f->row512 && (g_row3 == 7 || g_row3 == 8) && from_spectrum == 1 && use_fprime) {
+  if (f->row512 && from_spectrum == 1 && use_fprime) {
+    // the step's row pass: persistent one-wave workgroups, 8 per CU (2 waves per SIMD: twiddles held in registers), the next
+    // row pair's loads in flight during the two transforms.  H == G is allowed (in place: a row pair has one owner).
     const int npairs = a.ny * a.nz / 2;
-    const int wpc = g_qwgs > 0 ? g_qwgs : (g_row3 == 7 ? 12 : 8);   // persistent one-wave workgroups per CU
-    const int grid = f->ncu * wpc < npairs ? f->ncu * wpc : npairs;
-    if (g_row3 == 7)
-      hipLaunchKernelGGL(f3_row512p_kernel<3>, dim3(grid), dim3(64), 0, f->stream, a, H, c_out, G, (const double2*)f->tw8a,
-                         (const double2*)f->tw8b, npairs);
-    else
-      hipLaunchKernelGGL(f3_row512p_kernel<2>, dim3(grid), dim3(64), 0, f->stream, a, H, c_out, G, (const double2*)f->tw8a,
-                         (const double2*)f->tw8b, npairs);
+    const int grid = f->ncu * 8 < npairs ? f->ncu * 8 : npairs;
+    hipLaunchKernelGGL(f3_row512p_kernel<2>, dim3(grid), dim3(64), 0, f->stream, a, H, c_out, G, (const double2*)f->tw8a,
+                       (const double2*)f->tw8b, npairs);
     return;
   }
-  if (f->row512 && g_row3 > 0 && g_row3 < 7 && f->queues) {
-    const int npairs = a.ny * a.nz / 2;
-    int* qset = nullptr;
-    int* qother = nullptr;
-    if (g_row3 >= 4) {  // only a launch that really pops (and zeroes the other set) may take an epoch
-      const unsigned e = f->qepoch++;
-      qset = f->queues + (e & 1) * 8 * QSTRIDE;
-      qother = f->queues + ((e + 1) & 1) * 8 * QSTRIDE;
-    }
-    const double2 *ta = f->tw8a, *tb = f->tw8b;
-#define PF_ROW3(RWT, MINW, PERS, GRID)                                                                                \
-  hipLaunchKernelGGL((f3_row512_kernel<RWT, MINW, PERS>), dim3(GRID), dim3(64 * RWT), 0, f->stream, a, H, c_in, c_out, G, ta, \
-                     tb, from_spectrum, use_fprime, npairs, qset, qother)
-    const int wpc = g_qwgs > 0 ? g_qwgs : 16;  // persistent waves per CU
-    switch (g_row3) {
-      case 1: PF_ROW3(1, 5, false, npairs); break;
-      case 2: PF_ROW3(2, 4, false, npairs / 2); break;
-      case 3: PF_ROW3(4, 4, false, npairs / 4); break;
-      case 4: PF_ROW3(1, 4, true, f->ncu * wpc); break;
-      case 5: PF_ROW3(1, 5, true, f->ncu * (g_qwgs > 0 ? g_qwgs : 17)); break;
-      default: PF_ROW3(4, 4, true, f->ncu * wpc / 4); break;
-    }
-#undef PF_ROW3
-  } else if (f->row512)
+  if (f->row512)
     hipLaunchKernelGGL(f2_row512_kernel<true>, dim3(a.ny * a.nz / 2 / RW), dim3(64 * RW), 0, f->stream, a, H, c_in, c_out, G,
                        (const double2*)f->tw8a, (const double2*)f->tw8b, from_spectrum, use_fprime);
   else
@@ -1928,25 +1563,21 @@ struct ColGeom {
 ColGeom axis_geom(const Fused2D* f, const F2Args& a, int axis) {
   const int64_t row = a.pitch;
   ColGeom g;
-  // axis 1: columns along y, one batch per z-plane; axis 2: columns along z, one batch per y-row -- addresses = spec_row()
+  // axis 1: columns along y, one batch per z-plane; axis 2: columns along z, one batch per y-row 
   g.N = axis == 1 ? a.ny : a.nz;
   g.lg = axis == 1 ? a.lgy : f->lgz;
   g.tw = axis == 1 ? f->twy : f->twz;
   g.nbatch = axis == 1 ? a.nz : a.ny;
   g.twf = axis == 1 ? f->twfy : f->twfz;
   g.rd = axis == 1 ? f->ry : f->rz;
-  const int64_t grp = row * a.bp, plane_grp = grp * a.nyp;  // one (y, z-block) group of rows; one z-block of planes
+  const int64_t plane = row * a.ny;
   ColMap m;
   if (axis == 1) {  // r = y, b = z
-    m.rstride = grp;
-    m.lb = a.zb ? a.zb : 31;
-    m.bchunk = a.zb ? plane_grp : 0;
-    m.bstride = a.zb ? row : plane_grp;
+    m.rstride = row;
+    m.bstride = plane;
   } else {  // r = z, b = y
-    m.lr = a.zb ? a.zb : 31;
-    m.rchunk = a.zb ? plane_grp : 0;
-    m.rstride = a.zb ? row : plane_grp;
-    m.bstride = grp;
+    m.rstride = plane;
+    m.bstride = row;
   }
   g.mn = m;
   return g;
@@ -1962,8 +1593,10 @@ template <int MODE, int CW3>
 void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
   const int nblk = (a.nxh + CW3 - 1) / CW3;
   const int nitems = nblk * g.nbatch;
-  const bool zpass = MODE == 2 || MODE == 3 || MODE == 4;
-  const bool queued = f->queues && (g_queue >= 2 || (g_queue == 1 && zpass));
+  // z-type passes (two transforms and / or the resident spectrum per item): persistent workgroups, two per CU (what the CU
+  // holds at 4 waves per SIMD and 74 KB of LDS), fed by the per-XCD queues -- 0.19 ms per 512^3 step faster than the static
+  // map (profiles/r03/spectral_512c_alignment_and_queue.log); the y passes: one item per workgroup (queues measured slower)
+  const bool queued = f->queues && (MODE == 2 || MODE == 3 || MODE == 4);
   int* qset = nullptr;
   int* qother = nullptr;
   int grid = nitems;
@@ -1971,16 +1604,10 @@ void launch_col3_t(const Fused2D* f, const F2Args& a, double2* A, double2* chat,
     const unsigned e = f->qepoch++;
     qset = f->queues + (e & 1) * 8 * QSTRIDE;
     qother = f->queues + ((e + 1) & 1) * 8 * QSTRIDE;
-    // persistent workgroups: what the CU holds at 4 waves per SIMD (<= 128 VGPRs) and ~39 KB of LDS per 4 columns
-    const int per_cu = g_qwgs > 0 ? g_qwgs : 16 / CW3;
-    grid = f->ncu * per_cu < nitems ? f->ncu * per_cu : nitems;
+    grid = f->ncu * 2 < nitems ? f->ncu * 2 : nitems;
   }
-  if (MODE == 2 && g_zearly)
-    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, true>), dim3(grid), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                       g.mn, g.ms, g.spon, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, qset, qother);
-  else
-    hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3, false>), dim3(grid), dim3(64 * CW3), 0, f->stream, a, A, chat, H,
-                       g.mn, g.ms, g.spon, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, qset, qother);
+  hipLaunchKernelGGL((f3_col512_kernel<MODE, CW3>), dim3(grid), dim3(64 * CW3), 0, f->stream, a, A, chat, H, g.mn, g.ms,
+                     g.spon, nblk, nitems, (const double2*)f->tw8a, (const double2*)f->tw8b, qset, qother);
 }
 template <int MODE>
 void launch_col3_geom(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, const ColGeom& g) {
@@ -1992,38 +1619,55 @@ void launch_col3_geom(const Fused2D* f, const F2Args& a, double2* A, double2* ch
                        g.spon, nblk, N, g.twf, g.rd, 0, 0);
     return;
   }
-  if (N != 512 || g_generic512) {
-    if (N == 512) {
-      if (g_cwg == 4)
-        launch_col3_g<MODE, 4, 128, 512>(f, a, A, chat, H, g);
-      else
-        launch_col3_g<MODE, 8, 128, 512>(f, a, A, chat, H, g);
-      return;
-    }
-    // columns per workgroup, measured at 256^3: 8 -> 0.363 ms per step, 4 -> 0.379 (rocFFT path 0.578)
-    const int cwg = g_cwg ? g_cwg : 8;
-    if (N > 512)  // 4 columns of 1024 points: 76 KB of LDS, 1024 threads
+  if (N != 512) {
+    // radix-2^2 LDS transforms: 8 columns per workgroup (256^3: 0.363 ms per step; 4 columns: 0.379), 4 columns of 1024
+    // points (76 KB of LDS, 1024 threads)
+    if (N > 512)
       launch_col3_g<MODE, 4, 256, 1024>(f, a, A, chat, H, g);
-    else if (cwg == 8)
-      launch_col3_g<MODE, 8, 64, 256>(f, a, A, chat, H, g);
     else
-      launch_col3_g<MODE, 4, 64, 256>(f, a, A, chat, H, g);
+      launch_col3_g<MODE, 8, 64, 256>(f, a, A, chat, H, g);
     return;
   }
-  // columns per workgroup: 8 = one full 128-byte line per row on every pass.  (Round 2 ran the z pass with 4 -- four
-  // independent workgroups per CU instead of two, 999 vs 1073 us then -- at the price of half-line requests that the L2s
-  // fetched 1.57x; with the round-3 changes 8 is the faster form on every box measured: 964-1028 vs 1008-1081 us under
-  // rocprofv3, 2.68 vs 2.74 ms per step in one process, profiles/r03.  PFHIP_FFT3D_CW = 4 | 8 forces one width.)
-  int cw = g_cw3 ? g_cw3 : 8;
-  if (g_cwy && (MODE == 0 || MODE == 1)) cw = g_cwy;
-  if (cw == 4)
-    launch_col3_t<MODE, 4>(f, a, A, chat, H, g);
-  else
-    launch_col3_t<MODE, 8>(f, a, A, chat, H, g);
+  // 512 points: one wave per column, 8 columns per workgroup = one full 128-byte line per row on every pass (4-column
+  // workgroups fetched half lines 1.57x in round 2 and were slower on every box of round 3)
+  launch_col3_t<MODE, 8>(f, a, A, chat, H, g);
 }
 template <int MODE>
 void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, double2* H, int axis) {
   launch_col3_geom<MODE>(f, a, A, chat, H, axis_geom(f, a, axis));
+}
+
+// A group of passes that only couple points of one z-plane (x rows, y columns), chunk of planes by chunk of planes:
+// body(fc, ac, z0) launches the whole group on planes [z0, z0 + ac.nz) with the launch descriptor fc (its stream: chunks
+// are dealt round-robin to the side streams, which fork from and join f->stream, so the group is one node in the handle's
+// stream order).  A chunk that fits the 256 MiB Infinity Cache is still on the die when the group's next pass reads it,
+// and an intermediate that the next pass overwrites in place never reaches HBM: at 512^3 the three middle passes of a
+// spectral step cost 6 array moves of 1.08 GB whole-box and about 2 chunked (mempattern_probe: 1275 -> 980 us for pure
+// copies with these access patterns; the step: 2.30-2.54 -> 2.05 ms, profiles/r04/spectral_512c_chunk_ab.log).
+template <class Body>
+int run_chunked(const Fused2D* f, const F2Args& a, Body body) {
+  if (!(f->chunk > 0 && f->chunk < a.nz)) {
+    body(*f, a, 0);
+    return 0;
+  }
+  if (f->nside > 0) {
+    if (hipEventRecord(f->ev_fork, f->stream) != hipSuccess) return -3;
+    for (int k = 0; k < f->nside; ++k)
+      if (hipStreamWaitEvent(f->side[k], f->ev_fork, 0) != hipSuccess) return -3;
+  }
+  int k = 0;
+  for (int z0 = 0; z0 < a.nz; z0 += f->chunk, ++k) {
+    F2Args ac = a;
+    ac.nz = a.nz - z0 < f->chunk ? a.nz - z0 : f->chunk;
+    Fused2D fc = *f;  // launch descriptor only: the launchers read geometry, tables and the stream from it
+    if (f->nside > 0) fc.stream = f->side[k % f->nside];
+    body(fc, ac, z0);
+    f->qepoch = fc.qepoch;
+  }
+  for (int j = 0; j < f->nside; ++j)
+    if (hipEventRecord(f->ev_join[j], f->side[j]) != hipSuccess || hipStreamWaitEvent(f->stream, f->ev_join[j], 0) != hipSuccess)
+      return -3;
+  return 0;
 }
 }  // namespace
 
@@ -2101,18 +1745,6 @@ int fused_poisson_dirichlet(Fused2D* f, const double* c, double* phi, double* S,
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// the three column passes of fused3d_poisson on W (values irrelevant), for the placement probe of poisson_create
-int fused3d_probe_poisson(Fused2D* f, double2* W) {
-  if (!f->cube512 || ensure_sym(f) != 0) return -3;
-  F2Args a = f->a;
-  a.dtM = 1.0;
-  a.dtMkappa = -1.0;
-  launch_col3<0>(f, a, W, nullptr, nullptr, 1);
-  launch_col3<4>(f, a, W, reinterpret_cast<double2*>(f->sym), nullptr, 2);
-  launch_col3<1>(f, a, W, nullptr, nullptr, 1);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
 int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double k_over_eps, double inv_h2) {
   if (ensure_sym(f) != 0) return -3;
   F2Args a = f->a;
@@ -2124,11 +1756,18 @@ int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double
     launch_row(f, a, W, nullptr, phi, nullptr, 2, 0);
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
-  launch_row3(f, a, nullptr, c, nullptr, W, 0, 0);
-  launch_col3<0>(f, a, W, nullptr, nullptr, 1);
+  const int64_t plane = (int64_t)a.ny * a.pitch, rplane = (int64_t)a.ny * a.nx;
+  if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+        launch_row3(&fc, ac, nullptr, c + z0 * rplane, nullptr, W + z0 * plane, 0, 0);
+        launch_col3<0>(&fc, ac, W + z0 * plane, nullptr, nullptr, 1);
+      }) != 0)
+    return -3;
   launch_col3<4>(f, a, W, reinterpret_cast<double2*>(f->sym), nullptr, 2);
-  launch_col3<1>(f, a, W, nullptr, nullptr, 1);
-  launch_row3(f, a, W, nullptr, phi, nullptr, 2, 0);
+  if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+        launch_col3<1>(&fc, ac, W + z0 * plane, nullptr, nullptr, 1);
+        launch_row3(&fc, ac, W + z0 * plane, nullptr, phi + z0 * rplane, nullptr, 2, 0);
+      }) != 0)
+    return -3;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -2136,8 +1775,12 @@ int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   const F2Args& a = f->a;
   if (f->cube512) {
-    launch_row3(f, a, nullptr, c, nullptr, G, 0, 0);
-    launch_col3<0>(f, a, G, nullptr, nullptr, 1);
+    const int64_t plane = (int64_t)a.ny * a.pitch, rplane = (int64_t)a.ny * a.nx;
+    if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+          launch_row3(&fc, ac, nullptr, c + z0 * rplane, nullptr, G + z0 * plane, 0, 0);
+          launch_col3<0>(&fc, ac, G + z0 * plane, nullptr, nullptr, 1);
+        }) != 0)
+      return -3;
     launch_col3<3>(f, a, G, chat, nullptr, 2);
     f->g_valid = false;
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -2147,115 +1790,6 @@ int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   f->g_valid = false;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
-
-// PLACEMENT PROBE.  The time of the strided column passes is a property of the ALLOCATION they run on (see spectral.hip):
-// allocate up to PFHIP_SPEC_PROBE candidate blocks of `bytes` (default 12; 0 or 1 = off; 2 when a block exceeds 12 GB),
-// zero-fill each, time `run(block)` (3 repetitions after a warm-up) and keep the fastest; every candidate stays allocated until
-// the choice is made (freeing a loser first would hand the same block back), then the others are freed.  Stops early once two
-// candidates differ by more than 3.5 % (both kinds seen).  `first` = an already allocated block (candidate 0).  On return
-// *kept is the chosen block (its contents are whatever the probe left) and *log says what was measured.
-int place_block_by_probe(size_t bytes, unsigned char* first, hipStream_t stream, const std::function<int(unsigned char*)>& run,
-                         unsigned char** kept, std::string* log) {
-  int nprobe = 12;
-  if (const char* e = getenv("PFHIP_SPEC_PROBE")) nprobe = std::atoi(e);
-  *kept = first;
-  if (nprobe <= 1) return 0;
-  if (bytes > ((size_t)12 << 30)) nprobe = 2;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -3;
-  std::vector<unsigned char*> cand;
-  cand.push_back(first);
-  unsigned char* best = nullptr;
-  float best_ms = 0.f, worst_ms = 0.f;
-  std::string lg;
-  int rc = 0;
-  for (int k = 0; k < nprobe && rc == 0; ++k) {
-    if (k > 0) {
-      unsigned char* blk = nullptr;
-      if (hipMalloc(&blk, bytes) != hipSuccess) {
-        (void)hipGetLastError();  // no memory for another candidate: choose among what we have
-        break;
-      }
-      cand.push_back(blk);
-    }
-    unsigned char* blk = cand.back();
-    if (hipMemsetAsync(blk, 0, bytes, stream) != hipSuccess) rc = -3;
-    for (int rep = 0; rep < 4 && rc == 0; ++rep) {  // the first repetition is a warm-up
-      if (rep == 1 && hipEventRecord(e0, stream) != hipSuccess) rc = -3;
-      if (rc == 0 && run(blk) != 0) rc = -3;
-    }
-    float ms = 0.f;
-    if (rc == 0 && (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                    hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
-      rc = -3;
-    if (rc) break;
-    ms /= 3.f;
-    char buf[32];
-    snprintf(buf, sizeof buf, "%s%.4f", k ? ", " : "", ms);
-    lg += buf;
-    if (!best || ms < best_ms) {
-      best = blk;
-      best_ms = ms;
-    }
-    if (ms > worst_ms) worst_ms = ms;
-    if (k > 0 && best_ms < 0.965f * worst_ms) break;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  if (!best) best = first;
-  for (unsigned char* b : cand)
-    if (b != best) (void)hipFree(b);
-  *kept = best;
-  if (log) {
-    char buf[48];
-    snprintf(buf, sizeof buf, " ms -> kept %.4f", best_ms);
-    *log = "placement probe: candidates " + lg + buf;
-  }
-  return rc;
-}
-
-// The four passes of one 3-D step on the given arrays, no real-space field involved (values irrelevant: the arrays may
-// be all zero): what spectral_create times to choose among candidate allocations.
-int fused3d_probe_step(Fused2D* f, double2* chat, double2* G, double2* H) {
-  if (!f->cube512) return -3;
-  F2Args a = f->a;
-  a.ca = 0.3;
-  a.cb = 0.7;
-  a.two_rho = 10.0;
-  a.dtM = 0.05;
-  a.dtMkappa = 0.1;
-  launch_col3<2>(f, a, G, chat, H, 2);
-  launch_col3<1>(f, a, H, nullptr, nullptr, 1);
-  launch_row3(f, a, H, nullptr, nullptr, G, 1, 1);
-  launch_col3<0>(f, a, G, nullptr, nullptr, 1);
-  return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-// 512^2 only: `nsteps` steps that store no real-space field, in one launch (f2_persist512_kernel).  G must hold the row
-// transform of f'(current c) (fused2d_step leaves it so).  Returns 1 when this box / handle cannot do it (the caller steps
-// the ordinary way), -3 on a launch error or a barrier that gave up (state then undefined: the caller reports the error).
-int fused2d_persistent_steps(Fused2D* f, double2* chat, double2* G, double2* H, int nsteps, double dt, double M, double kappa,
-                             double ca, double cb, double two_rho, double gam) {
-  if (!f->persist || !f->g_valid || nsteps < 1) return 1;
-  F2Args a = f->a;
-  a.ca = ca;
-  a.cb = cb;
-  a.two_rho = two_rho;
-  a.dtM = dt * M;
-  a.dtMkappa = dt * M * kappa;
-  a.gam = gam;
-  if (hipMemsetAsync(f->pctl, 0, sizeof(unsigned) * 256, f->stream) != hipSuccess) return -3;
-  hipLaunchKernelGGL(f2_persist512_kernel, dim3(f->ncu), dim3(512), sizeof(double2) * 8 * W8, f->stream, a, G, chat, H,
-                     (const double2*)f->tw8a, (const double2*)f->tw8b, nsteps, f->pctl, 0);
-  if (hipGetLastError() != hipSuccess) return -3;
-  // the give-up flag must be looked at before anything is built on the result
-  if (hipMemcpyAsync(f->pctl_host, f->pctl, sizeof(unsigned) * 256, hipMemcpyDeviceToHost, f->stream) != hipSuccess ||
-      hipStreamSynchronize(f->stream) != hipSuccess)
-    return -3;
-  if (f->pctl_host[128] != 0 || f->pctl_host[160] == 0) return -3;
-  return 0;
-}
-int fused2d_persistent_participants(const Fused2D* f) { return f->pctl_host ? (int)f->pctl_host[160] : 0; }
 
 // one semi-implicit step c_in -> c_out; chat (resident, valid for c_in) is advanced; G, H are work arrays
 int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, double2* G, double2* H, double dt,
@@ -2268,42 +1802,42 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
   a.dtMkappa = dt * M * kappa;
   a.gam = gam;
   if (f->cube512) {
+    // ONE work array W (= G; H is not used on this path): every pass is in place on it -- a column belongs to one workgroup, a
+    // row pair to one wave -- so what a pass leaves in the Infinity Cache is what the next one reads, and an intermediate
+    // that is overwritten while still on the die is never written back.
+    double2* W = G;
+    const int64_t plane = (int64_t)a.ny * a.pitch, rplane = (int64_t)a.ny * a.nx;
     if (!f->g_valid) {  // x- and y-transform of f'(c_in) (first step, or after the field was replaced)
-      launch_row3(f, a, nullptr, c_in, nullptr, G, 0, 1);
-      launch_col3<0>(f, a, G, nullptr, nullptr, 1);
+      if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+            launch_row3(&fc, ac, nullptr, c_in + z0 * rplane, nullptr, W + z0 * plane, 0, 1);
+            launch_col3<0>(&fc, ac, W + z0 * plane, nullptr, nullptr, 1);
+          }) != 0)
+        return -3;
     }
-    launch_col3<2>(f, a, G, chat, H, 2);        // z: forward, k-space update of chat, inverse -> H
-    if (f->chunk > 0 && f->chunk < a.nz && a.zb == 0 && a.nyp == a.ny) {
-      // y inverse -> x -> y forward, chunk of planes by chunk of planes: the three passes only couple points of one
-      // z-plane, and a chunk (planes x 2.06 MB per array) that fits the 256 MiB Infinity Cache is still on the die when the
-      // next pass reads it
-      const int64_t plane = (int64_t)a.ny * a.pitch;
-      if (f->nside > 0) {
-        if (hipEventRecord(f->ev_fork, f->stream) != hipSuccess) return -3;
-        for (int k = 0; k < f->nside; ++k)
-          if (hipStreamWaitEvent(f->side[k], f->ev_fork, 0) != hipSuccess) return -3;
-      }
-      int k = 0;
-      for (int z0 = 0; z0 < a.nz; z0 += f->chunk, ++k) {
-        F2Args ac = a;
-        ac.nz = a.nz - z0 < f->chunk ? a.nz - z0 : f->chunk;
-        Fused2D fs = *f;  // (launch descriptor only: the launchers read geometry, tables and the stream from it)
-        if (f->nside > 0) fs.stream = f->side[k % f->nside];
-        double2 *Hc = H + z0 * plane, *Gc = G + z0 * plane;
-        launch_col3<1>(&fs, ac, Hc, nullptr, nullptr, 1);
-        launch_row3(&fs, ac, Hc, nullptr, c_out ? c_out + (int64_t)z0 * a.ny * a.nx : nullptr, Gc, 1, 1);
-        launch_col3<0>(&fs, ac, Gc, nullptr, nullptr, 1);
-      }
-      for (int j = 0; j < f->nside; ++j)
-        if (hipEventRecord(f->ev_join[j], f->side[j]) != hipSuccess ||
-            hipStreamWaitEvent(f->stream, f->ev_join[j], 0) != hipSuccess)
-          return -3;
-      f->g_valid = true;
-      return hipGetLastError() == hipSuccess ? 0 : -3;
+    // EXPERIMENT (PFHIP_SPEC_TWOARRAYS = 1: z and x out of place (round 3); 2: z out of place, x in place, roles swap every
+    // step; 3: z in place, x out of place, roles swap)
+    static const int mode2 = getenv("PFHIP_SPEC_TWOARRAYS") ? std::atoi(getenv("PFHIP_SPEC_TWOARRAYS")) : 0;
+    double2* W2 = W;
+    double2* Wx = W;   // where the x pass writes / the y forward pass works
+    if (H && H != G && mode2 == 1) { W2 = H; Wx = W; }
+    if (H && H != G && mode2 >= 2) {
+      double2* cur = f->flip ? H : G;     // holds the y-forward output of the previous step
+      double2* oth = f->flip ? G : H;
+      if (!f->g_valid) { f->flip = 0; cur = G; oth = H; }
+      W = cur;
+      if (mode2 == 2) { W2 = oth; Wx = oth; }   // z: cur -> oth; y inv oth; x oth in place; y fwd oth
+      else { W2 = cur; Wx = oth; }              // z in place on cur; y inv cur; x: cur -> oth; y fwd oth
+      f->flip ^= 1;
     }
-    launch_col3<1>(f, a, H, nullptr, nullptr, 1);  // y: inverse, in place
-    launch_row3(f, a, H, nullptr, c_out, G, 1, 1);  // x: inverse -> c_out, f'(c_out), forward -> G
-    launch_col3<0>(f, a, G, nullptr, nullptr, 1);  // y: forward, in place (ready for the next step's z pass)
+    launch_col3<2>(f, a, W, chat, W2, 2);  // z: forward, k-space update of chat, inverse (whole box: a column spans all planes)
+    // y inverse -> x (inverse -> c_out, f'(c_out), forward) -> y forward, ready for the next step's z pass
+    if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+          double2 *Wc = Wx + z0 * plane, *W2c = W2 + z0 * plane;
+          launch_col3<1>(&fc, ac, W2c, nullptr, nullptr, 1);
+          launch_row3(&fc, ac, W2c, nullptr, c_out ? c_out + z0 * rplane : nullptr, Wc, 1, 1);
+          launch_col3<0>(&fc, ac, Wc, nullptr, nullptr, 1);
+        }) != 0)
+      return -3;
     f->g_valid = true;
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
@@ -2323,7 +1857,7 @@ bool fusedslab_supported(int nx, int ny, int nz, int P) {
 }
 namespace {
 ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
-  ColGeom g = axis_geom(f, a, 1);  // a.nz == nzl: one batch per local plane (plain layout: a.zb == 0)
+  ColGeom g = axis_geom(f, a, 1);  // a.nz == nzl: one batch per local plane
   const int nyl = a.ny / P;
   g.spon = on;
   g.ms.lr = ilog2(nyl);            // element r of a column goes to chunk r / nyl of the all-to-all layout
@@ -2337,9 +1871,6 @@ ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
 int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double2* A, int nzl, int P, int use_fprime,
                          double ca, double cb, double two_rho) {
   F2Args a = f->a;
-  a.zb = 0;  // slab-decomposed passes: plain layouts
-  a.nyp = a.ny;
-  a.bp = 1;
   a.nz = nzl;
   a.ca = ca;
   a.cb = cb;
@@ -2351,9 +1882,6 @@ int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double
 // A [q][zl][yq][kx] -> inverse y columns -> tmp [zl][y][kx] -> inverse x rows -> real planes
 int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out, int nzl, int P) {
   F2Args a = f->a;
-  a.zb = 0;  // slab-decomposed passes: plain layouts
-  a.nyp = a.ny;
-  a.bp = 1;
   a.nz = nzl;
   launch_col3_geom<1>(f, a, A, nullptr, tmp, slab_y_geom(f, a, nzl, P, 2));
   launch_row3(f, a, tmp, nullptr, real_out, nullptr, 2, 0);
@@ -2363,9 +1891,6 @@ int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out,
 // (unnormalised); 2: forward -> k-space update of the resident chat -> inverse of chat / N; 3: forward, stored to chat.
 int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa) {
   F2Args a = f->a;
-  a.zb = 0;  // slab-decomposed passes: plain layouts
-  a.nyp = a.ny;
-  a.bp = 1;
   a.yoff = yoff;
   a.dtM = dtM;
   a.dtMkappa = dtMkappa;

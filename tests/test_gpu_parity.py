@@ -407,39 +407,6 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
         assert np.abs(s.get_c() - sp.c).max() <= 1e-11
 
 
-@pytest.mark.parametrize("model", ["bm1", "bm6"])
-def test_spectral_512sq_many_steps_in_one_launch_on_one_xcd(lib, monkeypatch, model):
-    """PFHIP_SPECTRAL_PERSIST=1 (BASELINE.json config 2, 512^2): all but the last two steps of a pf_step call run in ONE
-    launch whose workgroups all sit on one XCD (f2_persist512_kernel: single-XCD barriers, hand-offs through that XCD's L2
-    with L1-bypassing loads).  Same transforms, twiddles and k-space arithmetic as the two-launch step: the fields must be
-    BIT-identical, for several call lengths (incl. calls too short to use it), after set_c (first step of a call goes the
-    ordinary way), after rollback, and against the numpy oracle."""
-    from oracle import ch_fd, ch_spectral
-    c0 = ch_fd.ic(512, 512, 1)[0]
-    out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("PFHIP_SPECTRAL_PERSIST", mode)
-        with PhaseFieldSolver(dim=2, n=512, h=1.0, scheme="spectral", model=model) as s:
-            s.set_c(c0)
-            got = []
-            for k in (1, 2, 3, 7, 40):
-                s.step(1e-2, k)
-                got.append(s.get_c())
-            s.step(1e-2, 9)
-            s.rollback()                       # back to the state before the LAST step of the call (step 8 of 9)
-            got.append(s.get_c())
-            s.step(1e-2, 5)
-            got.append(s.get_c())
-            got.append(np.array(s.diagnostics()))
-            out[mode] = got
-    for a, b in zip(out["0"], out["1"]):
-        np.testing.assert_array_equal(a, b)
-    if model == "bm1":
-        sp = ch_spectral.SpectralCH(c0, h=1.0)
-        sp.step(1e-2, 53)
-        assert np.abs(out["1"][4] - sp.c).max() <= 1e-10 * np.abs(sp.c).max()
-
-
 @pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10), (128, 128, 128), (256, 128, 512),
                                    (200, 400), (20, 24, 50)])
 def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
@@ -468,6 +435,39 @@ def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
         assert abs(F - Fo) <= 1e-10 * abs(Fo) and abs(Ctot - Co) <= 1e-12 * abs(Co) and abs(E - Eo) <= 1e-9 * abs(Eo)
     with pytest.raises(Exception):          # reference boundary conditions need the FD scheme's Dirichlet Poisson solve
         PhaseFieldSolver(dim=2, n=65, h=1.0, bc="mirror", scheme="spectral", model="bm6")
+
+
+@pytest.mark.parametrize("shape,model", [((128, 128, 256), "bm1"), ((40, 96, 200), "bm1"), ((128, 256, 128), "bm6"),
+                                         ((64, 128, 128), "bm6fd")])
+def test_spectral_plane_local_passes_in_chunks_are_bit_identical(lib, monkeypatch, shape, model):
+    """The passes of a 3-D spectral step / Poisson solve that only couple points of one z-plane (x rows, y columns) run chunk
+    of planes by chunk of planes, the chunks dealt to side streams (run_chunked in csrc/spectral2d_fused.hip; default on
+    boxes above 96 MiB of half spectrum, e.g. 512^3: 32 planes, 2 streams).  Same kernels, same arithmetic: the fields of
+    PFHIP_FFT3D_CHUNK="0" (whole box per launch) and of several chunkings -- uneven last chunk, 1 to 4 streams -- must be
+    BIT-identical, on the power-of-two and the mixed-radix kernels, for the spectral schemes (BM1, BM6) and for the FD
+    scheme's periodic Poisson solve; pf_status_string names the chunking."""
+    monkeypatch.setenv("PFHIP_SPECTRAL_3D", "lds")
+    n = shape[::-1]
+    rng = np.random.default_rng(7)
+    c0 = 0.5 + 0.05 * rng.standard_normal(shape)
+    scheme = "fd" if model == "bm6fd" else "spectral"
+    dt = 5e-4 if model == "bm6fd" else 1e-2
+    out = {}
+    for chunk in ("0", "16,2", "24,3", "8,1", "5,4"):
+        monkeypatch.setenv("PFHIP_FFT3D_CHUNK", chunk)
+        with PhaseFieldSolver(dim=3, n=n, h=1.0, scheme=scheme, model=model[:3]) as s:
+            s.set_c(c0)
+            s.step(dt, 1)
+            a = s.get_c()
+            s.step(dt, 4)
+            out[chunk] = (a, s.get_c(), np.array(s.diagnostics()), s.get_phi() if model == "bm6fd" else None)
+            want = "whole box per launch" if chunk == "0" else "chunks of %s planes on %s stream" % tuple(chunk.split(","))
+            assert want in s.status, s.status
+    for chunk, got in out.items():
+        for x, y in zip(out["0"], got):
+            if x is not None:
+                np.testing.assert_array_equal(x, y, err_msg="PFHIP_FFT3D_CHUNK=%s" % chunk)
+
 
 
 def test_spectral_512cubed_one_step_against_the_cpu_oracle(lib):
@@ -1263,7 +1263,7 @@ def test_fem_be_pivot_policies_agree_at_production_block_sizes(lib, golden_dir, 
 def test_fem_be_own_dense_kernels_match_the_library_path(lib, monkeypatch, model, n):
     """The dense reduction levels on the repository's kernels (lu_npvt_coop_kernel: cooperative un-pivoted LU,
     lu_solve_mfma_kernel: both substitutions on fp64 MFMA tiles, gemv_sub_kernel) against the same solve on rocSOLVER /
-    rocBLAS (PFHIP_FEM_GETRF=rocsolver PFHIP_FEM_TRSM=rocblas PFHIP_FEM_GEMV=rocblas), at block sizes that exercise ragged
+    rocBLAS (PFHIP_FEM_GETRF=rocsolver PFHIP_FEM_TRSM=rocblas: substitutions and matrix-vector products), at block sizes that exercise ragged
     last tiles and every instantiation in use: 6 x 69 = 414, 6 x 76 = 456, 606, 6 x 121 = 726 (BM2), 2 x 202 = 404, 522, 702
     (BM3) unknowns per block -- 26..46 tiles of 16, i.e. 4, 5 and 6 tiles per wave.  Same Newton iteration counts, fields
     within 1e-10, one attempt per step (no factorisation reported singular, no partner lost).  The reference side of the
@@ -1275,12 +1275,11 @@ def test_fem_be_own_dense_kernels_match_the_library_path(lib, monkeypatch, model
     dts = (0.01, 0.02, 0.04) if model == "bm2" else (0.1, 0.2, 0.4)
     out = {}
     for mode in ("own", "library"):
-        for k in ("PFHIP_FEM_GETRF", "PFHIP_FEM_TRSM", "PFHIP_FEM_GEMV"):
+        for k in ("PFHIP_FEM_GETRF", "PFHIP_FEM_TRSM"):
             monkeypatch.delenv(k, raising=False)
         if mode == "library":
             monkeypatch.setenv("PFHIP_FEM_GETRF", "rocsolver")
             monkeypatch.setenv("PFHIP_FEM_TRSM", "rocblas")
-            monkeypatch.setenv("PFHIP_FEM_GEMV", "rocblas")
         with PhaseFieldSolver(**kw) as s:
             (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
             its = []

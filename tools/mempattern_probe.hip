@@ -223,5 +223,46 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // ---- placement: is the rate of a pattern a property of the ALLOCATION? ----------------------------------------------------
+  // `nbuf` buffers of one half-spectrum array each, all held; the y- and z-pattern in-place copies and the contiguous copy
+  // on each (round 3 saw the spectral step alternate between 2.43 and 2.62 ms from handle to handle)
+  {
+    const int nbuf = argc > 2 ? atoi(argv[2]) : 8;
+    std::vector<d2*> bufs;
+    for (int i = 0; i < nbuf; ++i) {
+      d2* X = nullptr;
+      if (hipMalloc(&X, elems * sizeof(d2)) != hipSuccess) break;
+      CK(hipMemset(X, 0, elems * sizeof(d2)));
+      bufs.push_back(X);
+    }
+    printf("placement: %zu buffers of %.2f GB; GB/s of the in-place y-pattern / z-pattern / z-pattern 256 B / contiguous copy\n",
+           bufs.size(), elems * 16.0 / 1e9);
+    for (size_t i = 0; i < bufs.size(); ++i) {
+      d2* X = bufs[i];
+      Pat py{pitch, plane, 8, 33, 33 * n, 512, 8};
+      py.lw = 3;
+      Pat pz{plane, pitch, 8, 33, 33 * n, 512, 8};
+      pz.lw = 3;
+      Pat pz2{plane, pitch, 16, 16, 16 * n * 2, 256, 16, n, (int64_t)256 * plane};
+      pz2.lw = 4;
+      Pat ps{4096, 4096, 4096, 1, (int)(elems / 4096), 1, 4096};
+      ps.lw = 12;
+      double r[4];
+      int k = 0;
+      for (Pat* pp : {&py, &pz, &pz2, &ps}) {
+        const Pat p = *pp;
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((lsb_kernel<512, 8, false>), dim3(p.nitems), dim3(512), 65536, 0, X, X, p);
+        CK(hipEventRecord(e0, 0));
+        for (int q = 0; q < 20; ++q) hipLaunchKernelGGL((lsb_kernel<512, 8, false>), dim3(p.nitems), dim3(512), 65536, 0, X, X, p);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        r[k++] = 2.0 * (double)p.nitems * p.rows * p.wseg * 16.0 / (ms / 20 * 1e-3) / GB;
+      }
+      printf("  buffer %zu at %p: y %6.0f  z %6.0f  z256 %6.0f  span %6.0f\n", i, (void*)X, r[0], r[1], r[2], r[3]);
+      fflush(stdout);
+    }
+  }
   return 0;
 }

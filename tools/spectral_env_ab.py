@@ -1,7 +1,7 @@
 """In-process A/B of environment-selected forms of the 512^3 spectral step (or BM6 FD + Poisson): one handle per form,
 created, timed and destroyed in turn, the whole list run ROUNDS times (the allocator hands consecutive handles of one
 process the same block, so the forms see the same placement; PFHIP_SPEC_PROBE=0 unless a form sets it).
-Usage: python tools/spectral_env_ab.py "NAME:K=V,K=V" "NAME2:..." [--rounds 2] [--model bm1|bm6] [--check]"""
+Usage: python tools/spectral_env_ab.py "NAME:K=V;K=V" "NAME2:..." [--rounds 2] [--model bm1|bm6] [--check]"""
 import argparse
 import os
 import sys
@@ -23,7 +23,7 @@ a = ap.parse_args()
 forms = []
 for f in a.forms:
     name, _, kv = f.partition(":")
-    forms.append((name, dict(x.split("=", 1) for x in kv.split(",") if x)))
+    forms.append((name, dict(x.split("=", 1) for x in kv.split(";") if x)))
 allkeys = {k for _, e in forms for k in e}
 ref = None
 for rnd in range(a.rounds):
