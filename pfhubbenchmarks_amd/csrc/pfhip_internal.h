@@ -95,8 +95,8 @@ void fftplan_destroy(FftPlan* p);
 // fused LDS-FFT spectral step for 2-D power-of-two grids (spectral2d_fused.hip); same spectrum layout as rocFFT D2Z
 struct Fused2D;
 bool fused2d_supported(int dim, int nx, int ny, int nz);
-struct SpecLayout {  // a half-spectrum array of the hand-written passes: [z][y][pitch] complex elements
-  int pitch;
+struct SpecLayout {  // a half-spectrum array of the hand-written passes: [z][nyp][pitch] complex elements (nyp = ny + pad rows)
+  int pitch, nyp;
   int64_t rows;      // rows to allocate (pitch complex elements each)
 };
 SpecLayout fused_spectrum_layout(int dim, int nx, int ny, int nz);

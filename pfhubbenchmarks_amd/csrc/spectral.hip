@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void dfdc_kernel(const double* __restrict__ c,
 struct KsArgs {
   int nxh, ny, nz;   // half-spectrum extents (x fastest)
   int pitch;         // complex elements per k_x row in memory (nxh, or 264 on the hand-written 512^3 path)
+  int nyp = 0;       // rows reserved per z-plane (ny + pad rows on the hand-written 3-D path; 0 = ny)
   int nx;            // full x extent
   double kx0, ky0, kz0;  // 2 pi / (n h) per axis
   double dtM, dtMkappa, inv_n;
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(256) void kspace_grad_energy_kernel(const double2* 
     const int mx = (int)(i % a.nxh);
     const double w = (mx == 0 || 2 * mx == a.nx) ? 1.0 : 2.0;
     const int64_t row = i / a.nxh;                         // i runs over the logical half spectrum: row = z ny + y
-    const double2 ch = chat[row * a.pitch + mx];
+    const int64_t z = a.nyp ? row / a.ny : 0;              // (pad rows per plane: SpecLayout)
+    const double2 ch = chat[(row + z * (a.nyp ? a.nyp - a.ny : 0)) * a.pitch + mx];
     const double k2 = ksq(a, i), m2 = ch.x * ch.x + ch.y * ch.y;
     acc += w * k2 * m2;
     if (k2 > 0.0) acc2 += w * m2 / k2;
@@ -187,9 +189,10 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
   sp->nh = (int64_t)nxh * ny * sp->nz;
   const char* e3 = getenv("PFHIP_SPECTRAL_2D");
   const bool want_fast = fused2d_supported(dim, nx, ny, sp->nz) && !(dim == 2 && e3 && std::string(e3) == "rocfft");
-  SpecLayout lay{nxh, (int64_t)ny * sp->nz};
+  SpecLayout lay{nxh, ny, (int64_t)ny * sp->nz};
   if (want_fast) lay = fused_spectrum_layout(dim, nx, ny, sp->nz);
   sp->ks.pitch = lay.pitch;
+  sp->ks.nyp = lay.nyp;
   const int64_t nh_alloc = (int64_t)lay.pitch * lay.rows;
   sp->ks.nxh = nxh;
   sp->ks.ny = ny;
@@ -209,30 +212,21 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
       SP_FFT(fftplan_real(&sp->fwd, dim, nn, 1, true, stream, &sp->err));
       SP_FFT(fftplan_real(&sp->inv, dim, nn, 1, false, stream, &sp->err));
     }
-    // The half-spectrum arrays come from ONE allocation (separate hipMallocs land wherever the allocator puts them).
-    // Hand-written 3-D passes: the resident spectrum and ONE work array -- every pass of a step is in place on it (a column
-    // or a row pair has exactly one owning workgroup / wave), so what a pass leaves in the Infinity Cache is what the next
-    // one reads, and a dead intermediate is overwritten while still on the die instead of being written back (see
-    // fused2d_step).  Library path and the 2-D kernels: spectrum, ghat and the inverse transform's input.
-    const bool one_work = want_fast && dim == 3 && !getenv("PFHIP_SPEC_TWOARRAYS");  // EXPERIMENT
+    // The three half-spectrum arrays (resident spectrum, ghat, the inverse transforms' input) come from ONE allocation
+    // (separate hipMallocs land wherever the allocator puts them).
     const size_t bytes = sizeof(double2) * nh_alloc, slot = (bytes + 255) / 256 * 256;
     {
       unsigned char* blk = nullptr;
-      static const bool contig = getenv("PFHIP_SPEC_CONTIG") != nullptr;  // EXPERIMENT
-      if (!(contig && hipExtMallocWithFlags(reinterpret_cast<void**>(&blk), (one_work ? 2 : 3) * slot, hipDeviceMallocContiguous) == hipSuccess)) {
-        (void)hipGetLastError();
-        if (contig) fprintf(stderr, "[spectral] contiguous allocation refused, plain hipMalloc\n");
-        SP_HIP(hipMalloc(&blk, (one_work ? 2 : 3) * slot));
-      }
+      SP_HIP(hipMalloc(&blk, 3 * slot));
       sp->block = blk;
       sp->chat = reinterpret_cast<double2*>(blk);
       sp->ghat = reinterpret_cast<double2*>(blk + slot);
-      sp->scratch = one_work ? sp->ghat : reinterpret_cast<double2*>(blk + 2 * slot);
+      sp->scratch = reinterpret_cast<double2*>(blk + 2 * slot);
     }
     if (nh_alloc != sp->nh) {  // padded rows: the pad columns are never written by the passes; keep them defined
       SP_HIP(hipMemsetAsync(sp->chat, 0, sizeof(double2) * nh_alloc, stream));
       SP_HIP(hipMemsetAsync(sp->ghat, 0, sizeof(double2) * nh_alloc, stream));
-      if (sp->scratch != sp->ghat) SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
+      SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
     }
     if (!want_fast) SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
     SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 4096));

@@ -45,12 +45,18 @@ struct F2Args {
   double kz0 = 0.0;
   double gam = 0.0;  // BM6: dt M k_c^2 / eps added to the implicit denominator for k != 0
   int yoff = 0;      // slab-decomposed z pass: global k_y index of the first local y-row
+  int nyp = 0;       // rows RESERVED per z-plane of a half-spectrum array (0 = ny): single-GPU 3-D boxes keep one pad row per
+                     // plane, see fused_spectrum_layout()
 };
 
-// Row (z, y) of a half-spectrum array [z][y][pitch] starts at (z ny + y) pitch complex elements; `row` = the flattened index
-// z ny + y (2-D: z = 0).  (Round 3 tried z-blocked and plane-padded layouts against the slower z pass -- no net gain,
-// profiles/r03/spectral_512c_variants_{zblock,planepad}.md -- and they are gone.)
-__host__ __device__ __forceinline__ int64_t spec_row_flat(const F2Args& a, int row) { return (int64_t)row * a.pitch; }
+// Row (z, y) of a half-spectrum array starts at (z nyp + y) pitch complex elements (nyp = ny + pad rows); `row` = the
+// flattened index z ny + y (2-D: z = 0).
+__host__ __device__ __forceinline__ int64_t spec_row_flat(const F2Args& a, int row) {
+  if (a.nyp == 0 || a.nyp == a.ny) return (int64_t)row * a.pitch;
+  const int z = a.lgy >= 0 ? row >> a.lgy : row / a.ny;  // ny a power of two except on the mixed-radix path
+  return ((int64_t)row + (int64_t)z * (a.nyp - a.ny)) * a.pitch;
+}
+__host__ __device__ __forceinline__ int64_t spec_plane(const F2Args& a) { return (int64_t)(a.nyp ? a.nyp : a.ny) * a.pitch; }
 
 // Where element r of the column of batch b lives (complex elements, k_x added by the caller):
 //   (r >> lr) rchunk + (r & (2^lr - 1)) rstride + (b >> lb) bchunk + (b & (2^lb - 1)) bstride        (lr / lb = 31: no split)
@@ -1248,7 +1254,6 @@ struct Fused2D {
   // z-chunked groups of passes (run_chunked): planes per chunk (0 = whole box, one launch per pass) and the side streams
   // the chunks are dealt to
   int chunk = 0, nside = 0;
-  int flip = 0;  // EXPERIMENT
   char desc[256] = {0};  // fused2d_describe (a plain array: run_chunked copies the struct per chunk)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1294,11 +1299,25 @@ int fused_spectrum_pitch(int dim, int nx, int ny, int nz) {
   return nxh;
 }
 
-// Layout of every half-spectrum array handed to fused2d_* / fused3d_poisson: [z][y][pitch], and the rows to allocate.
+// Layout of every half-spectrum array handed to fused2d_* / fused3d_poisson: [z][nyp][pitch], and the rows to allocate.
+// 3-D boxes reserve ONE PAD ROW PER PLANE.  The z passes walk columns whose rows are one plane apart; with ny and the
+// pitch both multiples of 8 the plane stride is a multiple of 1 KB (512 x 264 x 16 B = 0x210000), and strides that are
+// multiples of 1 KB spread a column's 128-byte lines badly over the HBM channels: a pure two-stream copy with the z pass's
+// access pattern runs at 4.45 TB/s on physically contiguous memory and 4.65 on a fragmented allocation -- the "placement
+// lottery" of round 3 -- against 5.0 on either once the plane stride is 256 B, 768 B or one 4224-byte row longer
+// (tools/pairstream_probe.hip, profiles/r04/pairstream_probe.log).  The row stride of the y passes (4224 B) has that form.
+// The whole step, six fresh processes on a box whose allocations were all of the slow kind without the pad row
+// (profiles/r04/spectral_512c_planepad_ab.log): 2.52 -> 2.31 ms whole-box, 2.32 -> 2.10 chunked in 4-5 processes of 6 (the
+// others stay slow: a second, physical-region effect of about 1.5 % on pure copies and up to 9 % on these latency-bound
+// passes remains, profiles/r04/mempattern_probe_64_buffers.log); on a box of the fast kind the pad costs 0.7 %.
 SpecLayout fused_spectrum_layout(int dim, int nx, int ny, int nz) {
   SpecLayout L;
   L.pitch = fused_spectrum_pitch(dim, nx, ny, nz);
-  L.rows = dim == 3 ? (int64_t)nz * ny : (int64_t)ny;
+  L.nyp = ny;
+  if (dim == 3 && fused2d_supported(dim, nx, ny, nz)) {
+    L.nyp = ny + 1;
+  }
+  L.rows = dim == 3 ? (int64_t)nz * L.nyp : (int64_t)ny;
   return L;
 }
 
@@ -1314,6 +1333,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   a.ny = ny;
   a.nxh = nx / 2 + 1;
   a.pitch = fused_spectrum_pitch(nz > 1 ? 3 : 2, nx, ny, nz);
+  a.nyp = fused_spectrum_layout(nz > 1 ? 3 : 2, nx, ny, nz).nyp;
   a.lgx = ilog2(nx);
   a.lgy = ilog2(ny);
   a.kx0 = TWO_PI_F / (nx * h);
@@ -1570,7 +1590,7 @@ ColGeom axis_geom(const Fused2D* f, const F2Args& a, int axis) {
   g.nbatch = axis == 1 ? a.nz : a.ny;
   g.twf = axis == 1 ? f->twfy : f->twfz;
   g.rd = axis == 1 ? f->ry : f->rz;
-  const int64_t plane = row * a.ny;
+  const int64_t plane = spec_plane(a);
   ColMap m;
   if (axis == 1) {  // r = y, b = z
     m.rstride = row;
@@ -1756,7 +1776,7 @@ int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double
     launch_row(f, a, W, nullptr, phi, nullptr, 2, 0);
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
-  const int64_t plane = (int64_t)a.ny * a.pitch, rplane = (int64_t)a.ny * a.nx;
+  const int64_t plane = spec_plane(a), rplane = (int64_t)a.ny * a.nx;
   if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
         launch_row3(&fc, ac, nullptr, c + z0 * rplane, nullptr, W + z0 * plane, 0, 0);
         launch_col3<0>(&fc, ac, W + z0 * plane, nullptr, nullptr, 1);
@@ -1775,7 +1795,7 @@ int fused3d_poisson(Fused2D* f, const double* c, double* phi, double2* W, double
 int fused2d_spectrum(Fused2D* f, const double* c, double2* chat, double2* G) {
   const F2Args& a = f->a;
   if (f->cube512) {
-    const int64_t plane = (int64_t)a.ny * a.pitch, rplane = (int64_t)a.ny * a.nx;
+    const int64_t plane = spec_plane(a), rplane = (int64_t)a.ny * a.nx;
     if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
           launch_row3(&fc, ac, nullptr, c + z0 * rplane, nullptr, G + z0 * plane, 0, 0);
           launch_col3<0>(&fc, ac, G + z0 * plane, nullptr, nullptr, 1);
@@ -1802,40 +1822,26 @@ int fused2d_step(Fused2D* f, const double* c_in, double* c_out, double2* chat, d
   a.dtMkappa = dt * M * kappa;
   a.gam = gam;
   if (f->cube512) {
-    // ONE work array W (= G; H is not used on this path): every pass is in place on it -- a column belongs to one workgroup, a
-    // row pair to one wave -- so what a pass leaves in the Infinity Cache is what the next one reads, and an intermediate
-    // that is overwritten while still on the die is never written back.
-    double2* W = G;
-    const int64_t plane = (int64_t)a.ny * a.pitch, rplane = (int64_t)a.ny * a.nx;
+    // Two work arrays: G (y-transformed f'(c), consumed by the z pass) and H (z pass output -> y inverse in place -> read by
+    // the x pass, which writes G again).  Measured against ONE array with every pass in place (one process, same
+    // allocations, profiles/r04/spectral_512c_work_arrays_ab.log): the in-place x pass costs 0.03-0.06 ms per step, the
+    // in-place z pass nothing -- the saved write-back of the dead intermediate does not pay for it.
+    const int64_t plane = spec_plane(a), rplane = (int64_t)a.ny * a.nx;
     if (!f->g_valid) {  // x- and y-transform of f'(c_in) (first step, or after the field was replaced)
       if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
-            launch_row3(&fc, ac, nullptr, c_in + z0 * rplane, nullptr, W + z0 * plane, 0, 1);
-            launch_col3<0>(&fc, ac, W + z0 * plane, nullptr, nullptr, 1);
+            launch_row3(&fc, ac, nullptr, c_in + z0 * rplane, nullptr, G + z0 * plane, 0, 1);
+            launch_col3<0>(&fc, ac, G + z0 * plane, nullptr, nullptr, 1);
           }) != 0)
         return -3;
     }
-    // EXPERIMENT (PFHIP_SPEC_TWOARRAYS = 1: z and x out of place (round 3); 2: z out of place, x in place, roles swap every
-    // step; 3: z in place, x out of place, roles swap)
-    static const int mode2 = getenv("PFHIP_SPEC_TWOARRAYS") ? std::atoi(getenv("PFHIP_SPEC_TWOARRAYS")) : 0;
-    double2* W2 = W;
-    double2* Wx = W;   // where the x pass writes / the y forward pass works
-    if (H && H != G && mode2 == 1) { W2 = H; Wx = W; }
-    if (H && H != G && mode2 >= 2) {
-      double2* cur = f->flip ? H : G;     // holds the y-forward output of the previous step
-      double2* oth = f->flip ? G : H;
-      if (!f->g_valid) { f->flip = 0; cur = G; oth = H; }
-      W = cur;
-      if (mode2 == 2) { W2 = oth; Wx = oth; }   // z: cur -> oth; y inv oth; x oth in place; y fwd oth
-      else { W2 = cur; Wx = oth; }              // z in place on cur; y inv cur; x: cur -> oth; y fwd oth
-      f->flip ^= 1;
-    }
-    launch_col3<2>(f, a, W, chat, W2, 2);  // z: forward, k-space update of chat, inverse (whole box: a column spans all planes)
-    // y inverse -> x (inverse -> c_out, f'(c_out), forward) -> y forward, ready for the next step's z pass
+    launch_col3<2>(f, a, G, chat, H, 2);  // z: forward, k-space update of chat, inverse -> H (whole box: a column spans all planes)
+    // y inverse (in place on H) -> x (inverse -> c_out, f'(c_out), forward -> G) -> y forward (in place on G, ready for the
+    // next step's z pass), chunk of planes by chunk of planes
     if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
-          double2 *Wc = Wx + z0 * plane, *W2c = W2 + z0 * plane;
-          launch_col3<1>(&fc, ac, W2c, nullptr, nullptr, 1);
-          launch_row3(&fc, ac, W2c, nullptr, c_out ? c_out + z0 * rplane : nullptr, Wc, 1, 1);
-          launch_col3<0>(&fc, ac, Wc, nullptr, nullptr, 1);
+          double2 *Gc = G + z0 * plane, *Hc = H + z0 * plane;
+          launch_col3<1>(&fc, ac, Hc, nullptr, nullptr, 1);
+          launch_row3(&fc, ac, Hc, nullptr, c_out ? c_out + z0 * rplane : nullptr, Gc, 1, 1);
+          launch_col3<0>(&fc, ac, Gc, nullptr, nullptr, 1);
         }) != 0)
       return -3;
     f->g_valid = true;
@@ -1871,6 +1877,7 @@ ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
 int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double2* A, int nzl, int P, int use_fprime,
                          double ca, double cb, double two_rho) {
   F2Args a = f->a;
+  a.nyp = a.ny;  // slab-decomposed passes: planes without pad rows
   a.nz = nzl;
   a.ca = ca;
   a.cb = cb;
@@ -1882,6 +1889,7 @@ int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double
 // A [q][zl][yq][kx] -> inverse y columns -> tmp [zl][y][kx] -> inverse x rows -> real planes
 int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out, int nzl, int P) {
   F2Args a = f->a;
+  a.nyp = a.ny;  // slab-decomposed passes: planes without pad rows
   a.nz = nzl;
   launch_col3_geom<1>(f, a, A, nullptr, tmp, slab_y_geom(f, a, nzl, P, 2));
   launch_row3(f, a, tmp, nullptr, real_out, nullptr, 2, 0);
@@ -1891,6 +1899,7 @@ int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out,
 // (unnormalised); 2: forward -> k-space update of the resident chat -> inverse of chat / N; 3: forward, stored to chat.
 int fusedslab_z(Fused2D* f, double2* B, double2* chat, int mode, int nyl, int yoff, double dtM, double dtMkappa) {
   F2Args a = f->a;
+  a.nyp = a.ny;  // slab-decomposed passes: planes without pad rows
   a.yoff = yoff;
   a.dtM = dtM;
   a.dtMkappa = dtMkappa;

@@ -809,8 +809,8 @@ class HipMultiFieldSlabEngine:
 
 class MultiFieldSlabSolver:
     """Ring of slabs for the multi-field explicit schemes: per step, refresh `ghost` planes per side of EVERY field of the
-    current time level from the two ring neighbours (torch.distributed isend / irecv: RCCL between GPUs, gloo in the CPU
-    tests), then one step of the local box.  No interior / boundary split: the exchange of nf x 2 x ghost planes is not
+    current time level from the two ring neighbours (torch.distributed isend / irecv IN PLACE, one message per field and
+    side: RCCL between GPUs, gloo in the CPU tests), then one step of the local box.  No interior / boundary split: the exchange of nf x 2 x ghost planes is not
     overlapped with compute (the BM1 / BM6 path does that; here the point is that the models decompose at all -- results are
     bit-identical to the single box).  `engine` is a HipMultiFieldSlabEngine or anything with its interface (buffers, cur,
     nf, ghost, nz, rank_lo, rank_hi, step_local, diag_local, sync, stream_context)."""
@@ -836,18 +836,18 @@ class MultiFieldSlabSolver:
             return
         if getattr(e, "device", None) is not None and dist.get_backend(self.group) != "nccl":
             e.sync()                                       # gloo reads GPU tensors from the host side
-        # strided views are staged through contiguous planes (nf x ghost x ny x nx each)
+        # in place: the layout is field-major, so the `g` boundary / ghost planes of ONE field are one contiguous block --
+        # one send and one receive per field and side straight from / into the time level the kernels use (round 3 staged
+        # the strided 5-field views through .contiguous() / new_empty / copy_: three extra device copies per side and step).
+        # Order matters when both neighbours are the same rank (world size 2): all "up" messages first on both sides.
         with e.stream_context():
-            s_lo, s_hi = send_lo.contiguous(), send_hi.contiguous()
-            r_lo, r_hi = recv_lo.new_empty(recv_lo.shape), recv_hi.new_empty(recv_hi.shape)
-            if getattr(e, "device", None) is not None and dist.get_backend(self.group) != "nccl":
-                e.sync()
-            ops = [dist.P2POp(dist.isend, s_hi, e.rank_hi, self.group, 1), dist.P2POp(dist.isend, s_lo, e.rank_lo, self.group, 2),
-                   dist.P2POp(dist.irecv, r_lo, e.rank_lo, self.group, 1), dist.P2POp(dist.irecv, r_hi, e.rank_hi, self.group, 2)]
+            nf = buf.shape[0]
+            ops = ([dist.P2POp(dist.isend, send_hi[f], e.rank_hi, self.group, 10 * f + 1) for f in range(nf)] +
+                   [dist.P2POp(dist.isend, send_lo[f], e.rank_lo, self.group, 10 * f + 2) for f in range(nf)] +
+                   [dist.P2POp(dist.irecv, recv_lo[f], e.rank_lo, self.group, 10 * f + 1) for f in range(nf)] +
+                   [dist.P2POp(dist.irecv, recv_hi[f], e.rank_hi, self.group, 10 * f + 2) for f in range(nf)])
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
-            recv_lo.copy_(r_lo)
-            recv_hi.copy_(r_hi)
 
     def step(self, dt, nsteps=1):
         for _ in range(nsteps):

@@ -260,7 +260,24 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         r[k++] = 2.0 * (double)p.nitems * p.rows * p.wseg * 16.0 / (ms / 20 * 1e-3) / GB;
       }
-      printf("  buffer %zu at %p: y %6.0f  z %6.0f  z256 %6.0f  span %6.0f\n", i, (void*)X, r[0], r[1], r[2], r[3]);
+      // does the Infinity Cache serve THIS buffer?  y pass in place on the whole array against the same pass on a 32-plane
+      // piece repeated 16 times (69 MB: resident after the first round if the pages may allocate there)
+      double mall[2];
+      for (int m = 0; m < 2; ++m) {
+        Pat p{pitch, plane, 8, 33, 33 * (m ? 32 : n), 512, 8};
+        p.lw = 3;
+        const int reps = m ? 16 * 20 : 20;
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((lsb_kernel<512, 8, false>), dim3(p.nitems), dim3(512), 65536, 0, X, X, p);
+        CK(hipEventRecord(e0, 0));
+        for (int q = 0; q < reps; ++q) hipLaunchKernelGGL((lsb_kernel<512, 8, false>), dim3(p.nitems), dim3(512), 65536, 0, X, X, p);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        mall[m] = 2.0 * (double)p.nitems * p.rows * p.wseg * 16.0 / (ms / reps * 1e-3) / GB;
+      }
+      printf("  buffer %zu at %p: y %6.0f  z %6.0f  z256 %6.0f  span %6.0f | y on a resident 32-plane piece %6.0f (whole %6.0f)\n", i,
+             (void*)X, r[0], r[1], r[2], r[3], mall[1], mall[0]);
       fflush(stdout);
     }
   }
