@@ -13,9 +13,11 @@ pfhubbenchmarks_amd/csrc/ch_fd_kernels.hip).  Workloads:
   bm1_fd_1024c  1024^3 on 1 GPU, or 1024 x 1024 x (1024/N) slabs on N GPUs (BASELINE.json config 4, strong)
   bm1_fd_512s   512^2 2-D (launch-latency bound; reported for completeness)
   bm1_spectral_512s / _256c / _512c   semi-implicit spectral scheme (BASELINE.json config 2); _512c also runs on N > 1
-                GPUs (512 x 512 x 512 N box, slab FFT: one RCCL all-to-all each way per transform)
-  bm6_fd_512c / _256c   BM6 (BASELINE.json config 5) in a periodic box: FFT Poisson solve + coupled fused FD step per
-                step; N > 1: slab FFT Poisson (2 all-to-alls) + ghost exchange of c and phi
+                GPUs: ONE 512^3 box in z-slabs (strong scaling; slab FFT: one RCCL all-to-all each way per transform);
+                _512c_weak: 512 x 512 x 512 N
+  bm6_fd_512c / _256c   BM6 (BASELINE.json config 5: "512^3, 8 x MI355X") in a periodic box: FFT Poisson solve + coupled
+                fused FD step per step; N > 1: the 512^3 box in z-slabs (strong), slab FFT Poisson (2 all-to-alls) + ghost
+                exchange of c and phi; bm6_fd_512c_weak: 512 x 512 x 512 N
   bm6_spectral_512c     BM6 with the semi-implicit spectral scheme (phi eliminated in Fourier space; 1 GPU)
   bm6_fd_512c_elim      the same physics with phi eliminated (lap_h(k phi) = -(k^2/eps)(c - mean c) exactly): the step is
                 the fused kernel alone, no transform in the time loop (phi is solved only for diagnostics)
@@ -274,7 +276,7 @@ def main():
                          "(pf_set_strip_stream: interior launch || exchange -> strips; the exchange wait leaves the critical "
                          "path); 'inline' = behind the interior launch on the compute stream (round-2 form).  Bit-identical.")
     ap.add_argument("--workload", default="bm1_fd_512c", choices=["bm1_fd_512c", "bm1_fd_1024c", "bm1_fd_512s", "bm1_spectral_512s", "bm1_spectral_256c", "bm1_spectral_1024c",
-                             "bm1_spectral_512c", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be", "bm2_fem_be", "bm3_fem_be",
+                             "bm1_spectral_512c", "bm1_spectral_512c_weak", "bm6_spectral_512c", "bm6_fd_512c", "bm6_fd_512c_weak", "bm6_fd_256c", "bm6_fd_512c_elim", "bm1_fem_be", "bm2_fem_be", "bm3_fem_be",
                              "bm2_fd_512c", "bm3_fd_512c"])
     ap.add_argument("--variant", type=int, default=-1, help="fused-kernel variant (pfk_set_tuning key 0)")
     ap.add_argument("--kernel", default="fused", choices=["fused", "twopass"])
@@ -407,6 +409,8 @@ def compact_entry(e, main=False):
     ck = ("workload", "grid", "parallelism", "newton_iterations", "time_grid", "field_store", "transforms") if main else \
          ("workload", "newton_iterations", "transforms")
     out["config"] = {k: cfg[k] for k in ck if k in cfg}
+    if main and cfg.get("status"):
+        out["config"]["status"] = cfg["status"][:320]      # which kernels / transform path ran (the N > 1 FFT modes say so here)
     rf = e.get("roofline")
     if rf is not None or main:
         out["roofline"] = None if rf is None else {k: rf[k] for k in (_ROOF_KEEP if main else _ROOF_KEEP[1:2] + _ROOF_KEEP[4:7])
@@ -445,17 +449,24 @@ def workload_table(workload, world):
     if workload == "bm6_fd_512c_elim":
         # BM6 with phi eliminated algebraically (PF_FLAG_BM6_ELIMINATE_PHI): the step is the fused CH kernel alone
         w.update(model="bm6", elim=True, gn=(512, 512, 512 * world))
-    elif workload in ("bm6_fd_512c", "bm6_fd_256c"):
-        # CH kernel 16 B + phi read 8 B + Poisson transform pair idealised at 48 B (r2c 16, invert 16, c2r 16)
-        nn = 512 if workload.endswith("512c") else 256
-        w.update(model="bm6", bytes_per_cell=72.0, gn=(nn, nn, nn * world))
+    elif workload in ("bm6_fd_512c", "bm6_fd_256c", "bm6_fd_512c_weak"):
+        # CH kernel 16 B + phi read 8 B + Poisson transform pair idealised at 48 B (r2c 16, invert 16, c2r 16).
+        # N > 1: BASELINE.json config 5 verbatim -- ONE 512^3 box split into z-slabs over the N ranks (strong scaling, the
+        # reference's `mpirun -np N` on one problem, README.md:22): every axis stays within the hand-written passes' 128..1024
+        # points.  _weak: 512 x 512 x 512 N (the slab engine's config.status says which transform path runs: beyond 1024
+        # planes it is rocFFT + pack / unpack); _256c keeps the weak form (a rehearsal size)
+        nn = 256 if workload.endswith("256c") else 512
+        weak = not workload.endswith("512c")
+        w.update(model="bm6", bytes_per_cell=72.0, gn=(nn, nn, nn * world if weak else nn), scaling="weak" if weak else "strong")
     elif workload == "bm6_spectral_512c":
         # BM6 with the spectral scheme: phi eliminated in Fourier space, same passes as bm1_spectral_512c (one GPU)
         w.update(scheme="spectral", model="bm6", bytes_per_cell=72.0, gn=(512, 512, 512), dt=1e-2)
         if world > 1:
             sys.exit("bm6_spectral_512c is single-GPU")
-    elif workload == "bm1_spectral_512c":
-        w.update(scheme="spectral", bytes_per_cell=72.0, gn=(512, 512, 512 * world), dt=1e-2)
+    elif workload in ("bm1_spectral_512c", "bm1_spectral_512c_weak"):
+        weak = workload.endswith("_weak")   # default: one 512^3 box over the N ranks (strong), as bm6_fd_512c above
+        w.update(scheme="spectral", bytes_per_cell=72.0, gn=(512, 512, 512 * world if weak else 512), dt=1e-2,
+                 scaling="weak" if weak else "strong")
     elif workload == "bm1_spectral_1024c":
         w.update(scheme="spectral", bytes_per_cell=72.0, gn=(1024, 1024, 1024), dt=1e-2)
         if world > 1:
@@ -668,8 +679,9 @@ def bench_grid(a, workload, ctx, steps, warmup, cpu=True, copy_ceiling=False):
         "ranks": ranks_info,
         "check": {"F_before": F0, "F_after": F1, "C_rel_drift": abs(C1 - C0) / abs(C0)},
     }
-    if not slab and getattr(solver, "status", ""):
-        out["config"]["status"] = solver.status      # pf_status_string: kernels in use; spectral: what the placement probe saw
+    st = getattr(solver, "status", "") or getattr(timer, "status", "")
+    if st:
+        out["config"]["status"] = st      # pf_status_string: kernels in use; FFT modes: which transform path runs, chunking
     if scheme == "spectral" and not slab:
         # one pf_step call advances `steps` steps; the state is the resident spectrum, the real-space field is written by
         # the last two steps of the call (PFHIP_SPECTRAL_STORE_EVERY_STEP=1 writes it every step)

@@ -689,6 +689,7 @@ const char* pf_status_string(const pf_handle* h) {
   } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
     m->status = "spectral: semi-implicit Fourier";
     if (h->sp) m->status += std::string("; ") + spectral_path(h->sp);
+    if (h->sf) m->status += std::string("; slab transforms (one all-to-all each way): ") + slabfft_path(h->sf);
   } else {
     FdArgs a = make_args(h, 1.0, 0, h->g.nz);
     const bool fused = c.kernel != PF_KERNEL_TWOPASS && ch_fd_fused_supported(a);
@@ -702,6 +703,8 @@ const char* pf_status_string(const pf_handle* h) {
                   "kernels, 40 B per cell update instead of 16 (about 6x slower); pad nx to an even number";
   }
   if (h->po) m->status += std::string("; Poisson solve: ") + poisson_path(h->po);
+  if (h->sf && !(h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI))
+    m->status += std::string("; slab Poisson solve (one all-to-all each way): ") + slabfft_path(h->sf);
   return m->status.c_str();
 }
 

@@ -152,6 +152,7 @@ int slabfft_spectral_update_on_T(SlabFFT* sf, double dtM, double dtMkappa);
 int slabfft_z_update(SlabFFT* sf, double dtM, double dtMkappa);
 int slabfft_grad_energy_local(SlabFFT* sf, double* out_dev);
 const char* slabfft_error(const SlabFFT* sf);
+const char* slabfft_path(const SlabFFT* sf);   // which transform kernels run between the all-to-alls
 
 // BE-parity mode (fem_be.hip): the reference's P1 crossed-mesh backward-Euler Newton solve on the GPU
 struct FemBE;

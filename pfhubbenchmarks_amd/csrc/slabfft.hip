@@ -174,6 +174,12 @@ struct SlabFFT {
   } while (0)
 
 const char* slabfft_error(const SlabFFT* sf) { return sf->err.c_str(); }
+// which transforms this rank runs between the all-to-alls (for pf_status_string)
+const char* slabfft_path(const SlabFFT* sf) {
+  return sf->fast ? fused2d_describe(sf->fast)
+                  : "rocFFT (native API): batched 2-D r2c / c2r on the local planes, strided 1-D c2c along z, pack / unpack kernels "
+                    "(the hand-written passes take power-of-two boxes of 128..1024 points per axis)";
+}
 int64_t slabfft_doubles_per_peer(const SlabFFT* sf) { return 2 * sf->blk; }
 double* slabfft_buf(const SlabFFT* sf, int which) { return reinterpret_cast<double*>(which == 0 ? sf->A : sf->B); }
 

@@ -1863,7 +1863,8 @@ bool fusedslab_supported(int nx, int ny, int nz, int P) {
 }
 namespace {
 ColGeom slab_y_geom(const Fused2D* f, const F2Args& a, int nzl, int P, int on) {
-  ColGeom g = axis_geom(f, a, 1);  // a.nz == nzl: one batch per local plane
+  ColGeom g = axis_geom(f, a, 1);  // one batch per plane of this launch (a.nz planes of the rank's nzl: the layout below
+                                   // speaks of the whole local slab, the caller offsets the base pointers by the first plane)
   const int nyl = a.ny / P;
   g.spon = on;
   g.ms.lr = ilog2(nyl);            // element r of a column goes to chunk r / nyl of the all-to-all layout
@@ -1882,8 +1883,13 @@ int fusedslab_forward_xy(Fused2D* f, const double* real_in, double2* tmp, double
   a.ca = ca;
   a.cb = cb;
   a.two_rho = two_rho;
-  launch_row3(f, a, nullptr, real_in, nullptr, tmp, 0, use_fprime);
-  launch_col3_geom<0>(f, a, tmp, nullptr, A, slab_y_geom(f, a, nzl, P, 1));
+  // both passes are plane-local: chunk of planes by chunk of planes (run_chunked), tmp stays on the die in between
+  const int64_t plane = spec_plane(a), rplane = (int64_t)a.ny * a.nx, aplane = (int64_t)(a.ny / P) * a.pitch;
+  if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+        launch_row3(&fc, ac, nullptr, real_in + z0 * rplane, nullptr, tmp + z0 * plane, 0, use_fprime);
+        launch_col3_geom<0>(&fc, ac, tmp + z0 * plane, nullptr, A + z0 * aplane, slab_y_geom(&fc, ac, nzl, P, 1));
+      }) != 0)
+    return -3;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 // A [q][zl][yq][kx] -> inverse y columns -> tmp [zl][y][kx] -> inverse x rows -> real planes
@@ -1891,8 +1897,12 @@ int fusedslab_inverse_yx(Fused2D* f, double2* A, double2* tmp, double* real_out,
   F2Args a = f->a;
   a.nyp = a.ny;  // slab-decomposed passes: planes without pad rows
   a.nz = nzl;
-  launch_col3_geom<1>(f, a, A, nullptr, tmp, slab_y_geom(f, a, nzl, P, 2));
-  launch_row3(f, a, tmp, nullptr, real_out, nullptr, 2, 0);
+  const int64_t plane = spec_plane(a), rplane = (int64_t)a.ny * a.nx, aplane = (int64_t)(a.ny / P) * a.pitch;
+  if (run_chunked(f, a, [&](const Fused2D& fc, const F2Args& ac, int z0) {
+        launch_col3_geom<1>(&fc, ac, A + z0 * aplane, nullptr, tmp + z0 * plane, slab_y_geom(&fc, ac, nzl, P, 2));
+        launch_row3(&fc, ac, tmp + z0 * plane, nullptr, real_out + z0 * rplane, nullptr, 2, 0);
+      }) != 0)
+    return -3;
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 // z columns of B (T layout, nyl local y-rows starting at global row yoff), in place.  mode 0: forward; 1: inverse

@@ -88,6 +88,7 @@ class PhaseFieldSolver:
         self.shape = tuple(int(cfg.n[d]) for d in reversed(range(dim)))  # numpy order (z, y, x) / (y, x)
         self._h = C.c_void_p()
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         self.nelem = int(self._lib.pf_field_elems(C.byref(cfg)))
         if scheme == "fem_be":      # fields are nodal vectors in the reference's node order (corners, then centres)
             self.shape = (self.nelem,)
@@ -304,6 +305,7 @@ class HipSlabEngine:
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         lay = _lib.PfHaloLayout()
         self._ck(self._lib.pf_halo_layout_get(self._h, C.byref(lay)))
         self.rank_lo, self.rank_hi = lay.rank_lo, lay.rank_hi   # -1 = wall (mirror bc): nothing to exchange there
@@ -738,6 +740,7 @@ class HipMultiFieldSlabEngine:
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         lay = _lib.PfHaloLayout()
         self._ck(self._lib.pf_field_halo_layout(self._h, 0, C.byref(lay)))
         self.rank_lo, self.rank_hi = lay.rank_lo, lay.rank_hi
@@ -923,6 +926,7 @@ class HipFFTSlabEngine(HipSlabEngine):
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
+        self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         self.rank_lo = (rank - 1) % nranks
         self.rank_hi = (rank + 1) % nranks
 

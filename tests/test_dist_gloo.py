@@ -145,12 +145,14 @@ def test_multifield_slab_solver_matches_single_domain(model, world, tmp_path):
 
 def test_eight_rank_partitions_of_the_baseline_configs():
     """pure-host geometry of the driver's 8-GPU runs (no GPU, no process group): BASELINE.json config 4 strong
-    (1024^3 -> 128 planes per rank, 16 MiB ghost messages), config 3/5 weak (512 planes per rank of a 512 x 512 x 4096
-    box), and the slab-FFT all-to-all block size -- what bench.py --gpus 8 will allocate per rank."""
+    (1024^3 -> 128 planes per rank, 16 MiB ghost messages), config 3 weak (512 planes per rank of a 512 x 512 x 4096
+    box), config 5 / the spectral scheme strong (ONE 512^3 box -> 64 planes per rank: every axis within the hand-written
+    passes' 128..1024 points), and the slab-FFT all-to-all block size -- what bench.py --gpus 8 will allocate per rank."""
     import ctypes as C
     from pfhubbenchmarks_amd import lib as L
     lib = L.load()
-    for (nx, ny, nzg, world) in ((1024, 1024, 1024, 8), (512, 512, 4096, 8), (512, 512, 1024, 2), (512, 512, 2048, 4)):
+    for (nx, ny, nzg, world) in ((1024, 1024, 1024, 8), (512, 512, 4096, 8), (512, 512, 1024, 2), (512, 512, 2048, 4),
+                                 (512, 512, 512, 8), (512, 512, 512, 4), (512, 512, 512, 2)):
         planes = []
         for r in range(world):
             f, c = C.c_int(), C.c_int()

@@ -1476,15 +1476,20 @@ def _lockstep(engs, op, dt=0.0):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("n,P", [((64, 24, 16), 2), ((128, 128, 128), 2), ((128, 256, 512), 4), ((512, 128, 128), 1)])
+@pytest.mark.parametrize("n,P,chunk", [((64, 24, 16), 2, None), ((128, 128, 128), 2, None), ((128, 256, 512), 4, None),
+                                       ((512, 128, 128), 1, None), ((128, 256, 512), 4, "24,2"), ((128, 128, 128), 2, "7,3")])
 @pytest.mark.parametrize("mode", ["spectral", "bm6"])
-def test_fft_slab_modes_on_one_gpu(lib, mode, n, P):
+def test_fft_slab_modes_on_one_gpu(lib, monkeypatch, mode, n, P, chunk):
     """slab FFT modes (pf_dist_begin / pf_dist_advance): P rank handles on the one GPU, collectives emulated by
     copies, against the single-domain numpy oracles.  (64, 24, 16): rocFFT + pack / unpack kernels; the power-of-two
     boxes: the hand-written LDS-FFT passes with the all-to-all layout written / read by the y pass itself
-    (fusedslab_*: radix-2^2 and radix-8 column kernels, 2 / 4 ranks and the single-rank ring)."""
+    (fusedslab_*: radix-2^2 and radix-8 column kernels, 2 / 4 ranks and the single-rank ring).  chunk: the rank-local x / y
+    passes chunk of planes by chunk of planes on side streams (PFHIP_FFT3D_CHUNK; the default at production sizes: 512^3
+    over 8 ranks = 64 planes per rank in chunks of 31)."""
     from oracle import bm6_fd, ch_spectral
     from pfhubbenchmarks_amd.solver import HipFFTSlabEngine
+    if chunk:
+        monkeypatch.setenv("PFHIP_FFT3D_CHUNK", chunk)
     rng = np.random.default_rng(31)
     full = 0.5 + 0.05 * rng.standard_normal(n[::-1])
     engs = [HipFFTSlabEngine(n, 1.0, P, r, 0, scheme="spectral" if mode == "spectral" else "fd",
@@ -1719,6 +1724,7 @@ def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
     (2, "bm1_fd_512c", [512, 512, 1024], "weak"),          # the driver's default series (weak: 512^3 per rank)
     (4, "bm1_fd_1024c", [1024, 1024, 1024], "strong"),     # BASELINE.json config 4: 1024^3 split into z-slabs
     (2, "bm6_fd_256c", [256, 256, 512], "weak"),           # BM6: slab-FFT Poisson (2 all-to-alls) + ghost exchange of c, phi
+    (2, "bm1_spectral_512c", [512, 512, 512], "strong"),   # FFT modes at N > 1: ONE 512^3 box over the ranks (BASELINE config 5's form)
 ])
 def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scaling):
     """The driver's N > 1 command line (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) on the
@@ -1752,6 +1758,8 @@ def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scali
     assert d["check"]["C_rel_drift"] < 1e-12 and d["check"]["F_after"] < d["check"]["F_before"]
     assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None
     assert d["repeats"] == 2 and len(d["block_ms_per_step"]) == 2 and d["preheat_steps"] >= 5
+    if workload.startswith("bm1_spectral") or workload.startswith("bm6"):      # the line says which transform path ran
+        assert "slab" in d["config"]["status"] and "hand-written LDS-FFT passes" in d["config"]["status"], d["config"]["status"]
     # the process group's own account of who ran: N ranks, one entry (rank, device, pid) each, distinct processes
     rk = d["ranks"]
     assert rk["world_size"] == world and rk["backend"] == "gloo"
