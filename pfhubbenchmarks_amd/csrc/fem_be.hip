@@ -1155,6 +1155,7 @@ struct FemBE {
   bool own_trsm = true;                    // D^-1 [L | U | r] of the dense levels by lu_solve_mfma_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS trsm / rocSOLVER getrs)
   bool own_getrf = true;                   // un-pivoted LU of the dense levels by lu_npvt_coop_kernel (PFHIP_FEM_GETRF=rocsolver: getrf_npvt)
   int* tflags = nullptr;                   // its panel flags: (ng / 2 + 1) x ceil(nb / 16)
+  bool coop_lost = false;                  // the cooperative LU was switched off on this handle (fembe_describe says so)
   bool getrf_check = false;                // PFHIP_FEM_GETRF=check (DEBUG): own LU and rocSOLVER's, compared entry by entry on the host
   bool test_starve = false;                // PFHIP_FEM_TEST_LU_STARVE=1 (TEST ONLY): the cooperative LU is launched with half of its workgroups
   bool own_gemv = true;                    // y -= A x of the levels by gemv_sub_kernel (PFHIP_FEM_TRSM=rocblas: rocBLAS, with the substitutions)
@@ -1204,6 +1205,17 @@ struct FemBE {
   } while (0)
 
 const char* fembe_error(const FemBE* fb) { return fb->err.c_str(); }
+// which kernels factor the dense reduction levels right now (for pf_status_string): the cooperative LU needs 8 XCDs and G
+// co-resident workgroups per matrix per XCD; on a part / partition mode where that does not hold it is switched off after
+// its first failed launch and the handle says so instead of only counting attempts
+const char* fembe_describe(const FemBE* fb) {
+  if (fb->coop_lost)
+    return "dense levels: rocSOLVER un-pivoted LU -- WARNING: the cooperative LU kernel (lu_npvt_coop_kernel) did not get its "
+           "workgroups on this device (XCD count / CU share / partition mode) and was switched off for this handle";
+  if (fb->solver == 1) return "sequential block Thomas sweep (PFHIP_FEM_SOLVER=thomas)";
+  return fb->own_getrf ? "dense levels: cooperative un-pivoted LU + MFMA substitutions (own kernels)"
+                       : "dense levels: rocSOLVER LU (PFHIP_FEM_GETRF)";
+}
 int fembe_nodes(const FemBE* fb) { return fb->p.nn; }
 int fembe_last_iters(const FemBE* fb) { return fb->last_iters; }
 
@@ -2721,6 +2733,7 @@ static int fembe_step_once(FemBE* fb, double dt, int* converged, int* iters) {
         // ... or the cooperative LU did not get its workgroups (another XCD count / CU share than its ticket scheme
         // assumes): not a property of the matrices -- leave it off for this handle instead of failing every solve once
         fb->own_getrf = false;
+        fb->coop_lost = true;
         if (fb->verbose) fprintf(stderr, "[fem_be] cooperative LU switched off: a matrix was left without its workgroups\n");
       }
       break;

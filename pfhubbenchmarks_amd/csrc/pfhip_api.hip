@@ -685,7 +685,7 @@ const char* pf_status_string(const pf_handle* h) {
     m->status = multifd_streaming(h->mf) ? "fd: explicit multi-field scheme (BM2 / BM3), streaming LDS-tiled kernels"
                                          : "fd: explicit multi-field scheme (BM2 / BM3), one thread per cell";
   } else if (h->fb) {
-    m->status = "fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction";
+    m->status = std::string("fem_be: P1 crossed-mesh backward Euler, Newton + block cyclic reduction; ") + fembe_describe(h->fb);
   } else if (h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI) {
     m->status = "spectral: semi-implicit Fourier";
     if (h->sp) m->status += std::string("; ") + spectral_path(h->sp);

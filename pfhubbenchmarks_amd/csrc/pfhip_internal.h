@@ -177,6 +177,7 @@ long long fembe_stat(const FemBE* fb, int key);
 void fembe_set_max_newton(FemBE* fb, int n);  // n <= 0: keep the default (10, bench1.py:88)
 int fembe_diagnostics(FemBE* fb, double out[3]);
 const char* fembe_error(const FemBE* fb);
+const char* fembe_describe(const FemBE* fb);  // which kernels factor the dense levels (says when the cooperative LU was switched off)
 
 // explicit finite-difference schemes of the multi-field benchmarks BM2 / BM3 (multi_fd.hip)
 struct MultiFD;

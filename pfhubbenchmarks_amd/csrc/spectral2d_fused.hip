@@ -622,6 +622,90 @@ __global__ __launch_bounds__(64, MINW) void f3_row512p_kernel(const F2Args a, co
   }
 }
 
+// The one-directional row passes (Poisson solve: real c -> forward x; ... -> inverse x -> real phi; initialisation: real
+// field -> forward x of it or of f'(it)) in the same persistent, prefetching form.  Round 3 ran them on f2_row512_kernel<true>
+// (one short-lived wave per row pair, twiddles re-read before every use, no load in flight during the transform): 1.56 ms
+// of the 2.96 ms BM6 FD + Poisson step for 4.3 GB, 2.8 TB/s (profiles/r04/summary_bm6_fd_512c_before_row_kernels.json).
+//   FWD: rows y0, y1 of a real field (8-byte loads, 512 B per wave instruction) -> [f'] -> forward x -> G rows
+//   INV: H rows -> inverse x -> rows of a real field
+template <bool FWD>
+__global__ __launch_bounds__(64, 2) void f3_row512d_kernel(const F2Args a, const double2* __restrict__ H,
+                                                           const double* __restrict__ r_in, double* __restrict__ r_out,
+                                                           double2* __restrict__ G, const double2* __restrict__ twA_g,
+                                                           const double2* __restrict__ twB_g, int npairs, int use_fprime) {
+  __shared__ __attribute__((aligned(16))) double2 L[W8];
+  constexpr int N = 512;
+  const int lane = threadIdx.x;
+  const int T = (lane >> 3) + 8 * (lane & 7);
+  double2 twN[7], twB[7];
+  load_tw(twN, twA_g, lane);
+  load_tw(twB, twB_g, lane & 7);
+  double2 p[8], q[8];  // INV: the two half-spectrum rows; FWD: p[j] = (row y0, row y1) at x = lane + 64 j (q unused)
+  auto issue = [&](int pr) {
+    if (FWD) {
+      const double *r0 = r_in + (int64_t)(2 * pr) * N + lane, *r1 = r0 + N;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] = make_double2(r0[64 * j], r1[64 * j]);
+    } else {
+      const int64_t r0 = spec_row_flat(a, 2 * pr), r1 = spec_row_flat(a, 2 * pr + 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = lane + 64 * j;
+        const int kk = k > N / 2 ? N - k : k;
+        p[j] = H[r0 + kk];
+        q[j] = H[r1 + kk];
+      }
+    }
+  };
+  int pair = blockIdx.x;
+  if (pair < npairs) issue(pair);
+  while (pair < npairs) {
+    double2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (FWD) {
+        v[j] = use_fprime ? make_double2(fp2(p[j].x, a), fp2(p[j].y, a)) : p[j];
+      } else {
+        const bool upper = lane + 64 * j > N / 2;
+        v[j] = upper ? make_double2(p[j].x + q[j].y, q[j].x - p[j].y) : make_double2(p[j].x - q[j].y, p[j].y + q[j].x);
+      }
+    }
+    const int y0 = 2 * pair, y1 = y0 + 1;
+    const int next = pair + gridDim.x;
+    if (next < npairs) issue(next);
+    fft512_wave<FWD ? -1 : +1>(v, L, lane, twN, twB, lane);
+    if (FWD) {
+      // Hermitian separation of the two real rows: needs X[k] and X[N - k] -> one more exchange (skewed: k + k / 8)
+      wave_lds_sync();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = T + 64 * t;
+        L[k + (k >> 3)] = v[t];
+      }
+      wave_lds_sync();
+      const int64_t g0 = spec_row_flat(a, y0), g1 = spec_row_flat(a, y1);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int k = lane + 64 * t;
+        if (k <= N / 2) {
+          const int km = (N - k) & (N - 1);
+          const double2 w = L[k + (k >> 3)], mm = L[km + (km >> 3)];
+          G[g0 + k] = make_double2(0.5 * (w.x + mm.x), 0.5 * (w.y - mm.y));
+          G[g1 + k] = make_double2(0.5 * (w.y + mm.y), -0.5 * (w.x - mm.x));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        r_out[(int64_t)y0 * N + T + 64 * t] = v[t].x;
+        r_out[(int64_t)y1 * N + T + 64 * t] = v[t].y;
+      }
+    }
+    wave_lds_sync();
+    pair = next;
+  }
+}
+
 // =====================================================================================================================
 // 3-D (512^3): the same one-wave radix-8 transforms applied along y and along z of the [z][y][kx] half spectrum.
 // A workgroup owns 8 adjacent k_x columns (one full 128-byte line per row of the column) of one "batch" (a z-plane for
@@ -1561,6 +1645,18 @@ void launch_row3(const Fused2D* f, const F2Args& a, const double2* H, const doub
     const int grid = f->ncu * 8 < npairs ? f->ncu * 8 : npairs;
     hipLaunchKernelGGL(f3_row512p_kernel<2>, dim3(grid), dim3(64), 0, f->stream, a, H, c_out, G, (const double2*)f->tw8a,
                        (const double2*)f->tw8b, npairs);
+    return;
+  }
+  if (f->row512 && (from_spectrum == 0 || from_spectrum == 2)) {
+    // the one-directional row passes (real field -> forward x; inverse x -> real field): same persistent form
+    const int npairs = a.ny * a.nz / 2;
+    const int grid = f->ncu * 8 < npairs ? f->ncu * 8 : npairs;
+    if (from_spectrum == 0)
+      hipLaunchKernelGGL(f3_row512d_kernel<true>, dim3(grid), dim3(64), 0, f->stream, a, H, c_in, c_out, G,
+                         (const double2*)f->tw8a, (const double2*)f->tw8b, npairs, use_fprime);
+    else
+      hipLaunchKernelGGL(f3_row512d_kernel<false>, dim3(grid), dim3(64), 0, f->stream, a, H, c_in, c_out, G,
+                         (const double2*)f->tw8a, (const double2*)f->tw8b, npairs, use_fprime);
     return;
   }
   if (f->row512)

@@ -141,6 +141,11 @@ class PhaseFieldSolver:
         self._ck(self._lib.pf_set_ic_bm3(self._h, r, w, vin, vout))
         self.t = 0.0
 
+    def describe(self):
+        """pf_status_string NOW (self.status is the string at creation): e.g. the BE-parity mode reports here when its
+        cooperative LU kernel was switched off on this device."""
+        return (self._lib.pf_status_string(self._h) or b"").decode()
+
     def stat(self, key):
         """pf_get_stat: counters of the last step (lib.PF_STAT_*; fem_be scheme)"""
         v = C.c_int64(0)

@@ -1318,6 +1318,9 @@ def test_fem_be_cooperative_lu_without_its_workgroups_is_reported_and_switched_o
             assert ok
             assert s.stat(L.PF_STAT_FEM_ATTEMPTS) == (2 if k == 0 else 1), k
             assert (s.stat(L.PF_STAT_FEM_NPVT_LEVELS) == 0) == (k == 0), k      # the repeat pivots everywhere; later: library npvt
+            # ... and the handle SAYS so (pf_status_string), it does not only count attempts
+            assert "cooperative LU kernel" in s.describe() and "switched off" in s.describe(), s.describe()
+        assert "own kernels" in s.status and "switched off" not in s.status      # (the string at creation)
             assert s.last_iters == ref[k][0]
             for a, b in zip((s.get_field("c"), s.get_field("eta3")), ref[k][1:]):
                 assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
