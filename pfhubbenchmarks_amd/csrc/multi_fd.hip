@@ -123,6 +123,18 @@ __global__ __launch_bounds__(256) void bm3_update_kernel(const MfdParams p, cons
 //     for 2-D problems and for extents that do not tile).
 // PASS 30: BM3 update (U, phi -> U, phi: 32 B/cell).  PASS 20: BM2 mu pass (c with stencil, 4 eta pointwise -> mu: 48 B).
 // PASS 21: BM2 update (mu and 4 eta with stencil, c pointwise -> 5 fields: 88 B).
+// output planes are never re-read inside the launch: non-temporal stores keep them from evicting the halo lines the
+// neighbour tiles are about to read from the XCD's L2 (the BM1 kernel gained 2-8 % from the same); NT is a
+// template switch for the in-process A/B (pfk_set_tuning key 10)
+template <bool NT>
+__device__ __forceinline__ void st_out(double* p, double2 v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+  } else {
+    *reinterpret_cast<double2*>(p) = v;
+  }
+}
 constexpr int SX = 128, SPITCH = 132;   // tile width; LDS row pitch (own cells at 2..129, halo at 1 and 130)
 
 template <int PASS>
@@ -134,7 +146,7 @@ struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2, MINW = 1;
 template <>
 struct PassTraits<21> { static constexpr int NS = 5, NPW = 1, RPT = 1, MINW = 1; };
 
-template <int PASS>
+template <int PASS, bool NT>
 __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel(const MfdParams p, const double* __restrict__ u,
                                                          const double* __restrict__ mu_in, double* __restrict__ out,
                                                          double dt, int zchunk) {
@@ -248,8 +260,8 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
             nU.x = nu_;
           }
         }
-        *reinterpret_cast<double2*>(out + o) = nU;
-        *reinterpret_cast<double2*>(out + cells + o) = nP;
+        st_out<NT>(out + o, nU);
+        st_out<NT>(out + cells + o, nP);
       } else if (PASS == 20) {
         const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3];
         double2 m;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
           }
         }
 #pragma unroll
-        for (int f = 0; f < 5; ++f) *reinterpret_cast<double2*>(out + (int64_t)f * cells + o) = res[f];
+        for (int f = 0; f < 5; ++f) st_out<NT>(out + (int64_t)f * cells + o, res[f]);
       }
     }
     __syncthreads();
@@ -341,6 +353,7 @@ struct Bm2Lds {
   double et[4][B2TY + 2][SPITCH];
 };
 
+template <bool NT>
 __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const double* __restrict__ u,
                                                        double* __restrict__ un, double dt, int zchunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
         double lx = ((xl + m.y) + (ym.x + yp.x)) - 4.0 * m.x, ly = ((m.x + xr) + (ym.y + yp.y)) - 4.0 * m.y;
         lx = lx + ((mu3[0].x + mu3[2].x) - 2.0 * m.x);
         ly = ly + ((mu3[0].y + mu3[2].y) - 2.0 * m.y);
-        *reinterpret_cast<double2*>(un + o) = make_double2(c.x + (dt * Mob * p.inv_h2) * lx, c.y + (dt * Mob * p.inv_h2) * ly);
+        st_out<NT>(un + o, make_double2(c.x + (dt * Mob * p.inv_h2) * lx, c.y + (dt * Mob * p.inv_h2) * ly));
       }
       double2 res[4];
 #pragma unroll
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<double2*>(un + (int64_t)(k + 1) * cells + o) = res[k];
+      for (int k = 0; k < 4; ++k) st_out<NT>(un + (int64_t)(k + 1) * cells + o, res[k]);
     }
     __syncthreads();
     // ---- P4: eta(z+1) -> tiles; rotate ----
@@ -739,9 +752,12 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, dou
     MF_HIP(hipMemsetAsync(mf->u[0], 0, bytes, stream));
     MF_HIP(hipMemsetAsync(mf->u[1], 0, bytes, stream));
     if (model == 2) MF_HIP(hipMalloc(&mf->mu, sizeof(double) * (size_t)mf->cells));
-    if (model == 2)
-      MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm2_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (model == 2) {
+      MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm2_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(Bm2Lds)));
+      MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm2_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sizeof(Bm2Lds)));
+    }
     MF_HIP(hipMalloc(&mf->partials, sizeof(double) * 5 * 1024));
     MF_HIP(hipMalloc(&mf->out5, sizeof(double) * 8));
     MF_HIP(hipHostMalloc(&mf->out5_host, sizeof(double) * 8, hipHostMallocDefault));
@@ -779,6 +795,9 @@ double* multifd_field_ptr(MultiFD* mf, int f) {   // the owned planes
 }
 void multifd_touch(MultiFD* mf) { mf->have_prev = false; }
 
+int g_mfd_nt = 1;  // non-temporal stores of the output planes of the streaming multi-field kernels (pfk_set_tuning key 10 = 0: plain stores, A/B:
+                   // BM3 0.8416 -> 0.8145 ms per 512^3 step, BM2 2.275 -> 2.265 in one process, profiles/r04/mfd_nt_stores_ab.log)
+void multifd_set_nt(int v) { g_mfd_nt = v; }
 namespace {
 // z-chunks so that the grid holds about 4 workgroups per CU
 template <int PASS>
@@ -790,7 +809,10 @@ void launch_stream(const MultiFD* mf, const double* u, const double* mu, double*
   if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
   const int zchunk = (p.nz + nchunk - 1) / nchunk;
   nchunk = (p.nz + zchunk - 1) / zchunk;
-  hipLaunchKernelGGL(mfd_stream_kernel<PASS>, dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
+  if (g_mfd_nt)
+    hipLaunchKernelGGL((mfd_stream_kernel<PASS, true>), dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
+  else
+    hipLaunchKernelGGL((mfd_stream_kernel<PASS, false>), dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
 }
 }  // namespace
 
@@ -814,7 +836,10 @@ int multifd_step(MultiFD* mf, double dt, int nsteps) {
         if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
         const int zchunk = (p.nz + nchunk - 1) / nchunk;
         nchunk = (p.nz + zchunk - 1) / zchunk;
-        hipLaunchKernelGGL(bm2_fused_kernel, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
+        if (g_mfd_nt)
+          hipLaunchKernelGGL(bm2_fused_kernel<true>, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
+        else
+          hipLaunchKernelGGL(bm2_fused_kernel<false>, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
       } else if (p.model == 2) {
         launch_stream<20>(mf, u, nullptr, mf->mu, dt);
         launch_stream<21>(mf, u, mf->mu, un, dt);

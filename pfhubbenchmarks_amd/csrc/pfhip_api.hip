@@ -1660,6 +1660,10 @@ int pfk_set_tuning(int key, int value) {
     set_diag_tuning(value, 0);
     return PF_OK;
   }
+  if (key == 10 && (value == 0 || value == 1)) {  // BM2 / BM3 streaming kernels: non-temporal stores of the output planes
+    multifd_set_nt(value);
+    return PF_OK;
+  }
   if (key == 9 && value > 0) {  // diagnostics kernel: target number of workgroups
     set_diag_tuning(-1, value);
     return PF_OK;
