@@ -36,7 +36,7 @@ stats = [r for r in stats if "pfhip" in r["Name"]]
 # spectral / Poisson steps run once per CHUNK of planes (17 launches per step at 512^3) on two streams: their per-launch
 # averages are per chunk and overlap in time, so the sum of the kernel times exceeds the wall time of a step.
 tot_max = max(float(r["TotalDurationNs"]) for r in stats)
-step_kernels = [r for r in stats if float(r["TotalDurationNs"]) >= 0.04 * tot_max]
+step_kernels = [r for r in stats if float(r["TotalDurationNs"]) >= 0.15 * tot_max]
 top = min(int(r["Calls"]) for r in step_kernels)
 cnt = {}
 for passdir, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
