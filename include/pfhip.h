@@ -295,7 +295,9 @@ int pf_get_stat(pf_handle* h, int key, int64_t* value);
 
 /* ---- measurement hooks ------------------------------------------------------------------------------- */
 /* average device time (ms) of the dominant step kernel over the launches since the last call, measured with
- * HIP events on the handle's stream; enable with pf_timing_enable(h, 1). */
+ * HIP events on the handle's stream; enable with pf_timing_enable(h, 1).  Launches that pf_set_strip_stream moved to
+ * another stream (the boundary strips of pf_step_finish) are NOT in this figure -- it then covers the interior launches
+ * only; time such a configuration with the wall clock (bench.py times every slab-mode run that way). */
 int pf_timing_enable(pf_handle* h, int on);
 int pf_timing_read(pf_handle* h, double* avg_ms, int64_t* launches);
 /* the individual launches since pf_timing_enable(h, 1) (at most 65536 are kept): device time of each (dur_ms) and
