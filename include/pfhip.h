@@ -254,7 +254,9 @@ int pf_halo_layout_get(pf_handle* h, pf_halo_layout* out);
  * planes in physical x, y nodes): the ghost planes
  * of field `field` (0 .. nf-1: BM2 c, eta1..4; BM3 U, phi -- dolfin/bench2.py:76-113, bench3.py:63-97 are the equations) in
  * the CURRENT time level, ghost = 2 (BM2: c reaches through mu) or 1 (BM3) per side, the slabs a ring.  Protocol per step:
- * refresh the ghost planes of EVERY field from the two ring neighbours, then pf_step(h, dt, 1, info); the layout moves to
+ * refresh the ghost planes of EVERY field from the two ring neighbours, then pf_step(h, dt, 1, info) -- or, overlapped like
+ * the single-field path: post the exchange, pf_step_begin (the planes that need no ghosts), wait for the exchange,
+ * pf_step_finish (the g owned planes next to each ghost layer; swaps the time levels).  The layout moves to
  * the other time level with each step (cur_index).  With pf_config.ext_c the two time levels live in caller-owned buffers
  * of pf_field_elems_with_ghosts() doubles each (all fields, field-major), so a communication library can send / receive
  * the planes in place.  Results are bit-identical to the single-GPU box. */

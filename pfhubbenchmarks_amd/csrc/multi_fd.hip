@@ -26,6 +26,7 @@ namespace {
 struct MfdParams {
   int model, nf, nx, ny, nz;
   int gz;   // slab mode: ghost planes per side inside nz (refreshed by the caller before every step); diagnostics skip them
+  int zlo = 0, zhi = 0;   // planes [zlo, zhi) to compute in this launch (multifd_step_range; a whole step: [0, nz))
   double inv_h2;
   // BM2: ca, cb, rho2, kappa_c, M, kappa_eta, w, alpha, L     BM3: lam, 1/tau, W^2, D
   double q[9];
@@ -52,8 +53,8 @@ __device__ __forceinline__ double hsp(double u) { return (30.0 * (u * u)) * ((1.
 __global__ __launch_bounds__(256) void bm2_mu_kernel(const MfdParams p, const double* __restrict__ u,
                                                      double* __restrict__ mu) {
   const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= cells) return;
+  const int64_t i = (int64_t)p.zlo * p.nx * p.ny + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)p.zhi * p.nx * p.ny) return;
   const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
   const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3];
   const double c = u[i];
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void bm2_update_kernel(const MfdParams p, cons
                                                          const double* __restrict__ mu, double* __restrict__ un,
                                                          double dt) {
   const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= cells) return;
+  const int64_t i = (int64_t)p.zlo * p.nx * p.ny + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)p.zhi * p.nx * p.ny) return;
   const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
   const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], Mob = p.q[4], ke = p.q[5], w = p.q[6], al = p.q[7], L = p.q[8];
   const double c = u[i];
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void bm2_update_kernel(const MfdParams p, cons
 __global__ __launch_bounds__(256) void bm3_update_kernel(const MfdParams p, const double* __restrict__ u,
                                                          double* __restrict__ un, double dt) {
   const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= cells) return;
+  const int64_t i = (int64_t)p.zlo * p.nx * p.ny + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)p.zhi * p.nx * p.ny) return;
   const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
   const double lam = p.q[0], it = p.q[1], W2 = p.q[2], D = p.q[3];
   const double U = u[i], ph = u[cells + i];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
   const int xq = blockIdx.x % 8, rq = blockIdx.x / 8;
   const int tile_id = full == 0 ? xq * per + rq : ((xq < full ? xq * per : full * per + (xq - full) * (per - 1)) + rq);
   const int x0 = (tile_id % ntx) * SX, y0 = ((tile_id / ntx) % nty) * TY;
-  const int zb = (tile_id / (ntx * nty)) * zchunk, ze = zb + zchunk < p.nz ? zb + zchunk : p.nz;
+  const int zb = p.zlo + (tile_id / (ntx * nty)) * zchunk, ze = zb + zchunk < p.zhi ? zb + zchunk : p.zhi;
   const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
   const int xo = x0 + 2 * lane;
   // stencilled field s of this pass -> where it lives
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
   const int tile = full == 0 ? xq * per + rq : ((xq < full ? xq * per : full * per + (xq - full) * (per - 1)) + rq);
   const int bx = tile % ntx, by = (tile / ntx) % nty, bz = tile / (ntx * nty);
   const int x0 = bx * SX, y0 = by * B2TY;
-  const int zb = bz * zchunk, ze = zb + zchunk < p.nz ? zb + zchunk : p.nz;
+  const int zb = p.zlo + bz * zchunk, ze = zb + zchunk < p.zhi ? zb + zchunk : p.zhi;
   const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
   const int xo = x0 + 2 * lane, tx = 2 + 2 * lane;
   const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3], Mob = p.q[4], ke = p.q[5], w = p.q[6], al = p.q[7], L = p.q[8];
@@ -798,65 +799,97 @@ void multifd_touch(MultiFD* mf) { mf->have_prev = false; }
 int g_mfd_nt = 1;  // non-temporal stores of the output planes of the streaming multi-field kernels (pfk_set_tuning key 10 = 0: plain stores, A/B:
                    // BM3 0.8416 -> 0.8145 ms per 512^3 step, BM2 2.275 -> 2.265 in one process, profiles/r04/mfd_nt_stores_ab.log)
 void multifd_set_nt(int v) { g_mfd_nt = v; }
-namespace {
-// z-chunks so that the grid holds about 4 workgroups per CU
-template <int PASS>
-void launch_stream(const MultiFD* mf, const double* u, const double* mu, double* out, double dt) {
-  const MfdParams& p = mf->p;
-  constexpr int TY = 4 * PassTraits<PASS>::RPT;
-  const int tiles = (p.nx / SX) * (p.ny / TY);
-  int nchunk = (4 * 256 + tiles - 1) / tiles;
-  if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
-  const int zchunk = (p.nz + nchunk - 1) / nchunk;
-  nchunk = (p.nz + zchunk - 1) / zchunk;
-  if (g_mfd_nt)
-    hipLaunchKernelGGL((mfd_stream_kernel<PASS, true>), dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
-  else
-    hipLaunchKernelGGL((mfd_stream_kernel<PASS, false>), dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
-}
-}  // namespace
-
 // which kernels multifd_step uses on this box: 1 = the streaming LDS-tiled forms, 0 = one thread per cell
 int multifd_streaming(const MultiFD* mf) {
   const MfdParams& p = mf->p;
   return mf->use_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 16 == 0;   // tile heights: 16 (BM3), 8 / 4 (BM2 passes), 8 (one-pass BM2)
 }
+namespace {
+// z-chunks so that the grid holds about 4 workgroups per CU; planes [zlo, zhi) of the box
+template <int PASS>
+void launch_stream(const MultiFD* mf, const double* u, const double* mu, double* out, double dt, int zlo, int zhi) {
+  MfdParams p = mf->p;
+  p.zlo = zlo;
+  p.zhi = zhi;
+  const int nzr = zhi - zlo;
+  constexpr int TY = 4 * PassTraits<PASS>::RPT;
+  const int tiles = (p.nx / SX) * (p.ny / TY);
+  int nchunk = (4 * 256 + tiles - 1) / tiles;
+  if (nchunk > nzr / 8) nchunk = nzr / 8 > 0 ? nzr / 8 : 1;
+  const int zchunk = (nzr + nchunk - 1) / nchunk;
+  nchunk = (nzr + zchunk - 1) / zchunk;
+  if (g_mfd_nt)
+    hipLaunchKernelGGL((mfd_stream_kernel<PASS, true>), dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
+  else
+    hipLaunchKernelGGL((mfd_stream_kernel<PASS, false>), dim3(tiles * nchunk), dim3(256), 0, mf->stream, p, u, mu, out, dt, zchunk);
+}
+
+// one explicit step on planes [zlo, zhi) of the box: current level -> other level (no swap).  The two-pass BM2 forms
+// need mu one plane beyond the range on each side (clamped to the box: a whole-box call wraps inside the kernels).
+void launch_range(MultiFD* mf, double dt, int zlo, int zhi) {
+  if (zhi <= zlo) return;
+  MfdParams p = mf->p;
+  p.zlo = zlo;
+  p.zhi = zhi;
+  const double* u = mf->u[mf->cur];
+  double* un = mf->u[1 - mf->cur];
+  const int64_t plane = (int64_t)p.nx * p.ny;
+  const int mlo = zlo > 0 ? zlo - 1 : 0, mhi = zhi < p.nz ? zhi + 1 : p.nz;   // mu range of the two-pass BM2 forms
+  if (multifd_streaming(mf) != 0) {
+    if (p.model == 2 && mf->bm2_fused) {
+      const int nzr = zhi - zlo;
+      const int tiles = (p.nx / SX) * (p.ny / B2TY);
+      int nchunk = (256 + tiles - 1) / tiles;   // one workgroup per CU
+      if (nchunk > nzr / 8) nchunk = nzr / 8 > 0 ? nzr / 8 : 1;
+      const int zchunk = (nzr + nchunk - 1) / nchunk;
+      nchunk = (nzr + zchunk - 1) / zchunk;
+      if (g_mfd_nt)
+        hipLaunchKernelGGL(bm2_fused_kernel<true>, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
+      else
+        hipLaunchKernelGGL(bm2_fused_kernel<false>, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
+    } else if (p.model == 2) {
+      launch_stream<20>(mf, u, nullptr, mf->mu, dt, mlo, mhi);
+      launch_stream<21>(mf, u, mf->mu, un, dt, zlo, zhi);
+    } else {
+      launch_stream<30>(mf, u, nullptr, un, dt, zlo, zhi);
+    }
+    return;
+  }
+  const unsigned nb = (unsigned)(((int64_t)(zhi - zlo) * plane + 255) / 256);
+  if (p.model == 2) {
+    MfdParams pm = p;
+    pm.zlo = mlo;
+    pm.zhi = mhi;
+    hipLaunchKernelGGL(bm2_mu_kernel, dim3((unsigned)(((int64_t)(mhi - mlo) * plane + 255) / 256)), dim3(256), 0, mf->stream, pm, u,
+                       mf->mu);
+    hipLaunchKernelGGL(bm2_update_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, (const double*)mf->mu, un, dt);
+  } else {
+    hipLaunchKernelGGL(bm3_update_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, un, dt);
+  }
+}
+}  // namespace
 
 int multifd_step(MultiFD* mf, double dt, int nsteps) {
-  const MfdParams& p = mf->p;
-  const unsigned nb = (unsigned)((mf->cells + 255) / 256);
-  const bool stream = multifd_streaming(mf) != 0;
   for (int s = 0; s < nsteps; ++s) {
-    const double* u = mf->u[mf->cur];
-    double* un = mf->u[1 - mf->cur];
-    if (stream) {
-      if (p.model == 2 && mf->bm2_fused) {
-        const int tiles = (p.nx / SX) * (p.ny / B2TY);
-        int nchunk = (256 + tiles - 1) / tiles;   // one workgroup per CU
-        if (nchunk > p.nz / 8) nchunk = p.nz / 8 > 0 ? p.nz / 8 : 1;
-        const int zchunk = (p.nz + nchunk - 1) / nchunk;
-        nchunk = (p.nz + zchunk - 1) / zchunk;
-        if (g_mfd_nt)
-          hipLaunchKernelGGL(bm2_fused_kernel<true>, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
-        else
-          hipLaunchKernelGGL(bm2_fused_kernel<false>, dim3(tiles * nchunk), dim3(B2T), sizeof(Bm2Lds), mf->stream, p, u, un, dt, zchunk);
-      } else if (p.model == 2) {
-        launch_stream<20>(mf, u, nullptr, mf->mu, dt);
-        launch_stream<21>(mf, u, mf->mu, un, dt);
-      } else {
-        launch_stream<30>(mf, u, nullptr, un, dt);
-      }
-    } else if (p.model == 2) {
-      hipLaunchKernelGGL(bm2_mu_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, mf->mu);
-      hipLaunchKernelGGL(bm2_update_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, (const double*)mf->mu, un, dt);
-    } else {
-      hipLaunchKernelGGL(bm3_update_kernel, dim3(nb), dim3(256), 0, mf->stream, p, u, un, dt);
-    }
+    launch_range(mf, dt, 0, mf->p.nz);
     mf->cur ^= 1;
     mf->have_prev = true;
   }
   MF_HIP(hipGetLastError());
   return 0;
+}
+
+// slab mode, one step in two parts (pf_step_begin / pf_step_finish of BM2 / BM3 handles): planes [zlo, zhi) of the ghosted
+// local box, current level -> other level, no swap; then multifd_swap
+int multifd_step_range(MultiFD* mf, double dt, int zlo, int zhi) {
+  if (zlo < 0 || zhi > mf->p.nz) return -1;
+  launch_range(mf, dt, zlo, zhi);
+  MF_HIP(hipGetLastError());
+  return 0;
+}
+void multifd_swap(MultiFD* mf) {
+  mf->cur ^= 1;
+  mf->have_prev = true;
 }
 
 int multifd_rollback(MultiFD* mf) {

@@ -1116,7 +1116,17 @@ int pf_step_begin(pf_handle* h, double dt) {
   if (!h) return PF_ERR_INVALID;
   if (!(dt > 0.0)) return fail(h, PF_ERR_INVALID, "pf_step_begin: need dt > 0");
   if (h->g.ghost == 0) return fail(h, PF_ERR_STATE, "pf_step_begin: not in slab mode");
-  if (h->mf) return fail(h, PF_ERR_STATE, "pf_step_begin: BM2 / BM3 slabs step through pf_step (ghost planes of every field refreshed first)");
+  if (h->mf) {
+    // BM2 / BM3 slabs: the planes whose stencils stay inside the owned planes -- buffer planes [2 g, nz) of the ghosted local
+    // box (a plane reaches g planes up and down: BM2's c through mu 2, BM3 1) -- need no fresh ghosts and run while the
+    // caller's exchange of every field's ghost planes is in flight; pf_step_finish does the two boundary strips
+    if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
+    const int g = h->g.ghost, nz = h->g.nz;
+    if (nz > 2 * g && multifd_step_range(h->mf, dt, 2 * g, nz) != 0) return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+    h->step_open = true;
+    h->open_dt = dt;
+    return PF_OK;
+  }
   if (h->sf && !h->elim)
     return fail(h, PF_ERR_STATE, "pf_step_begin: this mode steps through pf_dist_begin / pf_dist_advance");
   if (h->step_open) return fail(h, PF_ERR_STATE, "pf_step_begin: previous step not finished");
@@ -1149,6 +1159,19 @@ int pf_step_finish(pf_handle* h) {
   if (!h) return PF_ERR_INVALID;
   if (!h->step_open) return fail(h, PF_ERR_STATE, "pf_step_finish without pf_step_begin");
   const int g = h->g.ghost, nz = h->g.nz;
+  if (h->mf) {   // the owned planes next to the ghosts: [g, 2 g) and [nz, nz + g) (ghost planes themselves are not computed)
+    int rc2 = 0;
+    if (nz > 2 * g) {
+      rc2 = multifd_step_range(h->mf, h->open_dt, g, 2 * g);
+      if (rc2 == 0) rc2 = multifd_step_range(h->mf, h->open_dt, nz, nz + g);
+    } else {
+      rc2 = multifd_step_range(h->mf, h->open_dt, g, nz + g);
+    }
+    if (rc2 != 0) return fail(h, PF_ERR_HIP, multifd_error(h->mf));
+    multifd_swap(h->mf);
+    h->step_open = false;
+    return PF_OK;
+  }
   int rc;
   // the strips go to the strip stream when one is set (pf_set_strip_stream); everything else stays on the handle's stream
   struct StreamSwap {

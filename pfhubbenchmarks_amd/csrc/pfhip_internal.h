@@ -194,6 +194,8 @@ double* multifd_field_ptr(MultiFD* mf, int f);  // device pointer of field f of 
 void multifd_touch(MultiFD* mf);                // a field was overwritten: no rollback state
 int multifd_step(MultiFD* mf, double dt, int nsteps);
 int multifd_streaming(const MultiFD* mf);
+int multifd_step_range(MultiFD* mf, double dt, int zlo, int zhi);   // planes [zlo, zhi) of the (ghosted) box, no swap
+void multifd_swap(MultiFD* mf);
 void multifd_set_nt(int v);   // pfk_set_tuning key 10: non-temporal output stores of the streaming kernels (A/B)  // 1: the box tiles and multifd_step uses the streaming LDS-tiled kernels
 int multifd_rollback(MultiFD* mf);
 int multifd_diag_raw(MultiFD* mf, double raw[5]);

@@ -798,6 +798,14 @@ class HipMultiFieldSlabEngine:
         """one explicit step of the whole local box; the ghost planes of every field must be fresh"""
         self._ck(self._lib.pf_step(self._h, float(dt), 1, None))
 
+    def step_begin(self, dt):
+        """the planes of a step that need no ghosts (buffer planes [2 ghost, nz)): runs beside the ghost exchange"""
+        self._ck(self._lib.pf_step_begin(self._h, float(dt)))
+
+    def step_finish(self):
+        """the `ghost` owned planes next to each ghost layer (fresh ghosts needed), then the time levels swap"""
+        self._ck(self._lib.pf_step_finish(self._h))
+
     def diag_local(self):
         out = (C.c_double * 3)()
         self._ck(self._lib.pf_diagnostics_local(self._h, out))
@@ -818,9 +826,10 @@ class HipMultiFieldSlabEngine:
 class MultiFieldSlabSolver:
     """Ring of slabs for the multi-field explicit schemes: per step, refresh `ghost` planes per side of EVERY field of the
     current time level from the two ring neighbours (torch.distributed isend / irecv IN PLACE, one message per field and
-    side: RCCL between GPUs, gloo in the CPU tests), then one step of the local box.  No interior / boundary split: the exchange of nf x 2 x ghost planes is not
-    overlapped with compute (the BM1 / BM6 path does that; here the point is that the models decompose at all -- results are
-    bit-identical to the single box).  `engine` is a HipMultiFieldSlabEngine or anything with its interface (buffers, cur,
+    side: RCCL between GPUs, gloo in the CPU tests) OVERLAPPED with the planes of the step that need no ghosts
+    (engine.step_begin: buffer planes [2 ghost, nz)), then the boundary strips (engine.step_finish) -- the structure of
+    SlabSolver.step; engines without step_begin / slabs of <= 2 ghost planes: exchange, then the whole local box.  Results are
+    bit-identical to the single box.  `engine` is a HipMultiFieldSlabEngine or anything with its interface (buffers, cur,
     nf, ghost, nz, rank_lo, rank_hi, step_local, diag_local, sync, stream_context)."""
 
     def __init__(self, engine, group=None):
@@ -831,7 +840,9 @@ class MultiFieldSlabSolver:
         self.t = 0.0
         self.distributed = dist.is_available() and dist.is_initialized()
 
-    def exchange(self):
+    def _post(self):
+        """start the refresh of every field's ghost planes of the current time level; returns the requests to wait for
+        (empty: a single rank copies its own planes on the engine's stream)"""
         e, dist = self.engine, self.dist
         g, nz = e.ghost, e.nz
         buf = e.buffers[e.cur]
@@ -841,7 +852,7 @@ class MultiFieldSlabSolver:
             with e.stream_context():                       # the rank is its own neighbour on both sides
                 recv_lo.copy_(send_hi)
                 recv_hi.copy_(send_lo)
-            return
+            return []
         if getattr(e, "device", None) is not None and dist.get_backend(self.group) != "nccl":
             e.sync()                                       # gloo reads GPU tensors from the host side
         # in place: the layout is field-major, so the `g` boundary / ghost planes of ONE field are one contiguous block --
@@ -854,13 +865,30 @@ class MultiFieldSlabSolver:
                    [dist.P2POp(dist.isend, send_lo[f], e.rank_lo, self.group, 10 * f + 2) for f in range(nf)] +
                    [dist.P2POp(dist.irecv, recv_lo[f], e.rank_lo, self.group, 10 * f + 1) for f in range(nf)] +
                    [dist.P2POp(dist.irecv, recv_hi[f], e.rank_hi, self.group, 10 * f + 2) for f in range(nf)])
-            for r in dist.batch_isend_irecv(ops):
+            return dist.batch_isend_irecv(ops)
+
+    def exchange(self):
+        """blocking refresh of every field's ghost planes of the current time level"""
+        with self.engine.stream_context():
+            for r in self._post():
                 r.wait()
 
     def step(self, dt, nsteps=1):
+        e = self.engine
+        split = hasattr(e, "step_begin") and e.nz > 2 * e.ghost
         for _ in range(nsteps):
-            self.exchange()
-            self.engine.step_local(dt)
+            if split:
+                # exchange || interior planes, then the boundary strips (the structure of SlabSolver.step): RCCL's transfer runs
+                # on its own stream beside the interior launch; the engine's stream -- not the host -- waits for it
+                with e.stream_context():
+                    reqs = self._post()
+                    e.step_begin(dt)
+                    for r in reqs:
+                        r.wait()
+                    e.step_finish()
+            else:
+                self.exchange()
+                e.step_local(dt)
             self.t += dt
 
     def diagnostics(self):

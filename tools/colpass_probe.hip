@@ -45,11 +45,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ---- reg: the round-3 structure ------------------------------------------------------------------------------------------
 constexpr int W8C = W8 + 32;
+__device__ int g_stagger_us = 0;   // > 0: the second workgroup of every CU (blocks 256..511) starts that much later
 template <int SIGN, bool FFT>
 __global__ __launch_bounds__(512, 4) void reg_kernel(double2* __restrict__ A, const Geom g,
                                                      const double2* __restrict__ twA_g, const double2* __restrict__ twB_g) {
   __shared__ __attribute__((aligned(16))) double2 Lall[8 * W8C];
   __shared__ __attribute__((aligned(16))) double2 TWB[72];
+  if (g_stagger_us > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const long long t0 = __builtin_readcyclecounter();   // s_memtime: 100 MHz
+    while (__builtin_readcyclecounter() - t0 < 100ll * g_stagger_us) __builtin_amdgcn_s_sleep(8);
+  }
   if (threadIdx.x < 64) TWB[(threadIdx.x >> 3) * 9 + (threadIdx.x & 7)] = twB_g[threadIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double2* L = Lall + wave * W8C + 4 * wave;
@@ -233,13 +238,21 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const double bytes = 2.0 * 512.0 * 512.0 * nxh * 16.0;
+  const double bytes = 2.0 * 512.0 * (argc > 2 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 512.0) * nxh * 16.0;
   printf("device %s, %d CUs; bytes per pass (read + write) %.3f GB; dma LDS %zu B\n", prop.name, ncu, bytes / 1e9, lds);
-  for (int axis = 1; axis <= 2; ++axis) {
+  {  // pre-heat (~0.2 s): the chip answers a load step from idle with a reduced clock for ~25 ms
+    Geom g{pitch, (int64_t)n * pitch, n, 33, nxh, 33 * n};
+    CK(hipMemcpy(A, B, elems * sizeof(double2), hipMemcpyDeviceToDevice));
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL((reg_kernel<-1, false>), dim3(g.nitems), dim3(512), 0, 0, A, g, twa, twb);
+    CK(hipDeviceSynchronize());
+  }
+  const int resident = argc > 2 ? atoi(argv[2]) : 0;   // > 0: the y pass on a piece of that many planes only (stays in the
+                                                        // 256 MiB Infinity Cache between repetitions: the chunked regime)
+  for (int axis = 1; axis <= (resident ? 1 : 2); ++axis) {
     Geom g;
     g.nxh = nxh;
     g.nblk = (nxh + 7) / 8;
-    g.nbatch = n;
+    g.nbatch = resident ? resident : n;
     g.nitems = g.nblk * g.nbatch;
     g.rstride = axis == 1 ? pitch : (int64_t)n * pitch;
     g.bstride = axis == 1 ? (int64_t)n * pitch : pitch;
@@ -288,6 +301,38 @@ int main(int argc, char** argv) {
       printf("axis %c %-10s %8.1f us/pass %7.1f GB/s  maxdiff %.3g\n", axis == 1 ? 'y' : 'z', names[form], ms / nrep * 1e3,
              bytes / (ms / nrep * 1e-3) / 1e9, maxdiff);
       fflush(stdout);
+    }
+  }
+  if (resident) {
+    Geom g;
+    g.nxh = nxh;
+    g.nblk = 33;
+    g.nbatch = resident;
+    g.nitems = g.nblk * g.nbatch;
+    g.rstride = pitch;
+    g.bstride = (int64_t)n * pitch;
+    for (int st : {0, 2, 4, 6, 8, 12}) {
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stagger_us), &st, sizeof(int)));
+      for (int form = 0; form < 2; ++form) {
+        auto launch = [&]() {
+          if (form == 0)
+            hipLaunchKernelGGL((reg_kernel<-1, true>), dim3(g.nitems), dim3(512), 0, 0, A, g, twa, twb);
+          else
+            hipLaunchKernelGGL((reg_kernel<-1, false>), dim3(g.nitems), dim3(512), 0, 0, A, g, twa, twb);
+        };
+        CK(hipMemcpy(A, B, elems * sizeof(double2), hipMemcpyDeviceToDevice));
+        for (int w = 0; w < 5; ++w) launch();
+        CK(hipMemcpy(A, B, elems * sizeof(double2), hipMemcpyDeviceToDevice));
+        for (int w = 0; w < 2; ++w) launch();
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < nrep; ++r) launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("stagger %2d us  %-8s %8.1f us/pass %7.1f GB/s\n", st, form ? "copy_reg" : "reg", ms / nrep * 1e3,
+               bytes / (ms / nrep * 1e-3) / 1e9);
+      }
     }
   }
   return 0;
