@@ -93,7 +93,11 @@ typedef struct pf_config {
   int32_t nranks;       /* slab decomposition along z (3-D only; 2-D problems run as replicas); 1 = whole domain.
                            PERIODIC: a ring of slabs.  MIRROR (FD scheme, BM1): a LINE of slabs over the n[2] physical
                            planes -- x and y stay even-extended, z is not: the first / last rank own the walls and
-                           mirror their own planes into the outer ghost layers (>= 3 planes per rank). */
+                           mirror their own planes into the outer ghost layers (>= 3 planes per rank).
+                           MIRROR with the slab-FFT modes (PF_SCHEME_SPECTRAL_SI with BM1; PF_SCHEME_FD_EXPLICIT with BM6 = the
+                           reference's Dirichlet-x / no-flux Poisson problem, dolfin/bench6.py:77-90): the box stays on its even
+                           extension along z too, the slabs form a RING over the 2 (n[2] - 1) lattice planes and the periodic
+                           slab FFT transforms the extension (BM6: of the odd-in-x right-hand side). */
   int32_t rank;
   int32_t force_slab;   /* 1: use the ghost-plane (slab) code path even with nranks == 1 -- the rank is then its own ring
                            neighbour; lets a single GPU exercise the exact multi-GPU path (tests) */

@@ -71,7 +71,10 @@ int resolve(const pf_config* cfg, Geometry* g, std::string* err) {
     }
     // the spectral scheme with mirror bc keeps the even extension along z too (like the single-GPU path): the slabs form a
     // ring over the 2 (nz - 1) lattice planes and the slab FFT sees a periodic box
-    const bool fft_mirror = g->mirror && cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->model == PF_MODEL_BM1;
+    // ... and so does BM6 with the FD scheme (the reference's Dirichlet-x / no-flux Poisson problem, bench6.py:77-90): the slab
+    // FFT then transforms the odd-in-x / even-in-y,z extension of the right-hand side on that periodic lattice
+    const bool fft_mirror = g->mirror && ((cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->model == PF_MODEL_BM1) ||
+                                          (cfg->scheme == PF_SCHEME_FD_EXPLICIT && cfg->model == PF_MODEL_BM6));
     if (g->mirror && !fft_mirror) {
       // a line of slabs over the PHYSICAL planes: no even extension along z, the two wall ranks mirror their own planes
       // into the ghost layers (launch_reflect_ghosts) instead of receiving them
@@ -139,6 +142,7 @@ struct pf_handle {
   double cbar = 0.0;       // lattice mean of c (conserved); valid when cbar_valid
   bool cbar_valid = false;
   double* phi = nullptr;   // BM6: phi on the lattice, consistent with c[cur] when phi_valid
+  double* rhs_slab = nullptr;  // BM6, slab mode, mirror bc: right-hand side of the Dirichlet-x Poisson problem on this rank's planes
   bool phi_valid = false;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -539,8 +543,9 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
                 "PF_SCHEME_FEM_BE: 2-D, PF_BC_MIRROR (natural no-flux), square mesh, one GPU");
   const bool slab_fft = (cfg->nranks > 1 || cfg->force_slab == 1) &&
                         (cfg->scheme == PF_SCHEME_SPECTRAL_SI || cfg->model == PF_MODEL_BM6);
-  if (slab_fft && g.mirror && !(cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->model == PF_MODEL_BM1))
-    return fail(nullptr, PF_ERR_UNSUPPORTED, "mirror bc in slab mode: BM1 only (FD scheme: line of slabs; spectral: ring over the even extension)");
+  if (slab_fft && g.mirror && !(cfg->scheme == PF_SCHEME_SPECTRAL_SI && cfg->model == PF_MODEL_BM1) &&
+      !(cfg->scheme == PF_SCHEME_FD_EXPLICIT && cfg->model == PF_MODEL_BM6))
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "mirror bc in the slab FFT modes: BM1 with the spectral scheme or BM6 with the FD scheme (ring over the even extension)");
   if (slab_fft && slabfft_buffer_doubles(g.nx, g.ny, g.nzg, cfg->nranks) < 0)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "slab FFT modes need ny and nz divisible by nranks");
   if ((cfg->flags & PF_FLAG_BM6_ELIMINATE_PHI) &&
@@ -651,6 +656,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
       h->own_phi = true;
     }
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
+    if (g.mirror)   // reference boundary conditions: this rank's planes of the odd-in-x right-hand side
+      PF_HIP_C(hipMalloc(&h->rhs_slab, sizeof(double) * (size_t)g.plane * g.nz));
   } else if (cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_SPECTRAL_SI) {
     if (!h->phi) {
       PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
@@ -726,6 +733,7 @@ int pf_destroy(pf_handle* h) {
   if (h->fb) fembe_destroy(h->fb);
   if (h->mf) multifd_destroy(h->mf);
   if (h->phi && h->own_phi) (void)hipFree(h->phi);
+  if (h->rhs_slab) (void)hipFree(h->rhs_slab);
   if (h->sf) slabfft_destroy(h->sf);
   if (h->partials) (void)hipFree(h->partials);
   if (h->out6_dev) (void)hipFree(h->out6_dev);
@@ -1330,17 +1338,29 @@ int pf_dist_advance(pf_handle* h, pf_dist_request* req) {
     switch (h->d_phase) {
       case 0:
         if (h->phi_valid && h->d_op == PF_DIST_OP_REFRESH) return done();
-        SF_CALL(slabfft_forward_local(h->sf, owned));
+        if (g.mirror) {
+          // the reference's boundary conditions (phi = 0 / sin(y/7) on x = 0 / Lx, no flux elsewhere): this rank's planes of the
+          // odd-in-x right-hand side, Dirichlet data moved to node N - 1 -- the periodic slab FFT then IS the sine (x) x cosine
+          // (y, z) transform of the physical problem
+          if (poisson_dirichlet_rhs_planes(owned, h->rhs_slab, g.nx, g.ny, g.nz, g.np[0], g.np[1], c.h, c.k / c.eps_r, h->stream) != 0)
+            return fail(h, PF_ERR_HIP, "Dirichlet right-hand side kernel failed");
+          SF_CALL(slabfft_forward_local(h->sf, h->rhs_slab));
+        } else {
+          SF_CALL(slabfft_forward_local(h->sf, owned));
+        }
         h->d_phase = 1;
         return a2a(0);
       case 1:
         SF_CALL(slabfft_z(h->sf, 0));
-        SF_CALL(slabfft_poisson_on_T(h->sf, c.k / c.eps_r));
+        SF_CALL(slabfft_poisson_on_T(h->sf, g.mirror ? -1.0 : c.k / c.eps_r));   // (mirror: the right-hand side is already scaled)
         SF_CALL(slabfft_z(h->sf, 1));
         h->d_phase = 2;
         return a2a(1);
       case 2:
         SF_CALL(slabfft_inverse_local(h->sf, h->phi + (int64_t)g.ghost * g.plane));
+        if (g.mirror &&   // odd-in-x solution -> the even-in-x extension the Cahn-Hilliard kernel reads, boundary values written
+            poisson_dirichlet_fixup_planes(h->phi + (int64_t)g.ghost * g.plane, g.nx, g.ny, g.nz, g.np[0], g.np[1], c.h, h->stream) != 0)
+          return fail(h, PF_ERR_HIP, "Dirichlet fix-up kernel failed");
         h->d_phase = 3;
         req->kind = PF_DIST_HALO;
         req->n_halo = 2;

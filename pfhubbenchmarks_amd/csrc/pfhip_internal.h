@@ -132,7 +132,10 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
 void poisson_destroy(Poisson* po);
 int poisson_solve(Poisson* po, const double* c, double* phi, hipStream_t stream);
 const char* poisson_error(const Poisson* po);
-const char* poisson_path(const Poisson* po);  // which transform kernels the solve runs
+const char* poisson_path(const Poisson* po);
+int poisson_dirichlet_rhs_planes(const double* c, double* r, int nx, int ny, int nzl, int npx, int npy, double h, double k_over_eps,
+                                 hipStream_t stream);   // slab mode: the reference's BCs on a slab of lattice planes
+int poisson_dirichlet_fixup_planes(double* phi, int nx, int ny, int nzl, int npx, int npy, double h, hipStream_t stream);  // which transform kernels the solve runs
 
 // slab-decomposed FFT building blocks (slabfft.hip)
 struct SlabFFT;

@@ -170,6 +170,37 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
   return rc;
 }
 
+// The lattice kernels of the reference's boundary conditions on a SLAB of `nzl` lattice planes (slab mode: the periodic slab
+// FFT transforms the odd-in-x / even-in-y,z extension; the boundary function depends on y only, so a slab needs no z index):
+// r <- odd-in-x right-hand side of c (even extension), Dirichlet data of x = Lx moved to node N - 1; and, after the solve,
+// phi <- even-in-x extension with the Dirichlet values written on x = 0, Lx.  dolfin/bench6.py:77-90, pfbase.py:410-421.
+int poisson_dirichlet_rhs_planes(const double* c, double* r, int nx, int ny, int nzl, int npx, int npy, double h,
+                                 double k_over_eps, hipStream_t stream) {
+  PoArgs a{};
+  a.nx = nx;
+  a.ny = ny;
+  a.nz = nzl;
+  a.nxh = nx / 2 + 1;
+  a.npx = npx;
+  a.npy = npy;
+  a.h = h;
+  a.k_over_eps = k_over_eps;
+  a.inv_h2 = 1.0 / (h * h);
+  hipLaunchKernelGGL(rhs_dirichlet_kernel, dim3(grid_for_p((int64_t)nx * ny * nzl)), dim3(256), 0, stream, c, r, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int poisson_dirichlet_fixup_planes(double* phi, int nx, int ny, int nzl, int npx, int npy, double h, hipStream_t stream) {
+  PoArgs a{};
+  a.nx = nx;
+  a.ny = ny;
+  a.nz = nzl;
+  a.npx = npx;
+  a.npy = npy;
+  a.h = h;
+  hipLaunchKernelGGL(fixup_dirichlet_kernel, dim3(grid_for_p((int64_t)nx * ny * nzl)), dim3(256), 0, stream, phi, a);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 void poisson_destroy(Poisson* po) {
   if (!po) return;
   fftplan_destroy(po->fwd);

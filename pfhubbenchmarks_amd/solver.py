@@ -910,7 +910,8 @@ class HipFFTSlabEngine(HipSlabEngine):
     buffer for BM6) as torch tensors so that torch.distributed can run the exchanges the library asks for."""
 
     def __init__(self, n, h, nranks, rank, device, scheme="fd", model="bm1", eliminate_phi=False, bc="periodic", **params):
-        """bc="mirror" (spectral scheme, BM1): the reference's no-flux box on its even extension along all three axes, as on
+        """bc="mirror" (spectral scheme with BM1; FD scheme with BM6 = the reference's boundary conditions, phi = 0 / sin(y/7) on
+        x = 0 / Lx, dolfin/bench6.py:77-90): the reference's no-flux box on its even extension along all three axes, as on
         one GPU -- the slabs form a ring over the 2 (nz - 1) lattice planes; n = nodes of the physical box; set_global takes
         the whole physical field, get_local returns this rank's lattice planes (physical x, y), gather_field the physical box"""
         import torch

@@ -1,5 +1,5 @@
 """Worker of tests/test_dist_gloo.py (FFT slab modes): one gloo rank running FFTSlabSolver over the numpy mirror of the
-library's distributed state machine.  Usage: python tests/dist_fft_worker.py <out> <mode>   mode: spectral | bm6 | bm6_elim"""
+library's distributed state machine.  Usage: python tests/dist_fft_worker.py <out> <mode>   mode: spectral | spectral_mirror | bm6 | bm6_elim | bm6_mirror"""
 import os
 import sys
 
@@ -18,9 +18,10 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n = (16, 12, 8) if world <= 4 else (16, 2 * world, 2 * world)    # slab FFT: ny and nz divisible by the ranks
-    mirror = mode == "spectral_mirror"
+    mirror = mode in ("spectral_mirror", "bm6_mirror")
     eng = OracleFFTSlabEngine(n, 1.0, world, rank, scheme="spectral" if mode.startswith("spectral") else "fd",
-                              model="bm6" if mode.startswith("bm6") else "bm1", eliminate_phi=mode == "bm6_elim")
+                              model="bm6" if mode.startswith("bm6") else "bm1", eliminate_phi=mode == "bm6_elim",
+                              dirichlet=(n[0] // 2 + 1, n[1] // 2 + 1) if mode == "bm6_mirror" else None)
     rng = np.random.default_rng(4)
     if mirror:
         # the no-flux box of (9, 7, 5) nodes on its even extension = the 16 x 12 x 8 lattice: the slabs form a ring over the
@@ -36,7 +37,7 @@ def main():
     if mirror:                                                     # (what gather_field looks at)
         eng.bc, eng.nz_physical = "mirror", phys.shape[0]
     s = FFTSlabSolver(eng)
-    dt = 1e-2 if mode == "spectral" else 1e-3
+    dt = 1e-2 if mode.startswith("spectral") else 1e-3
     d0 = s.diagnostics()
     s.step(dt, 3)
     d1 = s.diagnostics()

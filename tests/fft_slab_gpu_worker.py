@@ -20,7 +20,8 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scheme, model, dt, elim = {"spectral": ("spectral", "bm1", 1e-2, False), "bm6": ("fd", "bm6", 1e-3, False),
-                               "bm6_elim": ("fd", "bm6", 1e-3, True), "spectral_mirror": ("spectral", "bm1", 1e-2, False)}[mode]
+                               "bm6_elim": ("fd", "bm6", 1e-3, True), "spectral_mirror": ("spectral", "bm1", 1e-2, False),
+                               "bm6_mirror": ("fd", "bm6", 1e-3, False)}[mode]       # the reference's BCs (bench6.py:77-90)
     bc = "mirror" if mode.endswith("mirror") else "periodic"
     n = (65, 17, 13) if bc == "mirror" else (128, 32, 24)      # mirror: nodes of the no-flux box -> lattice 128 x 32 x 24
     rng = np.random.default_rng(19)

@@ -187,8 +187,12 @@ class OracleFFTSlabEngine(OracleSlabEngine):
     csrc/pfhip_api.hip) restated with numpy FFTs, so FFTSlabSolver's collectives run under gloo without a GPU."""
 
     def __init__(self, n, h, nranks, rank, scheme="fd", model="bm1", k=0.09, eps=90.0, kappa=2.0, M=5.0,
-                 eliminate_phi=False):
+                 eliminate_phi=False, dirichlet=None):
+        """dirichlet = (npx, npy): BM6 with the reference's boundary conditions (bench6.py:77-90) -- n is then the LATTICE of
+        the even extension (2 (np - 1) points per axis), the slabs a ring over its planes, and the Poisson solve transforms
+        the odd-in-x right-hand side (csrc/pfhip_api.hip pf_dist_advance, g.mirror branches)"""
         super().__init__(n, h, nranks, rank)
+        self.dirichlet = dirichlet
         self.eliminate_phi = eliminate_phi
         self.cbar = None
         self.P, self.rank = nranks, rank
@@ -286,7 +290,18 @@ class OracleFFTSlabEngine(OracleSlabEngine):
             if self.phase == 0:
                 if self.phi_valid and self.op == 2:
                     return self._done()
-                self._fwd_local(self._owned(cur))
+                if self.dirichlet:      # rhs_dirichlet_kernel on this rank's lattice planes
+                    npx, npy = self.dirichlet
+                    N = npx - 1
+                    x, y = np.arange(nx), np.arange(ny)
+                    xr = np.where(x <= N, x, 2 * N - x)
+                    yr = np.where(y < npy, y, 2 * (npy - 1) - y)
+                    r = -(self.k / self.eps) * self._owned(cur).copy()
+                    r[..., xr == N - 1] -= (np.sin(yr * h / 7.0) / (h * h))[:, None]
+                    r = r * np.where((xr == 0) | (xr == N), 0.0, np.where(x > N, -1.0, 1.0))
+                    self._fwd_local(r)
+                else:
+                    self._fwd_local(self._owned(cur))
                 self.phase = 1
                 return ("alltoall", self.a2a[1], self.a2a[0])
             if self.phase == 1:
@@ -295,12 +310,21 @@ class OracleFFTSlabEngine(OracleSlabEngine):
                 lam = ((2 * np.cos(2 * np.pi * kx / nx) - 2) + (2 * np.cos(2 * np.pi * ky / ny) - 2)
                        + (2 * np.cos(2 * np.pi * kz / nz) - 2)) / (h * h)
                 with np.errstate(divide="ignore", invalid="ignore"):
-                    ph = np.where(lam != 0.0, -(self.k / self.eps) * ch / lam, 0.0)
+                    ph = np.where(lam != 0.0, (1.0 if self.dirichlet else -(self.k / self.eps)) * ch / lam, 0.0)
                 self._B()[...] = np.fft.ifft(ph, axis=0)
                 self.phase = 2
                 return ("alltoall", self.a2a[0], self.a2a[1])
             if self.phase == 2:
                 self._inv_local(self._owned(self.phi))
+                if self.dirichlet:      # fixup_dirichlet_kernel: even-in-x extension with the boundary values written
+                    npx, npy = self.dirichlet
+                    N = npx - 1
+                    x, y = np.arange(nx), np.arange(ny)
+                    yr = np.where(y < npy, y, 2 * (npy - 1) - y)
+                    p = self._owned(self.phi)
+                    p *= np.where(x > N, -1.0, 1.0)
+                    p[..., x == 0] = 0.0
+                    p[..., x == N] = np.sin(yr * h / 7.0)[:, None]
                 self.phase = 3
                 return ("halo", [cur, self.phi])
             self.phi_valid = True
@@ -343,6 +367,8 @@ class OracleFFTSlabEngine(OracleSlabEngine):
             return [vol * (f.sum() + 0.5 * self.kappa * g), vol * c.sum(), 0.0]
         phi = self.phi.numpy() if self.model == "bm6" else None
         F, C, E = ch_fd.diagnostics(cur, h=self.h, dim=3, ghost=2, zwrap=0, phi=phi, k=self.k)
+        if self.dirichlet:      # sums over the even extension along all three axes: the physical box is 1/8 of it
+            F, C, E = F / 8.0, C / 8.0, E / 8.0
         return [F, C, E]
 
 

@@ -75,7 +75,7 @@ def test_mirror_bc_line_of_slabs_matches_even_extension(world, halo, tmp_path, o
     np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
 
 
-@pytest.mark.parametrize("mode,world", [("spectral", 2), ("bm6", 2), ("bm6_elim", 2), ("spectral", 8), ("bm6", 8), ("spectral_mirror", 2), ("spectral_mirror", 4)])
+@pytest.mark.parametrize("mode,world", [("spectral", 2), ("bm6", 2), ("bm6_elim", 2), ("spectral", 8), ("bm6", 8), ("spectral_mirror", 2), ("spectral_mirror", 4), ("bm6_mirror", 2), ("bm6_mirror", 4)])
 def test_fft_slab_solver_matches_single_domain(mode, world, tmp_path, orc):
     """the all-to-all / halo orchestration of FFTSlabSolver (world size 2, and 8 = the driver's node, gloo) against the
     single-domain oracles"""
@@ -100,7 +100,9 @@ def test_fft_slab_solver_matches_single_domain(mode, world, tmp_path, orc):
         o.step(dt, 1)
         ref = o.c
     else:
-        o = bm6_fd.BM6FD(res["full"], 1.0, eliminate_phi=mode == "bm6_elim")
+        full = res["full"]
+        mn = (full.shape[2] // 2 + 1, full.shape[1] // 2 + 1) if mode == "bm6_mirror" else None    # reference BCs (bench6.py:77-90)
+        o = bm6_fd.BM6FD(full, 1.0, mirror_nodes=mn, eliminate_phi=mode == "bm6_elim")
         F0, C0, _ = o.diagnostics()
         o.step(dt, 3)
         F1, C1, _ = o.diagnostics()
@@ -108,7 +110,7 @@ def test_fft_slab_solver_matches_single_domain(mode, world, tmp_path, orc):
         ref = o.c
     np.testing.assert_allclose(res["d0"][:2], [F0, C0], rtol=1e-11)
     np.testing.assert_allclose(res["d1"][:2], [F1, C1], rtol=1e-11)
-    if mode == "spectral_mirror":     # gather_field keeps the physical planes of the ring over the even extension
+    if mode in ("spectral_mirror", "bm6_mirror"):     # gather_field keeps the physical planes of the ring over the even extension
         nzp = ref.shape[0] // 2 + 1
         assert res["field"].shape[0] == nzp
         ref = ref[:nzp]

@@ -1486,6 +1486,60 @@ def _lockstep(engs, op, dt=0.0):
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("nodes,P", [((9, 7, 5), 2), ((9, 7, 5), 4), ((65, 65, 65), 2), ((33, 9, 17), 4), ((9, 7, 5), 1)])
+def test_bm6_reference_boundary_conditions_on_slabs(lib, nodes, P):
+    """BM6 with the REFERENCE's boundary conditions across ranks (dolfin/bench6.py:77-90 under `mpirun`, README.md:22: phi = 0 /
+    sin(y/7) on x = 0 / Lx, no flux elsewhere): HipFFTSlabEngine(bc="mirror", model="bm6") -- the no-flux box lives on its even
+    extension along all three axes, the slabs form a ring over the 2 (nz - 1) lattice planes, and the periodic slab FFT
+    transforms the odd-in-x / even-in-y,z extension of the right-hand side (= the sine x cosine x cosine transform of the
+    physical problem; Dirichlet data moved to node N - 1, boundary values written back after the solve).  P rank handles on
+    the one GPU, collectives emulated by copies, against (a) the single-GPU solver with the same boundary conditions (its
+    Poisson solve runs the sine / cosine passes on the PHYSICAL nodes: a different route to the same discrete problem) and
+    (b) the numpy oracle.  (65, 65, 65): 128^3 lattice on the hand-written passes; the others: rocFFT."""
+    from oracle import bm6_fd
+    from oracle.multi_fd import even_extend
+    from pfhubbenchmarks_amd.solver import HipFFTSlabEngine
+    npx, npy, npz = nodes
+    rng = np.random.default_rng(sum(nodes) + P)
+    phys = 0.5 + 0.05 * rng.standard_normal((npz, npy, npx))
+    h, dt, nsteps = 1.0, 1e-3, 3
+    engs = [HipFFTSlabEngine(nodes, h, P, r, 0, scheme="fd", model="bm6", bc="mirror") for r in range(P)]
+    try:
+        for e in engs:
+            e.set_global(phys)
+        _lockstep(engs, L.PF_DIST_OP_REFRESH)
+        d0 = np.sum([e.diag_local() for e in engs], 0)
+        for _ in range(nsteps):
+            _lockstep(engs, L.PF_DIST_OP_STEP, dt)
+        _lockstep(engs, L.PF_DIST_OP_REFRESH)
+        d1 = np.sum([e.diag_local() for e in engs], 0)
+        lat = np.concatenate([e.get_local() for e in engs], 0)           # this ring's lattice planes, physical x, y nodes
+        phi_lat = np.concatenate([e.phi[2:2 + e.nz].cpu().numpy() for e in engs], 0)
+    finally:
+        for e in engs:
+            e.close()
+    assert lat.shape == (2 * (npz - 1), npy, npx)
+    # (a) the single-GPU solver
+    with PhaseFieldSolver(dim=3, n=nodes, h=h, bc="mirror", model="bm6") as s:
+        s.set_c(phys)
+        w0 = np.array(s.diagnostics())
+        s.step(dt, nsteps)
+        w1 = np.array(s.diagnostics())
+        whole, whole_phi = s.get_c(), s.get_phi()
+    assert np.abs(lat[:npz] - whole).max() <= 1e-12
+    assert np.abs(lat[npz:] - whole[-2:0:-1]).max() <= 1e-12              # the mirrored planes of the ring
+    np.testing.assert_allclose(d0, w0, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(d1, w1, rtol=1e-11, atol=1e-13)
+    # (b) the oracle on the whole lattice
+    full = even_extend(phys)
+    full = np.concatenate([full, full[-2:0:-1]], axis=0)
+    o = bm6_fd.BM6FD(full, h, mirror_nodes=(npx, npy))
+    o.step(dt, nsteps)
+    assert np.abs(lat - o.c[:, :npy, :npx]).max() <= 1e-12
+    assert np.abs(phi_lat - o.phi()).max() <= 1e-11 and np.abs(whole_phi - o.phi()[:npz, :npy, :npx]).max() <= 1e-11
+    assert np.all(phi_lat[:, :, 0] == 0.0)                                # the Dirichlet plane x = 0, exactly
+
+
 @pytest.mark.parametrize("n,P,chunk", [((64, 24, 16), 2, None), ((128, 128, 128), 2, None), ((128, 256, 512), 4, None),
                                        ((512, 128, 128), 1, None), ((128, 256, 512), 4, "24,2"), ((128, 128, 128), 2, "7,3")])
 @pytest.mark.parametrize("mode", ["spectral", "bm6"])
@@ -1661,7 +1715,7 @@ def test_multi_process_slabs_on_one_gpu_with_the_peer_copy_transport(lib, orc, w
     np.testing.assert_array_equal(res["field"], e[:nz, :ny, :nx])
 
 
-@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim", "spectral_mirror"])
+@pytest.mark.parametrize("mode", ["spectral", "bm6", "bm6_elim", "spectral_mirror", "bm6_mirror"])
 def test_multi_process_fft_slab_modes_on_one_gpu(lib, mode):
     """the slab-FFT modes with TWO ranks as separate processes sharing the GPU: real engines, the library's request
     protocol (pf_dist_begin / pf_dist_advance) served by gloo collectives on the GPU tensors (all_to_all_single + ghost
