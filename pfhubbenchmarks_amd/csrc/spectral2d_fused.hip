@@ -1338,6 +1338,7 @@ struct Fused2D {
   // z-chunked groups of passes (run_chunked): planes per chunk (0 = whole box, one launch per pass) and the side streams
   // the chunks are dealt to
   int chunk = 0, nside = 0;
+  int chunk_min_planes = 0;   // calls over fewer planes run whole (default policy; 0 when PFHIP_FFT3D_CHUNK forces the chunking)
   char desc[256] = {0};  // fused2d_describe (a plain array: run_chunked copies the struct per chunk)
   hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1488,20 +1489,30 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   if (f->cube512) {
     // Passes that only couple points of one z-plane (x rows, y columns) run chunk of planes by chunk of planes, one pass
     // after the other on the same chunk (run_chunked): a chunk that fits the 256 MiB Infinity Cache is still on the die
-    // when the next pass reads it.  Default: chunks of ~64 MiB of half spectrum dealt to two streams (the tail of one
-    // chunk's launch overlaps the head of the next chunk's); a box whose whole array is below 96 MiB is not chunked.
+    // when the next pass reads it.  Default (where chunking is on): chunks of ~64 MiB of half spectrum dealt to two streams
+    // (the tail of one chunk's launch overlaps the head of the next chunk's).
     // PFHIP_FFT3D_CHUNK="planes[,streams]" overrides (0 = whole box per launch): measured at 512^3 in one process,
     // profiles/r04/spectral_512c_chunk_ab.log.
     const double plane_mb = (double)ny * a.pitch * sizeof(double2) / (1024.0 * 1024.0);
     int ns = 2;
-    if (plane_mb * nz > 96.0) {
+    // ... by default only where it was measured to pay: 512 x 512 planes (the one-wave radix-8 kernels, which run near the
+    // copy rate of their access patterns, so the bytes they move are what counts) and a pass over at least 768 MiB of half
+    // spectrum (run_chunked looks at the planes of the call: a rank's 64 planes of a 512^3 box are not chunked).
+    // Measured in one process (profiles/r04/spectral_chunk_sizes.log): 512^3 2.30-2.54 -> 2.05-2.12 ms; 512 x 512 x 256
+    // 1.138 -> 1.151, x 128 0.554 -> 0.598 (most of such a box is on the die between whole-box passes anyway, the chunk
+    // launches only add tails); 256^3 0.341 -> 0.398; 1024^3 25.7 -> 26.6 (radix-2^2 kernels: LDS-bound, not memory-bound).
+    if (nx == 512 && ny == 512 && f->row512 && f->col512) {
       f->chunk = (int)(64.0 / plane_mb + 0.5);
       if (f->chunk < 2) f->chunk = 2;
+      f->chunk_min_planes = (int)(768.0 / plane_mb);
     }
     if (const char* e = getenv("PFHIP_FFT3D_CHUNK")) {
       int c = 0, n2 = ns;
       const int got = sscanf(e, "%d,%d", &c, &n2);
-      if (got >= 1 && c >= 0) f->chunk = c;
+      if (got >= 1 && c >= 0) {
+        f->chunk = c;
+        f->chunk_min_planes = 0;   // forced: every call with more planes than a chunk
+      }
       if (got >= 2 && n2 >= 0) ns = n2;
     }
     if (f->chunk >= nz) f->chunk = 0;
@@ -1541,7 +1552,8 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     if (nz > 1) {
       d += ", z " + kind(nz, nz == 512 && f->col512);
       d += f->chunk > 0 ? "; plane-local passes in chunks of " + std::to_string(f->chunk) + " planes on " +
-                              std::to_string(f->nside > 0 ? f->nside : 1) + " stream(s)"
+                              std::to_string(f->nside > 0 ? f->nside : 1) + " stream(s)" +
+                              (f->chunk_min_planes > 0 ? " (calls over >= " + std::to_string(f->chunk_min_planes) + " planes)" : "")
                         : "; whole box per launch";
     }
     snprintf(f->desc, sizeof f->desc, "%s", d.c_str());
@@ -1762,7 +1774,7 @@ void launch_col3(const Fused2D* f, const F2Args& a, double2* A, double2* chat, d
 // copies with these access patterns; the step: 2.30-2.54 -> 2.05 ms, profiles/r04/spectral_512c_chunk_ab.log).
 template <class Body>
 int run_chunked(const Fused2D* f, const F2Args& a, Body body) {
-  if (!(f->chunk > 0 && f->chunk < a.nz)) {
+  if (!(f->chunk > 0 && f->chunk < a.nz && a.nz >= f->chunk_min_planes)) {
     body(*f, a, 0);
     return 0;
   }
@@ -1771,14 +1783,16 @@ int run_chunked(const Fused2D* f, const F2Args& a, Body body) {
     for (int k = 0; k < f->nside; ++k)
       if (hipStreamWaitEvent(f->side[k], f->ev_fork, 0) != hipSuccess) return -3;
   }
-  int k = 0;
-  for (int z0 = 0; z0 < a.nz; z0 += f->chunk, ++k) {
+  // equal chunks (the remainder spread one plane each): 512 planes at 31 -> 17 chunks of 31 / 30; a rank's 64 planes -> 22, 21, 21
+  const int nchunks = (a.nz + f->chunk - 1) / f->chunk, base = a.nz / nchunks, rem = a.nz % nchunks;
+  for (int k = 0, z0 = 0; k < nchunks; ++k) {
     F2Args ac = a;
-    ac.nz = a.nz - z0 < f->chunk ? a.nz - z0 : f->chunk;
+    ac.nz = base + (k < rem ? 1 : 0);
     Fused2D fc = *f;  // launch descriptor only: the launchers read geometry, tables and the stream from it
     if (f->nside > 0) fc.stream = f->side[k % f->nside];
     body(fc, ac, z0);
     f->qepoch = fc.qepoch;
+    z0 += ac.nz;
   }
   for (int j = 0; j < f->nside; ++j)
     if (hipEventRecord(f->ev_join[j], f->side[j]) != hipSuccess || hipStreamWaitEvent(f->stream, f->ev_join[j], 0) != hipSuccess)

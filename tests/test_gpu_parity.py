@@ -1789,6 +1789,7 @@ def test_multi_process_slabs_unequal_planes_per_rank(lib, orc, tmp_path):
     (4, "bm1_fd_1024c", [1024, 1024, 1024], "strong"),     # BASELINE.json config 4: 1024^3 split into z-slabs
     (2, "bm6_fd_256c", [256, 256, 512], "weak"),           # BM6: slab-FFT Poisson (2 all-to-alls) + ghost exchange of c, phi
     (2, "bm1_spectral_512c", [512, 512, 512], "strong"),   # FFT modes at N > 1: ONE 512^3 box over the ranks (BASELINE config 5's form)
+    (2, "bm3_fd_512c", [512, 512, 1024], "weak"),          # multi-field slabs: in-place ghost exchange overlapped with the interior planes
 ])
 def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scaling):
     """The driver's N > 1 command line (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) on the
@@ -1819,7 +1820,9 @@ def test_bench_multi_rank_launch_contract_rehearsal(world, workload, grid, scali
     assert d["config"]["grid"] == grid and "REHEARSAL" in d["config"]["parallelism"]
     cells = grid[0] * grid[1] * grid[2]
     assert abs(d["value"] - cells * 4 / (d["ms_per_step"] * 1e-3 * 4)) <= 1e-6 * d["value"]
-    assert d["check"]["C_rel_drift"] < 1e-12 and d["check"]["F_after"] < d["check"]["F_before"]
+    if not workload.startswith("bm3"):                      # (BM3's second column is the solid fraction: it grows)
+        assert d["check"]["C_rel_drift"] < 1e-12
+    assert d["check"]["F_after"] < d["check"]["F_before"]
     assert "cpu_baseline" not in d and d["roofline"]["traffic"] is None
     assert d["repeats"] == 2 and len(d["block_ms_per_step"]) == 2 and d["preheat_steps"] >= 5
     if workload.startswith("bm1_spectral") or workload.startswith("bm6"):      # the line says which transform path ran

@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("forms", nargs="+")
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--model", default="bm1")
-ap.add_argument("--n", type=int, default=512)
+ap.add_argument("--n", default="512", help="points per axis: N or NX,NY,NZ")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--check", action="store_true", help="compare the field after 5 steps with the first form's")
 a = ap.parse_args()
@@ -33,7 +33,9 @@ for rnd in range(a.rounds):
         os.environ.setdefault("PFHIP_SPEC_PROBE", "0")
         os.environ.update(env)
         scheme = "spectral" if a.model == "bm1" else "fd"
-        with PhaseFieldSolver(dim=3, n=a.n, h=1.0, scheme=scheme, model=a.model) as s:
+        nn = tuple(int(v) for v in a.n.split(","))
+        nn = nn[0] if len(nn) == 1 else nn
+        with PhaseFieldSolver(dim=3, n=nn, h=1.0, scheme=scheme, model=a.model) as s:
             (s.set_ic_bm1 if a.model == "bm1" else s.set_ic_bm6)()
             dt = 1e-2 if a.model == "bm1" else 5e-4
             diff = None
