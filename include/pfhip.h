@@ -336,6 +336,16 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
  * target workgroup count; key 10 = 0 / 1: plain / non-temporal (default) stores of the output planes of the BM2 / BM3 streaming kernels */
 int pfk_set_tuning(int key, int value);
 
+/* Device memory with the placement policy the library uses for its own arrays (csrc/device_alloc.hip; no counterpart in the
+ * reference, which leaves allocation to PETSc / CuArrays).  On MI355X the bandwidth of a kernel depends on where its arrays
+ * lie physically, and hipMalloc does not give the same physical layout twice; arrays of 32 MiB and more are therefore
+ * physically contiguous allocations (hipExtMallocWithFlags, hipDeviceMallocContiguous), which gives every handle of every
+ * process the same step time.  A caller that hands its own buffers to pf_create (pf_config.ext_c / ext_phi) gets the same
+ * behaviour by allocating them here.  PFHIP_ALLOC=plain|scatter[:KiB] select the other measured policies (A/B only).
+ * pf_device_free takes pointers of pf_device_malloc only; it synchronises the device like hipFree. */
+int pf_device_malloc(void** dev_ptr, size_t bytes);
+int pf_device_free(void* dev_ptr);
+
 /* Device copy dst[i] = src[i], n doubles, 16-byte accesses: the measured HBM ceiling for a 1-read + 1-write stream
  * (8 B + 8 B per element -- the algorithmic traffic of the fused CH step).  bench.py times it beside the stencil so
  * roofline.frac (against the 8 TB/s datasheet peak, SURVEY 8d: "confirm with a device memcpy/triad on the box") can

@@ -510,9 +510,9 @@ hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* 
   int* flag = nullptr;
   double* slots = nullptr;
   hipError_t e;
-  if ((e = hipMalloc(&counter, sizeof(unsigned))) != hipSuccess) return e;
-  if ((e = hipMalloc(&flag, sizeof(int))) != hipSuccess) return e;
-  if ((e = hipMalloc(&slots, sizeof(double) * ((size_t)nblocks * 33 + 64))) != hipSuccess) return e;
+  if ((e = pf_malloc(&counter, sizeof(unsigned))) != hipSuccess) return e;
+  if ((e = pf_malloc(&flag, sizeof(int))) != hipSuccess) return e;
+  if ((e = pf_malloc(&slots, sizeof(double) * ((size_t)nblocks * 33 + 64))) != hipSuccess) return e;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
@@ -535,9 +535,9 @@ hipError_t run_grid_barrier_probe(int nblocks, int nthreads, int iters, double* 
   *ms_per_barrier = ms / (double)iters;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  (void)hipFree(counter);
-  (void)hipFree(flag);
-  (void)hipFree(slots);
+  (void)pf_free(counter);
+  (void)pf_free(flag);
+  (void)pf_free(slots);
   return e;
 }
 

@@ -50,7 +50,7 @@ int finish(FftPlan* p, hipStream_t stream, std::string* err) {
   RF(rocfft_plan_get_work_buffer_size(p->plan, &wb));
   RF(rocfft_execution_info_create(&p->info));
   if (wb) {
-    if (hipMalloc(&p->work, wb) != hipSuccess) {
+    if (pf_malloc(&p->work, wb) != hipSuccess) {
       if (err) *err = "hipMalloc of the rocFFT work buffer failed";
       return -5;
     }
@@ -110,7 +110,7 @@ void fftplan_destroy(FftPlan* p) {
   if (!p) return;
   if (p->info) (void)rocfft_execution_info_destroy(p->info);
   if (p->plan) (void)rocfft_plan_destroy(p->plan);
-  if (p->work) (void)hipFree(p->work);
+  if (p->work) (void)pf_free(p->work);
   delete p;
 }
 

@@ -747,20 +747,20 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, dou
       mf->u[1] = ext1;
       mf->own_u = false;
     } else {
-      MF_HIP(hipMalloc(&mf->u[0], bytes));
-      MF_HIP(hipMalloc(&mf->u[1], bytes));
+      MF_HIP(pf_malloc(&mf->u[0], bytes));
+      MF_HIP(pf_malloc(&mf->u[1], bytes));
     }
     MF_HIP(hipMemsetAsync(mf->u[0], 0, bytes, stream));
     MF_HIP(hipMemsetAsync(mf->u[1], 0, bytes, stream));
-    if (model == 2) MF_HIP(hipMalloc(&mf->mu, sizeof(double) * (size_t)mf->cells));
+    if (model == 2) MF_HIP(pf_malloc(&mf->mu, sizeof(double) * (size_t)mf->cells));
     if (model == 2) {
       MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm2_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(Bm2Lds)));
       MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bm2_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)sizeof(Bm2Lds)));
     }
-    MF_HIP(hipMalloc(&mf->partials, sizeof(double) * 5 * 1024));
-    MF_HIP(hipMalloc(&mf->out5, sizeof(double) * 8));
+    MF_HIP(pf_malloc(&mf->partials, sizeof(double) * 5 * 1024));
+    MF_HIP(pf_malloc(&mf->out5, sizeof(double) * 8));
     MF_HIP(hipHostMalloc(&mf->out5_host, sizeof(double) * 8, hipHostMallocDefault));
     return 0;
   };
@@ -773,7 +773,7 @@ void multifd_destroy(MultiFD* mf) {
   if (!mf) return;
   if (!mf->own_u) mf->u[0] = mf->u[1] = nullptr;
   for (void* q : {(void*)mf->u[0], (void*)mf->u[1], (void*)mf->mu, (void*)mf->partials, (void*)mf->out5})
-    if (q) (void)hipFree(q);
+    if (q) (void)pf_free(q);
   if (mf->out5_host) (void)hipHostFree(mf->out5_host);
   delete mf;
 }

@@ -228,10 +228,10 @@ FdArgs make_args(const pf_handle* h, double dt, int zlo, int zhi) {
 
 int ensure_mu_scratch(pf_handle* h, int64_t elems) {
   if (h->mu_scratch_elems >= elems) return PF_OK;
-  if (h->mu_scratch) PF_HIP(h, hipFree(h->mu_scratch));
+  if (h->mu_scratch) PF_HIP(h, pf_free(h->mu_scratch));
   h->mu_scratch = nullptr;
   h->mu_scratch_elems = 0;
-  PF_HIP(h, hipMalloc(&h->mu_scratch, sizeof(double) * elems));
+  PF_HIP(h, pf_malloc(&h->mu_scratch, sizeof(double) * elems));
   h->mu_scratch_elems = elems;
   return PF_OK;
 }
@@ -605,7 +605,7 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     h->own_c = true;
     const bool with_phi = cfg->model == PF_MODEL_BM6 && cfg->scheme == PF_SCHEME_FD_EXPLICIT && !cfg->ext_phi;
     const int64_t bytes = placed_offset_bytes(elems, with_phi ? 2 : 1) + (int64_t)sizeof(double) * elems;
-    PF_HIP_C(hipMalloc(&h->block, (size_t)bytes));
+    PF_HIP_C(pf_malloc(&h->block, (size_t)bytes));
     h->c[0] = static_cast<double*>(h->block);
     h->c[1] = h->c[0] + placed_offset_bytes(elems, 1) / (int64_t)sizeof(double);
     if (with_phi) h->phi = h->c[0] + placed_offset_bytes(elems, 2) / (int64_t)sizeof(double);
@@ -614,8 +614,8 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     PF_HIP_C(hipMemsetAsync(h->c[0], 0, sizeof(double) * elems, h->stream));
     PF_HIP_C(hipMemsetAsync(h->c[1], 0, sizeof(double) * elems, h->stream));
   }
-  PF_HIP_C(hipMalloc(&h->partials, sizeof(double) * diag_partials_elems()));
-  PF_HIP_C(hipMalloc(&h->out6_dev, sizeof(double) * 8));
+  PF_HIP_C(pf_malloc(&h->partials, sizeof(double) * diag_partials_elems()));
+  PF_HIP_C(pf_malloc(&h->out6_dev, sizeof(double) * 8));
   PF_HIP_C(hipHostMalloc(&h->out6_host, sizeof(double) * 8, hipHostMallocDefault));
   if (cfg->scheme == PF_SCHEME_FEM_BE) {
     int frc;
@@ -652,15 +652,15 @@ int pf_create(const pf_config* cfg, pf_handle** out) {
     if (cfg->ext_phi) {
       h->phi = cfg->ext_phi;
     } else if (!h->phi) {  // caller-owned c buffers without a phi buffer: phi is on its own
-      PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
+      PF_HIP_C(pf_malloc(&h->phi, sizeof(double) * elems));
       h->own_phi = true;
     }
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
     if (g.mirror)   // reference boundary conditions: this rank's planes of the odd-in-x right-hand side
-      PF_HIP_C(hipMalloc(&h->rhs_slab, sizeof(double) * (size_t)g.plane * g.nz));
+      PF_HIP_C(pf_malloc(&h->rhs_slab, sizeof(double) * (size_t)g.plane * g.nz));
   } else if (cfg->model == PF_MODEL_BM6 && cfg->scheme != PF_SCHEME_SPECTRAL_SI) {
     if (!h->phi) {
-      PF_HIP_C(hipMalloc(&h->phi, sizeof(double) * elems));
+      PF_HIP_C(pf_malloc(&h->phi, sizeof(double) * elems));
       h->own_phi = true;
     }
     PF_HIP_C(hipMemsetAsync(h->phi, 0, sizeof(double) * elems, h->stream));
@@ -712,6 +712,7 @@ const char* pf_status_string(const pf_handle* h) {
   if (h->po) m->status += std::string("; Poisson solve: ") + poisson_path(h->po);
   if (h->sf && !(h->sp || c.scheme == PF_SCHEME_SPECTRAL_SI))
     m->status += std::string("; slab Poisson solve (one all-to-all each way): ") + slabfft_path(h->sf);
+  m->status += "; " + pf_alloc_describe();
   return m->status.c_str();
 }
 
@@ -726,17 +727,17 @@ int pf_destroy(pf_handle* h) {
   if (h->ev_t0) {
     (void)hipEventDestroy(h->ev_t0);
   }
-  if (h->block) (void)hipFree(h->block);
-  if (h->mu_scratch) (void)hipFree(h->mu_scratch);
+  if (h->block) (void)pf_free(h->block);
+  if (h->mu_scratch) (void)pf_free(h->mu_scratch);
   if (h->sp) spectral_destroy(h->sp);
   if (h->po) poisson_destroy(h->po);
   if (h->fb) fembe_destroy(h->fb);
   if (h->mf) multifd_destroy(h->mf);
-  if (h->phi && h->own_phi) (void)hipFree(h->phi);
-  if (h->rhs_slab) (void)hipFree(h->rhs_slab);
+  if (h->phi && h->own_phi) (void)pf_free(h->phi);
+  if (h->rhs_slab) (void)pf_free(h->rhs_slab);
   if (h->sf) slabfft_destroy(h->sf);
-  if (h->partials) (void)hipFree(h->partials);
-  if (h->out6_dev) (void)hipFree(h->out6_dev);
+  if (h->partials) (void)pf_free(h->partials);
+  if (h->out6_dev) (void)pf_free(h->out6_dev);
   if (h->out6_host) (void)hipHostFree(h->out6_host);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1536,12 +1537,28 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
   // stateless entry point: scratch for mu is allocated per call (this is the slow reference path)
   double* mu = nullptr;
   const int64_t elems = (int64_t)nx * ny * (zhi - zlo + 2);
-  PF_HIP(nullptr, hipMalloc(&mu, sizeof(double) * elems));
+  PF_HIP(nullptr, pf_malloc(&mu, sizeof(double) * elems));
   hipError_t e = launch_ch_fd_twopass(a, mu, s);
   hipError_t e2 = hipStreamSynchronize(s);
-  (void)hipFree(mu);
+  (void)pf_free(mu);
   if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("twopass launch: ") + hipGetErrorString(e));
   if (e2 != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("twopass sync: ") + hipGetErrorString(e2));
+  return PF_OK;
+}
+
+int pf_device_malloc(void** dev_ptr, size_t bytes) {
+  if (!dev_ptr || bytes == 0) return fail(nullptr, PF_ERR_INVALID, "pf_device_malloc: need a result pointer and bytes > 0");
+  const hipError_t e = pf_malloc_bytes(dev_ptr, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(nullptr, e == hipErrorOutOfMemory ? PF_ERR_NOMEM : PF_ERR_HIP, std::string("pf_device_malloc: ") + hipGetErrorString(e));
+  }
+  return PF_OK;
+}
+
+int pf_device_free(void* dev_ptr) {
+  const hipError_t e = pf_free(dev_ptr);
+  if (e != hipSuccess) return fail(nullptr, PF_ERR_HIP, std::string("pf_device_free: ") + hipGetErrorString(e));
   return PF_OK;
 }
 
@@ -1587,14 +1604,14 @@ int pfk_flags_alloc(int n_words, int64_t** flags_dev, int32_t** timeout_host) {
   e = hipMemset(p, 0, sizeof(int64_t) * (size_t)n_words);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
-    (void)hipFree(p);
+    (void)pf_free(p);
     return fail(nullptr, PF_ERR_HIP, std::string("pfk_flags_alloc memset: ") + hipGetErrorString(e));
   }
   if (timeout_host) {
     void* t = nullptr;
     e = hipHostMalloc(&t, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e != hipSuccess) {
-      (void)hipFree(p);
+      (void)pf_free(p);
       return fail(nullptr, PF_ERR_HIP, std::string("hipHostMalloc(mapped): ") + hipGetErrorString(e));
     }
     *reinterpret_cast<volatile int32_t*>(t) = 0;
@@ -1605,7 +1622,7 @@ int pfk_flags_alloc(int n_words, int64_t** flags_dev, int32_t** timeout_host) {
 }
 
 int pfk_flags_free(int64_t* flags_dev, int32_t* timeout_host) {
-  if (flags_dev) (void)hipFree(flags_dev);
+  if (flags_dev) (void)pf_free(flags_dev);
   if (timeout_host) (void)hipHostFree(timeout_host);
   return PF_OK;
 }

@@ -10,6 +10,21 @@
 
 namespace pfhip {
 
+// device_alloc.hip: every device allocation of the library.  Arrays of 32 MiB and more are physically contiguous
+// (PFHIP_ALLOC), smaller ones are plain hipMallocs; pf_free takes either kind.
+hipError_t pf_malloc_bytes(void** p, size_t bytes);
+hipError_t pf_free(void* p);
+template <class T>
+inline hipError_t pf_malloc(T** p, size_t bytes) {
+  return pf_malloc_bytes(reinterpret_cast<void**>(p), bytes);
+}
+std::string pf_alloc_describe();
+// stream_util.hip: streams that do not share a hardware queue with the streams they are meant to run beside
+bool pf_streams_overlap(hipStream_t a, hipStream_t b);
+hipError_t pf_acquire_stream(const hipStream_t* avoid, int navoid, hipStream_t* out, bool* found);
+int pf_acquire_side_streams(hipStream_t main, int want, hipStream_t* out);
+
+
 // ---- arguments of the FD Cahn-Hilliard step launchers ---------------------------------------------------
 struct FdArgs {
   const double* cin;

@@ -150,15 +150,15 @@ int poisson_create(Poisson** out, int dim, int nx, int ny, int nz, int npx, int 
       PO_FFT(fftplan_real(&po->inv, dim, nn, 1, false, stream, &po->err));
     }
     if (fast_dir) {
-      PO_HIP(hipMalloc(&po->S, sizeof(double) * fused_dirichlet_work_doubles(npx, a.npy, dim == 3 ? nz / 2 + 1 : 1)));
+      PO_HIP(pf_malloc(&po->S, sizeof(double) * fused_dirichlet_work_doubles(npx, a.npy, dim == 3 ? nz / 2 + 1 : 1)));
       PO_HIP(hipMemsetAsync(po->S, 0, sizeof(double) * fused_dirichlet_work_doubles(npx, a.npy, dim == 3 ? nz / 2 + 1 : 1), stream));
     } else {  // the hand-written passes use a padded row pitch (fused_spectrum_pitch); the rocFFT path the natural one
       const SpecLayout lay = fused_spectrum_layout(dim, nx, ny, a.nz);
       const int64_t nh_alloc = fast ? (int64_t)lay.pitch * lay.rows : po->nh;
-      PO_HIP(hipMalloc(&po->ph, sizeof(double2) * nh_alloc));
+      PO_HIP(pf_malloc(&po->ph, sizeof(double2) * nh_alloc));
       if (nh_alloc != po->nh) PO_HIP(hipMemsetAsync(po->ph, 0, sizeof(double2) * nh_alloc, stream));
     }
-    if (npx > 0 && !fast_dir) PO_HIP(hipMalloc(&po->rhs, sizeof(double) * po->n));
+    if (npx > 0 && !fast_dir) PO_HIP(pf_malloc(&po->rhs, sizeof(double) * po->n));
     if (fast && fused2d_create(&po->fast, nx, ny, a.nz, h, stream, fast_dir ? 1 : 0) != 0) {
       po->err = "fused2d_create failed";
       return -3;
@@ -205,9 +205,9 @@ void poisson_destroy(Poisson* po) {
   if (!po) return;
   fftplan_destroy(po->fwd);
   fftplan_destroy(po->inv);
-  if (po->rhs) (void)hipFree(po->rhs);
-  if (po->S) (void)hipFree(po->S);
-  if (po->ph) (void)hipFree(po->ph);
+  if (po->rhs) (void)pf_free(po->rhs);
+  if (po->S) (void)pf_free(po->S);
+  if (po->ph) (void)pf_free(po->ph);
   if (po->fast) fused2d_destroy(po->fast);
   delete po;
 }

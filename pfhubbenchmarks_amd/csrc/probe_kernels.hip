@@ -129,9 +129,9 @@ hipError_t run_xcd_barrier_probe(int nblocks, int nthreads, int iters, int hando
   unsigned long long* rec = nullptr;
   double* out = nullptr;
   hipError_t e;
-  if ((e = hipMalloc(&ctl, sizeof(unsigned) * 256)) != hipSuccess) return e;
-  if ((e = hipMalloc(&rec, sizeof(unsigned long long) * 16 * (size_t)nblocks)) != hipSuccess) return e;
-  if ((e = hipMalloc(&out, sizeof(double) * 8)) != hipSuccess) return e;
+  if ((e = pf_malloc(&ctl, sizeof(unsigned) * 256)) != hipSuccess) return e;
+  if ((e = pf_malloc(&rec, sizeof(unsigned long long) * 16 * (size_t)nblocks)) != hipSuccess) return e;
+  if ((e = pf_malloc(&out, sizeof(double) * 8)) != hipSuccess) return e;
   unsigned h_ctl[256];
   double h_out = 0.0;
   for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {  // the second repetition is the reported one
@@ -150,9 +150,9 @@ hipError_t run_xcd_barrier_probe(int nblocks, int nthreads, int iters, int hando
     *stale = (int)h_ctl[96];
     *ok = h_ctl[128] == 0;
   }
-  (void)hipFree(ctl);
-  (void)hipFree(rec);
-  (void)hipFree(out);
+  (void)pf_free(ctl);
+  (void)pf_free(rec);
+  (void)pf_free(out);
   return e;
 }
 

@@ -227,19 +227,19 @@ int slabfft_create(SlabFFT** out, int nx, int ny, int nz, int P, int rank, doubl
       SF_FFT(fftplan_c2c_strided(&sf->pzi, nz, stride, 1, stride, stream, false, &sf->err));
     }
     const size_t loc = sizeof(double2) * (size_t)g.nzl * ny * g.pitch;
-    SF_HIP(hipMalloc(&sf->tmp, loc));
+    SF_HIP(pf_malloc(&sf->tmp, loc));
     if (extA && extB) {
       sf->A = reinterpret_cast<double2*>(extA);
       sf->B = reinterpret_cast<double2*>(extB);
     } else {
       sf->own_ab = true;
-      SF_HIP(hipMalloc(&sf->A, loc));
-      SF_HIP(hipMalloc(&sf->B, loc));
+      SF_HIP(pf_malloc(&sf->A, loc));
+      SF_HIP(pf_malloc(&sf->B, loc));
     }
-    SF_HIP(hipMalloc(&sf->partials, sizeof(double) * 2049));
+    SF_HIP(pf_malloc(&sf->partials, sizeof(double) * 2049));
     if (with_spectral) {
-      SF_HIP(hipMalloc(&sf->chat, loc));
-      if (!fast) SF_HIP(hipMalloc(&sf->greal, sizeof(double) * (size_t)g.nzl * ny * nx));
+      SF_HIP(pf_malloc(&sf->chat, loc));
+      if (!fast) SF_HIP(pf_malloc(&sf->greal, sizeof(double) * (size_t)g.nzl * ny * nx));
     }
     if (fast) {  // the passes never write the pad columns: keep them zero in every array they travel through
       SF_HIP(hipMemsetAsync(sf->tmp, 0, loc, stream));
@@ -261,14 +261,14 @@ void slabfft_destroy(SlabFFT* sf) {
   fftplan_destroy(sf->pzf);
   fftplan_destroy(sf->pzi);
   if (sf->fast) fused2d_destroy(sf->fast);
-  if (sf->tmp) (void)hipFree(sf->tmp);
+  if (sf->tmp) (void)pf_free(sf->tmp);
   if (sf->own_ab) {
-    if (sf->A) (void)hipFree(sf->A);
-    if (sf->B) (void)hipFree(sf->B);
+    if (sf->A) (void)pf_free(sf->A);
+    if (sf->B) (void)pf_free(sf->B);
   }
-  if (sf->chat) (void)hipFree(sf->chat);
-  if (sf->greal) (void)hipFree(sf->greal);
-  if (sf->partials) (void)hipFree(sf->partials);
+  if (sf->chat) (void)pf_free(sf->chat);
+  if (sf->greal) (void)pf_free(sf->greal);
+  if (sf->partials) (void)pf_free(sf->partials);
   delete sf;
 }
 

@@ -217,7 +217,7 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
     const size_t bytes = sizeof(double2) * nh_alloc, slot = (bytes + 255) / 256 * 256;
     {
       unsigned char* blk = nullptr;
-      SP_HIP(hipMalloc(&blk, 3 * slot));
+      SP_HIP(pf_malloc(&blk, 3 * slot));
       sp->block = blk;
       sp->chat = reinterpret_cast<double2*>(blk);
       sp->ghat = reinterpret_cast<double2*>(blk + slot);
@@ -228,8 +228,8 @@ int spectral_create(Spectral** out, int dim, int nx, int ny, int nz, double h, h
       SP_HIP(hipMemsetAsync(sp->ghat, 0, sizeof(double2) * nh_alloc, stream));
       SP_HIP(hipMemsetAsync(sp->scratch, 0, sizeof(double2) * nh_alloc, stream));
     }
-    if (!want_fast) SP_HIP(hipMalloc(&sp->g, sizeof(double) * sp->n));
-    SP_HIP(hipMalloc(&sp->partials, sizeof(double) * 4096));
+    if (!want_fast) SP_HIP(pf_malloc(&sp->g, sizeof(double) * sp->n));
+    SP_HIP(pf_malloc(&sp->partials, sizeof(double) * 4096));
     if (want_fast) {  // PFHIP_SPECTRAL_2D / _3D = rocfft force the library path (A/B comparison)
       if (fused2d_create(&sp->fast, nx, ny, sp->nz, h, stream) != 0) {
         sp->err = "fused2d_create failed";
@@ -245,9 +245,9 @@ void spectral_destroy(Spectral* sp) {
   if (!sp) return;
   fftplan_destroy(sp->fwd);
   fftplan_destroy(sp->inv);
-  if (sp->block) (void)hipFree(sp->block);
-  if (sp->g) (void)hipFree(sp->g);
-  if (sp->partials) (void)hipFree(sp->partials);
+  if (sp->block) (void)pf_free(sp->block);
+  if (sp->g) (void)pf_free(sp->g);
+  if (sp->partials) (void)pf_free(sp->partials);
   if (sp->fast) fused2d_destroy(sp->fast);
   delete sp;
 }

@@ -16,6 +16,7 @@
 // The same transforms serve 3-D boxes whose axes are powers of two in 128..1024 (four passes per step: z, y, x, y;
 // 512-point axes by the one-wave radix-8 kernels, the others by the radix-2^2 kernels), the 3-D periodic Poisson solve of
 // BM6, and the slab-decomposed transforms of the multi-GPU modes (fusedslab_*, used by slabfft.hip).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1430,7 +1431,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
       const double ang = TWO_PI_F * k / N;
       t[k] = make_double2(std::cos(ang), -std::sin(ang));
     }
-    hipError_t e = hipMalloc(dev, sizeof(double2) * t.size());
+    hipError_t e = pf_malloc(dev, sizeof(double2) * t.size());
     if (e != hipSuccess) return e;
     return hipMemcpy(*dev, t.data(), sizeof(double2) * t.size(), hipMemcpyHostToDevice);
   };
@@ -1447,7 +1448,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
         const double ang = TWO_PI_F * k / N;
         t[k] = make_double2(std::cos(ang), -std::sin(ang));
       }
-      hipError_t e = hipMalloc(dev, sizeof(double2) * t.size());
+      hipError_t e = pf_malloc(dev, sizeof(double2) * t.size());
       if (e != hipSuccess) return e;
       return hipMemcpy(*dev, t.data(), sizeof(double2) * t.size(), hipMemcpyHostToDevice);
     };
@@ -1472,13 +1473,13 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
         !big(reinterpret_cast<const void*>(mx_col_kernel<4>), lds_mcol))
       return -3;
   }
-  const char* e = getenv("PFHIP_FFT512");  // "radix2": keep the multi-wave radix-2^2 kernels (A/B comparison)
-  const bool allow8 = !(e && std::string(e) == "radix2");
-  f->row512 = (allow8 || f->cube512) && nx == 512 && (ny / 2) % RW == 0;
-  f->col512 = (allow8 || f->cube512) && (ny == 512 || nz == 512);  // (3-D: "some column pass needs the radix-8 tables")
+  // 512-point axes: the one-wave radix-8 kernels (the multi-wave radix-2^2 kernels at 512 points were 8 % slower in 2-D,
+  // profiles/r02; their A/B switch went in round 4)
+  f->row512 = nx == 512 && (ny / 2) % RW == 0;
+  f->col512 = ny == 512 || nz == 512;  // (3-D: "some column pass needs the radix-8 tables")
   if (f->mixed) f->row512 = f->col512 = false;
   if (f->cube512) {
-    if (hipMalloc(&f->queues, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess ||
+    if (pf_malloc(&f->queues, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess ||
         hipMemset(f->queues, 0, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess)
       return -3;
     int dev = 0;
@@ -1517,12 +1518,11 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     }
     if (f->chunk >= nz) f->chunk = 0;
     if (f->chunk > 0 && ns > 1) {
-      f->nside = ns > 4 ? 4 : ns;
+      // lanes of the chunked groups: the handle's stream + (ns - 1) side streams that REALLY run beside it
       if (hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) != hipSuccess) return -3;
+      f->nside = pf_acquire_side_streams(stream, (ns > 4 ? 4 : ns) - 1, f->side);
       for (int k = 0; k < f->nside; ++k)
-        if (hipStreamCreateWithFlags(&f->side[k], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&f->ev_join[k], hipEventDisableTiming) != hipSuccess)
-          return -3;
+        if (hipEventCreateWithFlags(&f->ev_join[k], hipEventDisableTiming) != hipSuccess) return -3;
     }
   }
   if (f->row512 || f->col512) {
@@ -1537,8 +1537,8 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
         const double ang = TWO_PI_F * (double)(l0 * sidx) / 64.0;
         tb[l0 * 8 + sidx] = make_double2(std::cos(ang), -std::sin(ang));
       }
-    if (hipMalloc(&f->tw8a, sizeof(double2) * 512) != hipSuccess ||
-        hipMalloc(&f->tw8b, sizeof(double2) * 64) != hipSuccess ||
+    if (pf_malloc(&f->tw8a, sizeof(double2) * 512) != hipSuccess ||
+        pf_malloc(&f->tw8b, sizeof(double2) * 64) != hipSuccess ||
         hipMemcpy(f->tw8a, ta.data(), sizeof(double2) * 512, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(f->tw8b, tb.data(), sizeof(double2) * 64, hipMemcpyHostToDevice) != hipSuccess)
       return -3;
@@ -1552,7 +1552,7 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
     if (nz > 1) {
       d += ", z " + kind(nz, nz == 512 && f->col512);
       d += f->chunk > 0 ? "; plane-local passes in chunks of " + std::to_string(f->chunk) + " planes on " +
-                              std::to_string(f->nside > 0 ? f->nside : 1) + " stream(s)" +
+                              std::to_string(f->nside + 1) + " stream(s)" +
                               (f->chunk_min_planes > 0 ? " (calls over >= " + std::to_string(f->chunk_min_planes) + " planes)" : "")
                         : "; whole box per launch";
     }
@@ -1580,16 +1580,16 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
 
 void fused2d_destroy(Fused2D* f) {
   if (!f) return;
-  if (f->twz) (void)hipFree(f->twz);
-  if (f->twfx) (void)hipFree(f->twfx);
-  if (f->twfy) (void)hipFree(f->twfy);
-  if (f->twfz) (void)hipFree(f->twfz);
-  if (f->twx) (void)hipFree(f->twx);
-  if (f->twy) (void)hipFree(f->twy);
-  if (f->tw8a) (void)hipFree(f->tw8a);
-  if (f->tw8b) (void)hipFree(f->tw8b);
-  if (f->sym) (void)hipFree(f->sym);
-  if (f->queues) (void)hipFree(f->queues);
+  if (f->twz) (void)pf_free(f->twz);
+  if (f->twfx) (void)pf_free(f->twfx);
+  if (f->twfy) (void)pf_free(f->twfy);
+  if (f->twfz) (void)pf_free(f->twfz);
+  if (f->twx) (void)pf_free(f->twx);
+  if (f->twy) (void)pf_free(f->twy);
+  if (f->tw8a) (void)pf_free(f->tw8a);
+  if (f->tw8b) (void)pf_free(f->tw8b);
+  if (f->sym) (void)pf_free(f->sym);
+  if (f->queues) (void)pf_free(f->queues);
   for (int k = 0; k < 4; ++k) {
     if (f->side[k]) (void)hipStreamDestroy(f->side[k]);
     if (f->ev_join[k]) (void)hipEventDestroy(f->ev_join[k]);
@@ -1789,7 +1789,8 @@ int run_chunked(const Fused2D* f, const F2Args& a, Body body) {
     F2Args ac = a;
     ac.nz = base + (k < rem ? 1 : 0);
     Fused2D fc = *f;  // launch descriptor only: the launchers read geometry, tables and the stream from it
-    if (f->nside > 0) fc.stream = f->side[k % f->nside];
+    const int lane = k % (f->nside + 1);   // lane 0 = the handle's stream, the others = the side streams tested at create
+    if (lane > 0) fc.stream = f->side[lane - 1];
     body(fc, ac, z0);
     f->qepoch = fc.qepoch;
     z0 += ac.nz;
@@ -1811,7 +1812,7 @@ int ensure_sym(Fused2D* f) {
   std::vector<double> t;
   for (int d = 0; d < 3; ++d)
     for (int m = 0; m < nn[d]; ++m) t.push_back(2.0 * std::cos(TWO_PI_F * m / nn[d]) - 2.0);
-  if (hipMalloc(&f->sym, sizeof(double) * t.size()) != hipSuccess ||
+  if (pf_malloc(&f->sym, sizeof(double) * t.size()) != hipSuccess ||
       hipMemcpy(f->sym, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice) != hipSuccess)
     return -3;
   return 0;

@@ -114,6 +114,8 @@ SYMBOLS = {
                                  C.c_int, C.c_int, C.POINTER(PfkChParams), C.c_int, C.c_void_p]),
     "pfk_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "pfk_stream_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pf_device_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "pf_device_free": (C.c_int, [C.c_void_p]),
     "pfk_grid_barrier_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _D]),
     "pfk_xcd_barrier_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _D, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pfk_push_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

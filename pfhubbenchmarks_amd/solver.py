@@ -53,7 +53,7 @@ class PhaseFieldSolver:
     """Single-GPU solver handle (pf_create .. pf_destroy)."""
 
     def __init__(self, dim=2, n=512, h=1.0, bc="periodic", scheme="fd", model="bm1", kernel="auto", device=0,
-                 stream=None, eliminate_phi=False, always_pivot=False, **params):
+                 stream=None, eliminate_phi=False, always_pivot=False, ext_c=None, **params):
         self._lib = _lib.load()
         n3 = list(n) if isinstance(n, (tuple, list)) else [n] * dim
         cfg = _lib.default_config(dim, int(n3[0]), float(h))
@@ -83,6 +83,9 @@ class PhaseFieldSolver:
             setattr(cfg, k, int(v) if k == "max_newton" else float(v))
         if stream is not None:
             cfg.stream = C.c_void_p(int(stream))
+        if ext_c is not None:       # the caller's own field pair (device pointers; pf_config.ext_c, e.g. from pf_device_malloc)
+            cfg.ext_c[0] = C.c_void_p(int(ext_c[0]))
+            cfg.ext_c[1] = C.c_void_p(int(ext_c[1]))
         self.cfg = cfg
         self.dim = dim
         self.shape = tuple(int(cfg.n[d]) for d in reversed(range(dim)))  # numpy order (z, y, x) / (y, x)

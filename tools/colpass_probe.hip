@@ -303,6 +303,29 @@ int main(int argc, char** argv) {
       fflush(stdout);
     }
   }
+  if (!resident) {   // is the y pass (real transform) equally fast on every stream?  (streams share a few hardware queues)
+    Geom g;
+    g.nxh = nxh;
+    g.nblk = 33;
+    g.nbatch = n;
+    g.nitems = g.nblk * g.nbatch;
+    g.rstride = pitch;
+    g.bstride = (int64_t)n * pitch;
+    for (int sidx = 0; sidx < 10; ++sidx) {
+      hipStream_t st;
+      CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      CK(hipMemcpy(A, B, elems * sizeof(double2), hipMemcpyDeviceToDevice));
+      for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((reg_kernel<-1, true>), dim3(g.nitems), dim3(512), 0, st, A, g, twa, twb);
+      CK(hipMemcpyAsync(A, B, elems * sizeof(double2), hipMemcpyDeviceToDevice, st));
+      CK(hipEventRecord(e0, st));
+      for (int r = 0; r < 20; ++r) hipLaunchKernelGGL((reg_kernel<-1, true>), dim3(g.nitems), dim3(512), 0, st, A, g, twa, twb);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("stream %d (kept alive): y pass reg %8.1f us/pass\n", sidx, ms / 20 * 1e3);
+    }
+  }
   if (resident) {
     Geom g;
     g.nxh = nxh;

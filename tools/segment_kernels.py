@@ -19,7 +19,9 @@ for r in rows:
             cur = defaultdict(list)
         continue
     if "f3_" in n or "f2_row512" in n:
-        k = n[n.index("::f") + 2:n.index("(")] if "::f" in n else n[:30]
+        k = n[:n.index("(")] if "(" in n else n
+        k = k.replace("void ", "").replace("pfhip::", "").replace("(anonymous namespace)::", "")
+        k += "/%s" % r.get("Grid_Size_X", r.get("Grid_Size", "?"))     # the z pass and the y passes share one kernel template
         cur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 if cur:
     segs.append(cur)

@@ -18,6 +18,7 @@ ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--model", default="bm1")
 ap.add_argument("--n", default="512", help="points per axis: N or NX,NY,NZ")
 ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--dummy-streams", type=int, default=0, help="create this many extra HIP streams before every handle (shifts the stream -> hardware queue assignment)")
 ap.add_argument("--check", action="store_true", help="compare the field after 5 steps with the first form's")
 a = ap.parse_args()
 forms = []
@@ -33,6 +34,8 @@ for rnd in range(a.rounds):
         os.environ.setdefault("PFHIP_SPEC_PROBE", "0")
         os.environ.update(env)
         scheme = "spectral" if a.model == "bm1" else "fd"
+        import torch
+        dummies = [torch.cuda.Stream() for _ in range(a.dummy_streams)]
         nn = tuple(int(v) for v in a.n.split(","))
         nn = nn[0] if len(nn) == 1 else nn
         with PhaseFieldSolver(dim=3, n=nn, h=1.0, scheme=scheme, model=a.model) as s:
