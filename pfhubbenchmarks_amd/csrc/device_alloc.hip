@@ -16,7 +16,9 @@
 //               in shuffled order: a distribution instead of two states (spectral 2.03 ... 2.60, BM3 0.72 ... 0.75 ms);
 //               its best cases are the best seen, but which case a handle gets is again the driver's choice of pieces.
 //               Pieces below 2 MiB (the page-table fragment the TLBs hold in one entry) cost 2-4x.
-// Allocations below 32 MiB are plain hipMallocs.  If the contiguous (or virtual-memory) calls fail the array is a plain
+// Allocations below 32 MiB are plain hipMallocs, and so is everything of the BE-parity mode (csrc/fem_be.hip calls hipMalloc
+// itself): its band and dense blocks showed no lottery, and on contiguous memory its steps were 16 % SLOWER (BM3 186 vs
+// 160 ms, BM2 58.5 vs 50.2: profiles/r04/alloc_fem_be.log).  If the contiguous (or virtual-memory) calls fail the array is a plain
 // hipMalloc and pf_alloc_describe() says so -- results never depend on the placement.
 #include <algorithm>
 #include <cstring>

@@ -1316,7 +1316,7 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     // ---- device
     auto up = [&](auto** dptr, const auto& v) -> hipError_t {
       using T = typename std::remove_reference<decltype(v[0])>::type;
-      hipError_t e = pf_malloc(dptr, sizeof(T) * v.size());
+      hipError_t e = hipMalloc(dptr, sizeof(T) * v.size());
       if (e != hipSuccess) return e;
       return hipMemcpy(*dptr, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
     };
@@ -1330,18 +1330,18 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     FB_HIP(up(&fb->nt_loc, nt_loc));
     const size_t nb = sizeof(double) * p.nn;
     for (double** f : {&fb->c, &fb->mu, &fb->phi, &fb->c0, &fb->mu0, &fb->phi0}) {
-      FB_HIP(pf_malloc(f, nb));
+      FB_HIP(hipMalloc(f, nb));
       FB_HIP(hipMemset(*f, 0, nb));
     }
     const size_t bs = sizeof(double) * (size_t)p.nb * p.nb * p.ng;
-    FB_HIP(pf_malloc(&fb->D, bs));
-    FB_HIP(pf_malloc(&fb->Lo, bs));
-    FB_HIP(pf_malloc(&fb->Up, bs));
-    FB_HIP(pf_malloc(&fb->Lo2, bs));
-    FB_HIP(pf_malloc(&fb->Up2, bs));
-    FB_HIP(pf_malloc(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
-    FB_HIP(pf_malloc(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
-    FB_HIP(pf_malloc(&fb->tflags, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
+    FB_HIP(hipMalloc(&fb->D, bs));
+    FB_HIP(hipMalloc(&fb->Lo, bs));
+    FB_HIP(hipMalloc(&fb->Up, bs));
+    FB_HIP(hipMalloc(&fb->Lo2, bs));
+    FB_HIP(hipMalloc(&fb->Up2, bs));
+    FB_HIP(hipMalloc(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
+    FB_HIP(hipMalloc(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
+    FB_HIP(hipMalloc(&fb->tflags, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
     FB_HIP(hipMemset(fb->tflags, 0, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
@@ -1363,17 +1363,17 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       fb->verbose = v && v[0] == '1';
     }
     fb->vec_len = condensed ? (size_t)p.nn * nf : (size_t)p.nb * p.ng;
-    FB_HIP(pf_malloc(&fb->rhs, sizeof(double) * fb->vec_len));
+    FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * fb->vec_len));
     if (condensed) {
-      FB_HIP(pf_malloc(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
-      FB_HIP(pf_malloc(&fb->fac, sizeof(double) * (size_t)(p.ng / 2 + 1) * n1 * 3 * nf * nf));
+      FB_HIP(hipMalloc(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
+      FB_HIP(hipMalloc(&fb->fac, sizeof(double) * (size_t)(p.ng / 2 + 1) * n1 * 3 * nf * nf));
       const char* b0 = getenv("PFHIP_FEM_BAND0");  // "0": dense rocSOLVER / rocBLAS kernels on the first level too (A/B)
       fb->band0 = !(b0 && b0[0] == '0');
     }
-    FB_HIP(pf_malloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
-    FB_HIP(pf_malloc(&fb->info, sizeof(rocblas_int) * p.ng));
-    FB_HIP(pf_malloc(&fb->scal, sizeof(double) * 4));
-    FB_HIP(pf_malloc(&fb->partials, sizeof(double) * 3 * 256));
+    FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
+    FB_HIP(hipMalloc(&fb->info, sizeof(rocblas_int) * p.ng));
+    FB_HIP(hipMalloc(&fb->scal, sizeof(double) * 4));
+    FB_HIP(hipMalloc(&fb->partials, sizeof(double) * 3 * 256));
     FB_HIP(hipHostMalloc(&fb->scal_host, sizeof(double) * 4, hipHostMallocDefault));
     FB_BLAS(rocblas_create_handle(&fb->bh));
     FB_BLAS(rocblas_set_stream(fb->bh, stream));
@@ -1453,15 +1453,15 @@ void fembe_destroy(FemBE* fb) {
                   (void*)fb->c0, (void*)fb->mu0, (void*)fb->phi0, (void*)fb->D, (void*)fb->Lo, (void*)fb->Up,
                   (void*)fb->Lo2, (void*)fb->Up2, (void*)fb->tinv, (void*)fb->tperm, (void*)fb->tflags,
                   (void*)fb->rhs, (void*)fb->piv, (void*)fb->info, (void*)fb->scal, (void*)fb->partials})
-    if (q) (void)pf_free(q);
+    if (q) (void)hipFree(q);
   if (fb->scal_host) (void)hipHostFree(fb->scal_host);
-  if (fb->rhs0) (void)pf_free(fb->rhs0);
-  if (fb->rhs1) (void)pf_free(fb->rhs1);
-  if (fb->Aloc) (void)pf_free(fb->Aloc);
-  if (fb->fac) (void)pf_free(fb->fac);
+  if (fb->rhs0) (void)hipFree(fb->rhs0);
+  if (fb->rhs1) (void)hipFree(fb->rhs1);
+  if (fb->Aloc) (void)hipFree(fb->Aloc);
+  if (fb->fac) (void)hipFree(fb->fac);
   for (int f = 3; f < MAXF; ++f) {  // fields 0..2 alias c / mu / phi
-    if (fb->u.u[f]) (void)pf_free(fb->u.u[f]);
-    if (fb->u0.u[f]) (void)pf_free(fb->u0.u[f]);
+    if (fb->u.u[f]) (void)hipFree(fb->u.u[f]);
+    if (fb->u0.u[f]) (void)hipFree(fb->u0.u[f]);
   }
   delete fb;
 }
@@ -1534,14 +1534,14 @@ int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, con
   fb->u0.u[2] = fb->phi0;
   const size_t nbytes = sizeof(double) * fb->p.nn;
   for (int f = 3; f < nf; ++f) {
-    FB_HIP(pf_malloc(&fb->u.u[f], nbytes));
-    FB_HIP(pf_malloc(&fb->u0.u[f], nbytes));
+    FB_HIP(hipMalloc(&fb->u.u[f], nbytes));
+    FB_HIP(hipMalloc(&fb->u0.u[f], nbytes));
     FB_HIP(hipMemset(fb->u.u[f], 0, nbytes));
     FB_HIP(hipMemset(fb->u0.u[f], 0, nbytes));
   }
   for (int f = nf; f < MAXF; ++f) fb->u.u[f] = fb->u0.u[f] = nullptr;
-  FB_HIP(pf_malloc(&fb->rhs0, sizeof(double) * fb->vec_len));
-  FB_HIP(pf_malloc(&fb->rhs1, sizeof(double) * fb->vec_len));
+  FB_HIP(hipMalloc(&fb->rhs0, sizeof(double) * fb->vec_len));
+  FB_HIP(hipMalloc(&fb->rhs1, sizeof(double) * fb->vec_len));
   // the reference's SNES line search: 'cp' for BM2 (bench2.py:140), 'basic' for BM3 (bench3.py:124)
   fb->line_search = model == 2 ? 1 : 0;
   if (const char* e = getenv("PFHIP_FEM_LINESEARCH")) fb->line_search = std::string(e) == "cp" ? 1 : 0;
@@ -2504,14 +2504,14 @@ static int block_solve_bcr(FemBE* fb) {
         std::vector<double> ref, mine;
         if (check) {   // DEBUG: the same batch through rocSOLVER, compared entry by entry on the host
           double* tmp = nullptr;
-          FB_HIP(pf_malloc(&tmp, sizeof(double) * (size_t)ne * bs));
+          FB_HIP(hipMalloc(&tmp, sizeof(double) * (size_t)ne * bs));
           FB_HIP(hipMemcpy2DAsync(tmp, sizeof(double) * bs, De, sizeof(double) * st, sizeof(double) * bs, ne,
                                   hipMemcpyDeviceToDevice, fb->stream));
           FB_BLAS(rocsolver_dgetrf_npvt_strided_batched(fb->bh, nb, nb, tmp, nb, bs, fb->info, ne));
           ref.resize((size_t)ne * bs);
           FB_HIP(hipMemcpyAsync(ref.data(), tmp, sizeof(double) * ref.size(), hipMemcpyDeviceToHost, fb->stream));
           FB_HIP(hipStreamSynchronize(fb->stream));
-          FB_HIP(pf_free(tmp));
+          FB_HIP(hipFree(tmp));
         }
         for (int e0 = 0; e0 < ne; e0 += 32) {
           const int nn = ne - e0 < 32 ? ne - e0 : 32;
