@@ -365,7 +365,7 @@ def test_full_size_properties_1024cubed(lib):
 @pytest.mark.parametrize("shape", [(512, 512), (128, 256), (1024, 128), (256, 512), (512, 128), (96, 40), (34, 18, 10),
                                    (64, 64, 64), (128, 128, 128), (256, 128, 512), (128, 512, 256), (1024, 128, 128),
                                    (128, 128, 1024), (128, 1024, 128), (200, 200), (400, 400), (40, 96, 200), (9, 12, 30),
-                                   (1000, 8), (250, 1024, 16)])
+                                   (1000, 8), (250, 1024, 16), (512, 128, 128), (512, 256, 128)])
 def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
     """BASELINE.json config 2 (512^2 semi-implicit spectral) vs the pocketfft oracle, 1e-11 relative: 2-D power-of-two
     shapes take the fused LDS-FFT path (csrc/spectral2d_fused.hip: one-wave radix-8 kernels on 512-point axes -- (256, 512)
@@ -408,7 +408,7 @@ def test_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(512, 512), (128, 256), (96, 40), (34, 18, 10), (128, 128, 128), (256, 128, 512),
-                                   (200, 400), (20, 24, 50)])
+                                   (200, 400), (20, 24, 50), (512, 128, 128)])
 def test_bm6_spectral_scheme_matches_numpy_oracle(lib, shape, monkeypatch):
     """BM6 with the semi-implicit spectral scheme in a periodic box: phi eliminated in Fourier space (one more implicit
     term in the k-space update, every kernel form: radix-8 LDS FFT, radix-2^2 LDS FFT, rocFFT 2-D and 3-D), f_elec by
@@ -476,7 +476,7 @@ def test_allocation_policies_give_identical_fields_and_say_what_they_are(lib, mo
 
 
 @pytest.mark.parametrize("shape,model", [((128, 128, 256), "bm1"), ((40, 96, 200), "bm1"), ((128, 256, 128), "bm6"),
-                                         ((64, 128, 128), "bm6fd")])
+                                         ((64, 128, 128), "bm6fd"), ((512, 128, 128), "bm1")])
 def test_spectral_plane_local_passes_in_chunks_are_bit_identical(lib, monkeypatch, shape, model):
     """The passes of a 3-D spectral step / Poisson solve that only couple points of one z-plane (x rows, y columns) run chunk
     of planes by chunk of planes, the chunks dealt to side streams (run_chunked in csrc/spectral2d_fused.hip; default on
