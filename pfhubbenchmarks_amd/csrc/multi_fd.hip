@@ -27,6 +27,7 @@ struct MfdParams {
   int model, nf, nx, ny, nz;
   int gz;   // slab mode: ghost planes per side inside nz (refreshed by the caller before every step); diagnostics skip them
   int zlo = 0, zhi = 0;   // planes [zlo, zhi) to compute in this launch (multifd_step_range; a whole step: [0, nz))
+  int64_t fs = 0;         // field stride in doubles: nx ny nz for the caller's buffers, padded for the library's own (multifd_create)
   double inv_h2;
   // BM2: ca, cb, rho2, kappa_c, M, kappa_eta, w, alpha, L     BM3: lam, 1/tau, W^2, D
   double q[9];
@@ -52,7 +53,6 @@ __device__ __forceinline__ double hsp(double u) { return (30.0 * (u * u)) * ((1.
 // BM2 pass 1: mu = f_c - kappa_c inv_h2 lap_raw(c)
 __global__ __launch_bounds__(256) void bm2_mu_kernel(const MfdParams p, const double* __restrict__ u,
                                                      double* __restrict__ mu) {
-  const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
   const int64_t i = (int64_t)p.zlo * p.nx * p.ny + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)p.zhi * p.nx * p.ny) return;
   const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void bm2_mu_kernel(const MfdParams p, const do
   const double c = u[i];
   double h = 0.0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) h = h + hs(u[(k + 1) * cells + i]);
+  for (int k = 0; k < 4; ++k) h = h + hs(u[(k + 1) * p.fs + i]);
   const double fc = (2.0 * r2) * (c - ca) * (1.0 - h) + (2.0 * r2) * (c - cb) * h;
   mu[i] = fc - (kc * p.inv_h2) * lap_raw(u, x, y, z, p.nx, p.ny, p.nz);
 }
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void bm2_mu_kernel(const MfdParams p, const do
 __global__ __launch_bounds__(256) void bm2_update_kernel(const MfdParams p, const double* __restrict__ u,
                                                          const double* __restrict__ mu, double* __restrict__ un,
                                                          double dt) {
-  const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
   const int64_t i = (int64_t)p.zlo * p.nx * p.ny + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)p.zhi * p.nx * p.ny) return;
   const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256) void bm2_update_kernel(const MfdParams p, cons
   double e[4], e2 = 0.0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    e[k] = u[(k + 1) * cells + i];
+    e[k] = u[(k + 1) * p.fs + i];
     e2 = e2 + e[k] * e[k];
   }
   const double dfab = r2 * ((c - cb) * (c - cb)) - r2 * ((c - ca) * (c - ca));  // f_beta - f_alpha
@@ -88,24 +87,23 @@ __global__ __launch_bounds__(256) void bm2_update_kernel(const MfdParams p, cons
     const double ek = e[k];
     const double well = (2.0 * ek * ((1.0 - ek) * (1.0 - ek)) - 2.0 * (ek * ek) * (1.0 - ek)) + (2.0 * al) * ek * (e2 - ek * ek);
     const double fe = dfab * hsp(ek) + w * well;
-    const double lap = lap_raw(u + (k + 1) * cells, x, y, z, p.nx, p.ny, p.nz);
-    un[(k + 1) * cells + i] = ek - (dt * L) * (fe - (ke * p.inv_h2) * lap);
+    const double lap = lap_raw(u + (k + 1) * p.fs, x, y, z, p.nx, p.ny, p.nz);
+    un[(k + 1) * p.fs + i] = ek - (dt * L) * (fe - (ke * p.inv_h2) * lap);
   }
 }
 
 // BM3: phi_t = (1/tau) (W^2 inv_h2 lap_raw(phi) + dfdp);  phi+ = phi + dt phi_t;  U+ = U + dt (D inv_h2 lap_raw(U) + phi_t / 2)
 __global__ __launch_bounds__(256) void bm3_update_kernel(const MfdParams p, const double* __restrict__ u,
                                                          double* __restrict__ un, double dt) {
-  const int64_t cells = (int64_t)p.nx * p.ny * p.nz;
   const int64_t i = (int64_t)p.zlo * p.nx * p.ny + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)p.zhi * p.nx * p.ny) return;
   const int x = (int)(i % p.nx), y = (int)((i / p.nx) % p.ny), z = (int)(i / ((int64_t)p.nx * p.ny));
   const double lam = p.q[0], it = p.q[1], W2 = p.q[2], D = p.q[3];
-  const double U = u[i], ph = u[cells + i];
+  const double U = u[i], ph = u[p.fs + i];
   const double P = 1.0 - ph * ph;
   const double dfdp = (ph - (lam * U) * P) * P;
-  const double pt = it * ((W2 * p.inv_h2) * lap_raw(u + cells, x, y, z, p.nx, p.ny, p.nz) + dfdp);
-  un[cells + i] = ph + dt * pt;
+  const double pt = it * ((W2 * p.inv_h2) * lap_raw(u + p.fs, x, y, z, p.nx, p.ny, p.nz) + dfdp);
+  un[p.fs + i] = ph + dt * pt;
   un[i] = U + dt * ((D * p.inv_h2) * lap_raw(u, x, y, z, p.nx, p.ny, p.nz) + 0.5 * pt);
 }
 
@@ -163,15 +161,15 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
   const int tile_id = full == 0 ? xq * per + rq : ((xq < full ? xq * per : full * per + (xq - full) * (per - 1)) + rq);
   const int x0 = (tile_id % ntx) * SX, y0 = ((tile_id / ntx) % nty) * TY;
   const int zb = p.zlo + (tile_id / (ntx * nty)) * zchunk, ze = zb + zchunk < p.zhi ? zb + zchunk : p.zhi;
-  const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
+  const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny;
   const int xo = x0 + 2 * lane;
   // stencilled field s of this pass -> where it lives
   auto sfield = [&](int s) -> const double* {
-    if (PASS == 30) return u + (int64_t)s * cells;            // U, phi
+    if (PASS == 30) return u + (int64_t)s * p.fs;            // U, phi
     if (PASS == 20) return u;                                   // c
-    return s == 0 ? mu_in : u + (int64_t)s * cells;             // mu, eta1..eta4
+    return s == 0 ? mu_in : u + (int64_t)s * p.fs;             // mu, eta1..eta4
   };
-  auto pfield = [&](int k) -> const double* { return PASS == 20 ? u + (int64_t)(k + 1) * cells : u; };  // eta_k / c
+  auto pfield = [&](int k) -> const double* { return PASS == 20 ? u + (int64_t)(k + 1) * p.fs : u; };  // eta_k / c
   double2 zm[NS][RPT], zc[NS][RPT], zp[NS][RPT];   // own cells in planes z-1, z, z+1
   const int64_t own = (int64_t)(y0 + wave * RPT) * row + xo;
 #define MFD_LOAD_OWN(DST, Z)                                                                                     \
@@ -262,7 +260,7 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
           }
         }
         st_out<NT>(out + o, nU);
-        st_out<NT>(out + cells + o, nP);
+        st_out<NT>(out + p.fs + o, nP);
       } else if (PASS == 20) {
         const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3];
         double2 m;
@@ -311,7 +309,7 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
           }
         }
 #pragma unroll
-        for (int f = 0; f < 5; ++f) st_out<NT>(out + (int64_t)f * cells + o, res[f]);
+        for (int f = 0; f < 5; ++f) st_out<NT>(out + (int64_t)f * p.fs + o, res[f]);
       }
     }
     __syncthreads();
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
   const int bx = tile % ntx, by = (tile / ntx) % nty, bz = tile / (ntx * nty);
   const int x0 = bx * SX, y0 = by * B2TY;
   const int zb = p.zlo + bz * zchunk, ze = zb + zchunk < p.zhi ? zb + zchunk : p.zhi;
-  const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
+  const int64_t row = p.nx, plane = (int64_t)p.nx * p.ny;
   const int xo = x0 + 2 * lane, tx = 2 + 2 * lane;
   const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3], Mob = p.q[4], ke = p.q[5], w = p.q[6], al = p.q[7], L = p.q[8];
   auto zw = [&](int z) { return z < 0 ? z + p.nz : (z >= p.nz ? z - p.nz : z); };  // z in [-nz, 2 nz): no integer division
@@ -417,7 +415,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
 #define B2_LOAD_E(DST, DSTH, Z)                                                                                 \
   {                                                                                                             \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                             \
-      const double* ez_ = u + (int64_t)(k + 1) * cells + (int64_t)zw(Z) * plane;                                \
+      const double* ez_ = u + (int64_t)(k + 1) * p.fs + (int64_t)zw(Z) * plane;                                \
       DST[k] = *reinterpret_cast<const double2*>(ez_ + a_own);                                                  \
       DSTH[k] = e_row ? *reinterpret_cast<const double2*>(ez_ + a_erow) : make_double2(e_col ? ez_[a_ecol] : 0.0, 0.0); \
     }                                                                                                           \
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) st_out<NT>(un + (int64_t)(k + 1) * cells + o, res[k]);
+      for (int k = 0; k < 4; ++k) st_out<NT>(un + (int64_t)(k + 1) * p.fs + o, res[k]);
     }
     __syncthreads();
     // ---- P4: eta(z+1) -> tiles; rotate ----
@@ -580,7 +578,7 @@ __global__ __launch_bounds__(256) void mfd_diag_kernel(const MfdParams p, const 
       const double ca = p.q[0], cb = p.q[1], r2 = p.q[2], kc = p.q[3], ke = p.q[5], w = p.q[6], al = p.q[7];
       const double c = u[i];
       double e[4], h = 0.0, g = 0.0;
-      for (int k = 0; k < 4; ++k) e[k] = u[(k + 1) * cells + i];
+      for (int k = 0; k < 4; ++k) e[k] = u[(k + 1) * p.fs + i];
       for (int k = 0; k < 4; ++k) {
         h = h + hs(e[k]);
         g = g + (e[k] * e[k]) * ((1.0 - e[k]) * (1.0 - e[k]));
@@ -590,7 +588,7 @@ __global__ __launch_bounds__(256) void mfd_diag_kernel(const MfdParams p, const 
       v[0] += c;
       v[1] += (fa * (1.0 - h) + fb * h) + w * g;
       double gr = kc * fwd2(u, x, y, z, p.nx, p.ny, p.nz);
-      for (int k = 0; k < 4; ++k) gr = gr + ke * fwd2(u + (k + 1) * cells, x, y, z, p.nx, p.ny, p.nz);
+      for (int k = 0; k < 4; ++k) gr = gr + ke * fwd2(u + (k + 1) * p.fs, x, y, z, p.nx, p.ny, p.nz);
       v[2] += gr;
       v[3] = fmin(v[3], c);
       v[4] = fmax(v[4], c);
@@ -600,10 +598,10 @@ __global__ __launch_bounds__(256) void mfd_diag_kernel(const MfdParams p, const 
       }
     } else {
       const double lam = p.q[0], W2 = p.q[2];
-      const double U = u[i], ph = u[cells + i], p2 = ph * ph;
+      const double U = u[i], ph = u[p.fs + i], p2 = ph * ph;
       v[0] += 0.5 * (ph + 1.0);
       v[1] += (-0.5 * p2 + 0.25 * (p2 * p2)) + (lam * U) * ph * ((1.0 - (2.0 / 3.0) * p2) + 0.2 * (p2 * p2));
-      v[2] += W2 * fwd2(u + cells, x, y, z, p.nx, p.ny, p.nz);
+      v[2] += W2 * fwd2(u + p.fs, x, y, z, p.nx, p.ny, p.nz);
       v[3] = fmin(v[3], fmin(U, ph));
       v[4] = fmax(v[4], fmax(U, ph));
     }
@@ -646,7 +644,7 @@ __global__ void mfd_diag_final_kernel(const double* __restrict__ partials, int n
 // initial conditions on the lattice (z-extruded); mnx / mny > 0: even extension of a no-flux domain with that many nodes
 __global__ __launch_bounds__(256) void mfd_ic_kernel(const MfdParams p, double* __restrict__ u, double h, int mnx, int mny,
                                                      double a0, double a1, double a2, double a3, double a4) {
-  const int64_t plane = (int64_t)p.nx * p.ny, cells = plane * p.nz;
+  const int64_t plane = (int64_t)p.nx * p.ny;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= plane) return;
   const int x = (int)(i % p.nx), y = (int)(i / p.nx);
@@ -679,7 +677,7 @@ __global__ __launch_bounds__(256) void mfd_ic_kernel(const MfdParams p, double* 
       val[1] = a4 + 0.5 * (a3 - a4) * (1.0 + cos(3.14159265358979323846 * (r - a1 + 0.5 * a2) / a2));
   }
   for (int f = 0; f < nf; ++f)
-    for (int z = 0; z < p.nz; ++z) u[f * cells + z * plane + i] = val[f];
+    for (int z = 0; z < p.nz; ++z) u[f * p.fs + z * plane + i] = val[f];
 }
 
 }  // namespace
@@ -687,6 +685,7 @@ __global__ __launch_bounds__(256) void mfd_ic_kernel(const MfdParams p, double* 
 struct MultiFD {
   MfdParams p;
   int64_t cells = 0;
+  unsigned char* block = nullptr;   // the library's own two time levels (null: the caller's buffers)
   double h = 1.0;
   double* u[2] = {nullptr, nullptr};
   double* mu = nullptr;
@@ -741,14 +740,27 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, dou
   mf->cells = (int64_t)nx * ny * nz;
   mf->stream = stream;
   auto body = [&]() -> int {
-    const size_t bytes = sizeof(double) * (size_t)mf->cells * p.nf;
+    size_t bytes = sizeof(double) * (size_t)mf->cells * p.nf;
+    p.fs = mf->cells;
     if (ext0 && ext1) {
       mf->u[0] = ext0;
       mf->u[1] = ext1;
       mf->own_u = false;
     } else {
-      MF_HIP(pf_malloc(&mf->u[0], bytes));
-      MF_HIP(pf_malloc(&mf->u[1], bytes));
+      // Both time levels from ONE block (csrc/device_alloc.hip: physically contiguous, so distances inside it are physical
+      // distances).  At 512^3 a field is exactly 1 GiB, and the 2 nf streams of a step (every field read and written) would
+      // all share their low 30 address bits: fields are spaced 68 KiB further apart and the second level starts 64 KiB
+      // after a 512 KiB boundary (the distance that serves the BM1 kernel, pfhip_api.hip placed_offset_bytes).  Worth
+      // 1.5 % for BM3 (0.787 -> 0.775 ms) and 0.5 % for BM2 on contiguous memory, 13 combinations scanned
+      // (profiles/r04/mfd_placement_scan.log) -- on this memory system the big effect is WHERE a block lies, not how its
+      // parts are spaced.  The caller's buffers (slab mode) keep their dense layout: fs = cells.
+      const int64_t fpad = 68 * 1024, off = 64 * 1024;
+      p.fs = mf->cells + fpad / (int64_t)sizeof(double);
+      bytes = sizeof(double) * (size_t)p.fs * p.nf;
+      const size_t lvl = (bytes + (512u << 10) - 1) / (512u << 10) * (512u << 10) + (size_t)off;
+      MF_HIP(pf_malloc(&mf->block, lvl + bytes));
+      mf->u[0] = reinterpret_cast<double*>(mf->block);
+      mf->u[1] = reinterpret_cast<double*>(mf->block + lvl);
     }
     MF_HIP(hipMemsetAsync(mf->u[0], 0, bytes, stream));
     MF_HIP(hipMemsetAsync(mf->u[1], 0, bytes, stream));
@@ -772,7 +784,7 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, dou
 void multifd_destroy(MultiFD* mf) {
   if (!mf) return;
   if (!mf->own_u) mf->u[0] = mf->u[1] = nullptr;
-  for (void* q : {(void*)mf->u[0], (void*)mf->u[1], (void*)mf->mu, (void*)mf->partials, (void*)mf->out5})
+  for (void* q : {(void*)mf->block, (void*)mf->mu, (void*)mf->partials, (void*)mf->out5})
     if (q) (void)pf_free(q);
   if (mf->out5_host) (void)hipHostFree(mf->out5_host);
   delete mf;
@@ -789,10 +801,10 @@ int multifd_set_ic(MultiFD* mf, int mnx, int mny, const double* a) {
   return 0;
 }
 
-double* multifd_field_base(MultiFD* mf, int f) { return mf->u[mf->cur] + (int64_t)f * mf->cells; }
+double* multifd_field_base(MultiFD* mf, int f) { return mf->u[mf->cur] + (int64_t)f * mf->p.fs; }
 int multifd_cur_index(const MultiFD* mf) { return mf->cur; }
 double* multifd_field_ptr(MultiFD* mf, int f) {   // the owned planes
-  return mf->u[mf->cur] + (int64_t)f * mf->cells + (int64_t)mf->p.gz * mf->p.nx * mf->p.ny;
+  return mf->u[mf->cur] + (int64_t)f * mf->p.fs + (int64_t)mf->p.gz * mf->p.nx * mf->p.ny;
 }
 void multifd_touch(MultiFD* mf) { mf->have_prev = false; }
 
