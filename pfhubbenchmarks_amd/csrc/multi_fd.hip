@@ -686,6 +686,7 @@ struct MultiFD {
   MfdParams p;
   int64_t cells = 0;
   unsigned char* block = nullptr;   // the library's own two time levels (null: the caller's buffers)
+  int ncu = 256;
   double h = 1.0;
   double* u[2] = {nullptr, nullptr};
   double* mu = nullptr;
@@ -737,6 +738,10 @@ int multifd_create(MultiFD** out, int model, int nx, int ny, int nz, int gz, dou
     p.q[3] = mp[2];
   }
   mf->h = h;
+  {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) mf->ncu = n;
+  }
   mf->cells = (int64_t)nx * ny * nz;
   mf->stream = stream;
   auto body = [&]() -> int {
@@ -817,7 +822,10 @@ int multifd_streaming(const MultiFD* mf) {
   return mf->use_stream && p.nz >= 4 && p.nx % SX == 0 && p.ny % 16 == 0;   // tile heights: 16 (BM3), 8 / 4 (BM2 passes), 8 (one-pass BM2)
 }
 namespace {
-// z-chunks so that the grid holds about 4 workgroups per CU; planes [zlo, zhi) of the box
+// z-chunks so that the grid holds ONE workgroup per CU; planes [zlo, zhi) of the box.  Measured at 512^3 (BM3,
+// profiles/r04/mfd_bm3_grid_scan.log): 256 workgroups 0.743 ms, 512: 0.755, 768: 0.760, 1024 (rounds 3-4a): 0.775, 3072: 0.753,
+// 128: 1.23 -- four waves per CU already keep enough bytes in flight (the next plane is requested a plane ahead), and every
+// further workgroup is another set of streams for the DRAM pages and another z-chunk boundary whose halo planes are read twice.
 template <int PASS>
 void launch_stream(const MultiFD* mf, const double* u, const double* mu, double* out, double dt, int zlo, int zhi) {
   MfdParams p = mf->p;
@@ -826,7 +834,7 @@ void launch_stream(const MultiFD* mf, const double* u, const double* mu, double*
   const int nzr = zhi - zlo;
   constexpr int TY = 4 * PassTraits<PASS>::RPT;
   const int tiles = (p.nx / SX) * (p.ny / TY);
-  int nchunk = (4 * 256 + tiles - 1) / tiles;
+  int nchunk = (mf->ncu + tiles - 1) / tiles;
   if (nchunk > nzr / 8) nchunk = nzr / 8 > 0 ? nzr / 8 : 1;
   const int zchunk = (nzr + nchunk - 1) / nchunk;
   nchunk = (nzr + zchunk - 1) / zchunk;
