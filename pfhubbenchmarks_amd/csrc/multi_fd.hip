@@ -139,18 +139,18 @@ constexpr int SX = 128, SPITCH = 132;   // tile width; LDS row pitch (own cells 
 template <int PASS>
 struct PassTraits;
 template <>
-struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 4, MINW = 3; };   // stencilled fields, pointwise inputs, rows per thread, waves per SIMD asked of the register allocator
+struct PassTraits<30> { static constexpr int NS = 2, NPW = 0, RPT = 4, MINW = 1, AHEAD = 2; };   // (AHEAD = 3: 0.6905 vs 0.6942 ms at 254 VGPRs + AGPRs -- not worth the registers)   // stencilled fields, pointwise inputs, rows per thread, waves per SIMD asked of the register allocator
 template <>
-struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2, MINW = 1; };
+struct PassTraits<20> { static constexpr int NS = 1, NPW = 4, RPT = 2, MINW = 1, AHEAD = 1; };
 template <>
-struct PassTraits<21> { static constexpr int NS = 5, NPW = 1, RPT = 1, MINW = 1; };
+struct PassTraits<21> { static constexpr int NS = 5, NPW = 1, RPT = 1, MINW = 1, AHEAD = 1; };
 
 template <int PASS, bool NT>
 __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel(const MfdParams p, const double* __restrict__ u,
                                                          const double* __restrict__ mu_in, double* __restrict__ out,
                                                          double dt, int zchunk) {
   using T = PassTraits<PASS>;
-  constexpr int NS = T::NS, NPW = T::NPW, RPT = T::RPT, TY = 4 * RPT;
+  constexpr int NS = T::NS, NPW = T::NPW, RPT = T::RPT, TY = 4 * RPT, AH = T::AHEAD;   // AH: planes between request and use
   __shared__ __attribute__((aligned(16))) double tile[NS][TY + 2][SPITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // XCD-aware tile order (as in bm2_fused_kernel below): every XCD gets a contiguous run of tiles, so that the halo rows a
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
   };
   auto pfield = [&](int k) -> const double* { return PASS == 20 ? u + (int64_t)(k + 1) * p.fs : u; };  // eta_k / c
   double2 zm[NS][RPT], zc[NS][RPT], zp[NS][RPT];   // own cells in planes z-1, z, z+1
+  double2 zq[NS][RPT], zr[NS][RPT];                // AH >= 2: plane z+2 (AH == 3: and z+3), in flight
   const int64_t own = (int64_t)(y0 + wave * RPT) * row + xo;
 #define MFD_LOAD_OWN(DST, Z)                                                                                     \
   {                                                                                                              \
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
   const int yh = wrapm(wave == 0 ? y0 - 1 : y0 + TY, p.ny);
   const int yy = y0 + (do_col ? (lane >> 1) : 0), xh = wrapm((lane & 1) ? x0 + SX : x0 - 1, p.nx);
   const int64_t arow0 = (int64_t)yh * row + xo, acol0 = (int64_t)yy * row + xh;
-  double2 hrow[NS], hrow_n[NS];
-  double hcol[NS], hcol_n[NS];
+  double2 hrow[NS], hrow_n[NS], hrow_q[NS], hrow_r[NS];
+  double hcol[NS], hcol_n[NS], hcol_q[NS], hcol_r[NS];
 #define MFD_LOAD_HALO(HR, HC, Z)                                                                                 \
   {                                                                                                              \
     const int64_t zo_ = (int64_t)wrapm((Z), p.nz) * plane;                                                       \
@@ -202,9 +203,25 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
     }                                                                                                            \
   }
   MFD_LOAD_HALO(hrow, hcol, zb)
+  if (AH >= 2) {
+    MFD_LOAD_OWN(zp, zb + 1)
+    MFD_LOAD_HALO(hrow_n, hcol_n, zb + 1)
+  }
+  if (AH == 3) {
+    MFD_LOAD_OWN(zq, zb + 2)
+    MFD_LOAD_HALO(hrow_q, hcol_q, zb + 2)
+  }
   for (int z = zb; z < ze; ++z) {
-    MFD_LOAD_OWN(zp, z + 1)
-    MFD_LOAD_HALO(hrow_n, hcol_n, z + 1)
+    if (AH == 3) {
+      MFD_LOAD_OWN(zr, z + 3)
+      MFD_LOAD_HALO(hrow_r, hcol_r, z + 3)
+    } else if (AH == 2) {   // one workgroup per CU (launch_stream): two planes in flight keep the memory pipe as full as four waves can
+      MFD_LOAD_OWN(zq, z + 2)
+      MFD_LOAD_HALO(hrow_q, hcol_q, z + 2)
+    } else {
+      MFD_LOAD_OWN(zp, z + 1)
+      MFD_LOAD_HALO(hrow_n, hcol_n, z + 1)
+    }
     double2 pw[NPW > 0 ? NPW : 1][RPT];
 #pragma unroll
     for (int k = 0; k < NPW; ++k)
@@ -319,9 +336,19 @@ __global__ __launch_bounds__(256, PassTraits<PASS>::MINW) void mfd_stream_kernel
       for (int r = 0; r < RPT; ++r) {
         zm[s][r] = zc[s][r];
         zc[s][r] = zp[s][r];
+        if (AH >= 2) zp[s][r] = zq[s][r];
+        if (AH == 3) zq[s][r] = zr[s][r];
       }
       hrow[s] = hrow_n[s];
       hcol[s] = hcol_n[s];
+      if (AH >= 2) {
+        hrow_n[s] = hrow_q[s];
+        hcol_n[s] = hcol_q[s];
+      }
+      if (AH == 3) {
+        hrow_q[s] = hrow_r[s];
+        hcol_q[s] = hcol_r[s];
+      }
     }
   }
 #undef MFD_LOAD_OWN
@@ -826,6 +853,7 @@ namespace {
 // profiles/r04/mfd_bm3_grid_scan.log): 256 workgroups 0.743 ms, 512: 0.755, 768: 0.760, 1024 (rounds 3-4a): 0.775, 3072: 0.753,
 // 128: 1.23 -- four waves per CU already keep enough bytes in flight (the next plane is requested a plane ahead), and every
 // further workgroup is another set of streams for the DRAM pages and another z-chunk boundary whose halo planes are read twice.
+// With one workgroup per CU the BM3 kernel keeps TWO planes in flight (PassTraits<30>::AHEAD): 0.742 -> 0.694 ms (frac 0.77).
 template <int PASS>
 void launch_stream(const MultiFD* mf, const double* u, const double* mu, double* out, double dt, int zlo, int zhi) {
   MfdParams p = mf->p;
