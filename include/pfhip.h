@@ -333,7 +333,9 @@ int pfk_ch_fd_step(const double* c_in, double* c_out, const double* phi, int nx,
  * key 3 = largest number of 2-D time steps fused into one launch (1, 2 or 4); key 4 = 10 K + rows per wave of the 2-D
  * K-step kernel; keys 5 / 6 = workgroups per CU / kernel form of pfk_stream_copy; key 7 = workgroups per pfk_push_planes
  * message; key 8 = diagnostics kernel form (10 x rows per wave + planes in flight; 0 = the round-1 kernel); key 9 = its
- * target workgroup count; key 10 = 0 / 1: plain / non-temporal (default) stores of the output planes of the BM2 / BM3 streaming kernels */
+ * target workgroup count; key 10 = 0 / 1: plain / non-temporal (default) stores of the output planes of the BM2 / BM3 streaming kernels;
+ * key 11 = TEST HOOK: every new device allocation of the library is filled with this byte (0 .. 255; -1 = off) -- results must not
+ * depend on it */
 int pfk_set_tuning(int key, int value);
 
 /* Device memory with the placement policy the library uses for its own arrays (csrc/device_alloc.hip; no counterpart in the

@@ -106,7 +106,23 @@ hipError_t scatter_alloc(void** out, size_t bytes, size_t piece) {
 
 }  // namespace
 
+// TEST HOOK (pfk_set_tuning key 11): fill every new allocation with this byte (-1 = off).  Fresh processes get zero pages
+// from the driver, recycled memory is anything: a kernel that reads what nobody wrote passes every test of a fresh process
+// and fails in the field (csrc/fem_be.hip did, round 4).  tests/test_gpu_parity.py runs every scheme with a finite pattern.
+int g_alloc_fill = -1;
+void pf_alloc_set_fill(int byte) { g_alloc_fill = byte < 0 ? -1 : (byte & 0xFF); }
+
+static hipError_t pf_malloc_bytes_raw(void** p, size_t bytes);
 hipError_t pf_malloc_bytes(void** p, size_t bytes) {
+  hipError_t r = pf_malloc_bytes_raw(p, bytes);
+  if (r == hipSuccess && g_alloc_fill >= 0) {
+    r = hipMemset(*p, g_alloc_fill, bytes);
+    if (r == hipSuccess) r = hipDeviceSynchronize();   // (the library initialises on its own non-blocking streams)
+  }
+  return r;
+}
+
+static hipError_t pf_malloc_bytes_raw(void** p, size_t bytes) {
   *p = nullptr;
   const Policy pol = policy();
   if (bytes >= kScatterMin && pol.mode == 2) {

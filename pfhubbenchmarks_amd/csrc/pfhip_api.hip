@@ -1720,6 +1720,10 @@ int pfk_set_tuning(int key, int value) {
     set_diag_tuning(value, 0);
     return PF_OK;
   }
+  if (key == 11 && value >= -1 && value <= 255) {  // TEST HOOK: fill every new device allocation with this byte (-1 = off)
+    pf_alloc_set_fill(value);
+    return PF_OK;
+  }
   if (key == 10 && (value == 0 || value == 1)) {  // BM2 / BM3 streaming kernels: non-temporal stores of the output planes
     multifd_set_nt(value);
     return PF_OK;

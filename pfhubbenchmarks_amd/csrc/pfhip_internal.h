@@ -19,6 +19,7 @@ inline hipError_t pf_malloc(T** p, size_t bytes) {
   return pf_malloc_bytes(reinterpret_cast<void**>(p), bytes);
 }
 std::string pf_alloc_describe();
+void pf_alloc_set_fill(int byte);   // test hook: fill new allocations with a byte pattern (-1 = off)
 // stream_util.hip: streams that do not share a hardware queue with the streams they are meant to run beside
 bool pf_streams_overlap(hipStream_t a, hipStream_t b);
 hipError_t pf_acquire_stream(const hipStream_t* avoid, int navoid, hipStream_t* out, bool* found);

@@ -910,6 +910,74 @@ def test_bm6_fd_scheme_converges_to_the_reference_algorithm(lib):
     assert abs(fem[1] - fem[0]) > 5e-4 * fem[0]
 
 
+def test_no_scheme_reads_memory_that_nobody_wrote(lib):
+    """Fresh processes get zero pages from the driver; recycled memory holds anything.  With the test hook of the allocator
+    (pfk_set_tuning key 11: every new device allocation filled with a byte pattern -- 0x3F.. is the double 4.8e-4, 0xFF.. a
+    NaN) every scheme must return BIT-identical fields and diagnostics: explicit FD (2-D multi-step, 3-D fused, mirror box),
+    spectral (2-D, 3-D power-of-two with chunked passes, mixed radix, BM6), BM6 FD + Poisson (periodic and the reference's
+    boundary conditions), BM2 / BM3 explicit FD (cell kernels and streaming kernels), diagnostics included."""
+    rng = np.random.default_rng(23)
+
+    def cases():
+        yield dict(dim=2, n=(128, 96), h=1.0, scheme="fd"), 1e-3
+        yield dict(dim=3, n=(128, 64, 48), h=1.0, scheme="fd"), 1e-3
+        yield dict(dim=3, n=(33, 17, 9), h=1.0, scheme="fd", bc="mirror"), 1e-3
+        yield dict(dim=2, n=(512, 128), h=1.0, scheme="spectral"), 1e-2
+        yield dict(dim=3, n=(128, 128, 256), h=1.0, scheme="spectral"), 1e-2
+        yield dict(dim=3, n=(40, 96, 200), h=1.0, scheme="spectral"), 1e-2
+        yield dict(dim=3, n=(128, 128, 128), h=1.0, scheme="spectral", model="bm6"), 1e-2
+        yield dict(dim=3, n=(128, 128, 128), h=1.0, scheme="fd", model="bm6"), 5e-4
+        yield dict(dim=3, n=(65, 17, 13), h=1.0, scheme="fd", model="bm6", bc="mirror"), 5e-4
+        yield dict(dim=2, n=(65, 33), h=1.0, scheme="fd", model="bm6", bc="mirror"), 5e-4
+
+    def run(fill):
+        assert lib.pfk_set_tuning(11, fill) == 0
+        out = []
+        try:
+            os.environ["PFHIP_SPECTRAL_3D"] = "lds"
+            os.environ["PFHIP_FFT3D_CHUNK"] = "24,2"
+            for kw, dt in cases():
+                shape = tuple(kw["n"])[::-1]
+                c0 = 0.5 + 0.05 * np.random.default_rng(len(out)).standard_normal(shape)
+                with PhaseFieldSolver(**kw) as s:
+                    s.set_c(c0)
+                    d0 = np.array(s.diagnostics())
+                    s.step(dt, 3)
+                    out.append((kw, s.get_c(), d0, np.array(s.diagnostics())))
+            for model, n in (("bm2", (128, 32, 8)), ("bm3", (128, 32, 8)), ("bm2", (40, 24)), ("bm3", (48, 40))):
+                with PhaseFieldSolver(dim=len(n), n=n, h=1.0, scheme="fd", model=model) as s:
+                    (s.set_ic_bm2 if model == "bm2" else s.set_ic_bm3)()
+                    s.step(1e-3, 3)
+                    out.append(((model, n), s.get_c() if model == "bm2" else s.get_field("phi"), None, np.array(s.diagnostics())))
+        finally:
+            os.environ.pop("PFHIP_SPECTRAL_3D", None)
+            os.environ.pop("PFHIP_FFT3D_CHUNK", None)
+            assert lib.pfk_set_tuning(11, -1) == 0
+        return out
+    import ctypes as C
+    import os
+    import torch
+
+    class Raw:      # a raw device pointer as a CUDA array (to look at what pf_device_malloc returned)
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+    assert lib.pfk_set_tuning(11, 0x3F) == 0           # the hook is live: a new allocation comes back filled
+    ptr = C.c_void_p()
+    assert lib.pf_device_malloc(C.byref(ptr), C.c_size_t(8 * 4096)) == 0
+    seen = torch.as_tensor(Raw(ptr.value, 4096), device="cuda").cpu().numpy().copy()
+    assert lib.pf_device_free(ptr) == 0 and lib.pfk_set_tuning(11, -1) == 0
+    assert (seen.view(np.uint8) == 0x3F).all()
+    ref = run(-1)
+    for fill in (0x3F, 0xFF):
+        got = run(fill)
+        for (kw, c, d0, d1), (_, c2, e0, e1) in zip(ref, got):
+            np.testing.assert_array_equal(c, c2, err_msg="fill 0x%02X %r" % (fill, kw))
+            np.testing.assert_array_equal(d1, e1, err_msg="fill 0x%02X %r" % (fill, kw))
+            if d0 is not None:
+                np.testing.assert_array_equal(d0, e0, err_msg="fill 0x%02X %r" % (fill, kw))
+    del rng
+
+
 def test_fem_be_does_not_depend_on_what_the_memory_held_before(lib):
     """A BE-parity run must not depend on the history of the process.  Round 4: the same BM2 run (200 intervals, dt = 0.01,
     t = 0.02) returned F = 5405.5 in a fresh process and 4088.6 right after explicit-FD handles had used and freed device
