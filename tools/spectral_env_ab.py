@@ -31,7 +31,6 @@ for rnd in range(a.rounds):
     for name, env in forms:
         for k in allkeys:
             os.environ.pop(k, None)
-        os.environ.setdefault("PFHIP_SPEC_PROBE", "0")
         os.environ.update(env)
         scheme = "spectral" if a.model == "bm1" else "fd"
         import torch

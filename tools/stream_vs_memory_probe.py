@@ -13,8 +13,10 @@ ap.add_argument("--handles", type=int, default=5)
 ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--keep", type=int, default=0, help="keep the previous handle alive while the next is timed")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--chunked", action="store_true", help="leave PFHIP_FFT3D_CHUNK alone (default: whole-box passes, the placement-sensitive form)")
 a = ap.parse_args()
-os.environ.setdefault("PFHIP_FFT3D_CHUNK", "0")
+if not a.chunked:
+    os.environ.setdefault("PFHIP_FFT3D_CHUNK", "0")
 import torch
 from pfhubbenchmarks_amd.solver import PhaseFieldSolver
 
