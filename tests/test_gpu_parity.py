@@ -983,8 +983,9 @@ def test_fem_be_does_not_depend_on_what_the_memory_held_before(lib):
     t = 0.02) returned F = 5405.5 in a fresh process and 4088.6 right after explicit-FD handles had used and freed device
     memory -- hipMalloc recycles memory within a process and the dense levels read tile remainders they never write
     (zero pages on a fresh process).  Every create-time allocation of csrc/fem_be.hip is zeroed now: the run before and
-    the run after a batch of other handles (FD lattices of two sizes, a spectral box, fields full of ones) are
-    BIT-identical, for BM2 and for BM1."""
+    the run after a batch of other handles (FD lattices of two sizes, a spectral box, fields full of ones) agree to
+    1e-12 relative for BM2 and for BM1 (the library GEMMs of the dense levels are not bitwise reproducible from call to
+    call: 1 ulp differences occur; the defect was 25 %)."""
     from pfhubbenchmarks_amd import verification as V
     ts = (0.02,)
     before = V.multi_energy("bm2", "fem_be", 200, 0.01, ts)
@@ -1001,11 +1002,11 @@ def test_fem_be_does_not_depend_on_what_the_memory_held_before(lib):
         s.set_c(np.ones((512, 512)))
         s.step(1e-2, 2)
     after = V.multi_energy("bm2", "fem_be", 200, 0.01, ts)
-    np.testing.assert_array_equal(before, after)
+    np.testing.assert_allclose(after, before, rtol=1e-12, atol=0.0)
     with PhaseFieldSolver(dim=2, n=201, h=1.0, bc="mirror", scheme="fem_be") as s:
         s.set_ic_bm1()
         s.step(0.1, 1, check=True)
-        np.testing.assert_array_equal(b1, np.array(s.diagnostics()))
+        np.testing.assert_allclose(np.array(s.diagnostics()), b1, rtol=1e-12, atol=1e-12)
     assert abs(before[0, 0] - 5405.51233352) <= 1e-8 * 5405.5     # (the fresh-process value, profiles/r04/fem_be_order_dependence.log)
 
 
