@@ -1187,18 +1187,6 @@ struct FemBE {
   std::string err;
 };
 
-// Every create-time allocation of this mode starts ZEROED.  hipMalloc hands back recycled memory within a process, and the
-// dense levels read pad rows / tile remainders they never write: on a fresh process those are zero pages (the state every
-// parity test of rounds 2-4 ran in); after another handle of the same process had used the memory, one BM2 run at
-// 200 intervals came back with F = 4088.6 instead of 5405.5 (round 4, found when the explicit-FD handles of the same test
-// changed their allocation sizes; tests/test_gpu_parity.py::test_fem_be_does_not_depend_on_what_the_memory_held_before).
-template <class T>
-static hipError_t fb_malloc_zero(T** p, size_t bytes) {
-  hipError_t e = hipMalloc(p, bytes);
-  if (e != hipSuccess) return e;
-  return hipMemset(*p, 0, bytes);
-}
-
 #define FB_HIP(expr)                                                       \
   do {                                                                     \
     hipError_t e_ = (expr);                                                \
@@ -1346,14 +1334,14 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       FB_HIP(hipMemset(*f, 0, nb));
     }
     const size_t bs = sizeof(double) * (size_t)p.nb * p.nb * p.ng;
-    FB_HIP(fb_malloc_zero(&fb->D, bs));
-    FB_HIP(fb_malloc_zero(&fb->Lo, bs));
-    FB_HIP(fb_malloc_zero(&fb->Up, bs));
-    FB_HIP(fb_malloc_zero(&fb->Lo2, bs));
-    FB_HIP(fb_malloc_zero(&fb->Up2, bs));
-    FB_HIP(fb_malloc_zero(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
-    FB_HIP(fb_malloc_zero(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
-    FB_HIP(fb_malloc_zero(&fb->tflags, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
+    FB_HIP(hipMalloc(&fb->D, bs));
+    FB_HIP(hipMalloc(&fb->Lo, bs));
+    FB_HIP(hipMalloc(&fb->Up, bs));
+    FB_HIP(hipMalloc(&fb->Lo2, bs));
+    FB_HIP(hipMalloc(&fb->Up2, bs));
+    FB_HIP(hipMalloc(&fb->tinv, sizeof(double) * (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16) * 2 * 256));  // TS_NB = 16 (lu_diag_inv_kernel)
+    FB_HIP(hipMalloc(&fb->tperm, sizeof(int) * (size_t)(p.ng / 2 + 1) * p.nb));
+    FB_HIP(hipMalloc(&fb->tflags, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
     FB_HIP(hipMemset(fb->tflags, 0, sizeof(int) * (256 + (size_t)(p.ng / 2 + 1) * ((p.nb + 15) / 16))));
     {
       const char* e = getenv("PFHIP_FEM_SOLVER");
@@ -1375,17 +1363,17 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
       fb->verbose = v && v[0] == '1';
     }
     fb->vec_len = condensed ? (size_t)p.nn * nf : (size_t)p.nb * p.ng;
-    FB_HIP(fb_malloc_zero(&fb->rhs, sizeof(double) * fb->vec_len));
+    FB_HIP(hipMalloc(&fb->rhs, sizeof(double) * fb->vec_len));
     if (condensed) {
-      FB_HIP(fb_malloc_zero(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
-      FB_HIP(fb_malloc_zero(&fb->fac, sizeof(double) * (size_t)(p.ng / 2 + 1) * n1 * 3 * nf * nf));
+      FB_HIP(hipMalloc(&fb->Aloc, sizeof(double) * (size_t)N * N * 25 * nf * nf));
+      FB_HIP(hipMalloc(&fb->fac, sizeof(double) * (size_t)(p.ng / 2 + 1) * n1 * 3 * nf * nf));
       const char* b0 = getenv("PFHIP_FEM_BAND0");  // "0": dense rocSOLVER / rocBLAS kernels on the first level too (A/B)
       fb->band0 = !(b0 && b0[0] == '0');
     }
-    FB_HIP(fb_malloc_zero(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
-    FB_HIP(fb_malloc_zero(&fb->info, sizeof(rocblas_int) * p.ng));
-    FB_HIP(fb_malloc_zero(&fb->scal, sizeof(double) * 4));
-    FB_HIP(fb_malloc_zero(&fb->partials, sizeof(double) * 3 * 256));
+    FB_HIP(hipMalloc(&fb->piv, sizeof(rocblas_int) * (size_t)p.nb * p.ng));
+    FB_HIP(hipMalloc(&fb->info, sizeof(rocblas_int) * p.ng));
+    FB_HIP(hipMalloc(&fb->scal, sizeof(double) * 4));
+    FB_HIP(hipMalloc(&fb->partials, sizeof(double) * 3 * 256));
     FB_HIP(hipHostMalloc(&fb->scal_host, sizeof(double) * 4, hipHostMallocDefault));
     FB_BLAS(rocblas_create_handle(&fb->bh));
     FB_BLAS(rocblas_set_stream(fb->bh, stream));
@@ -1446,6 +1434,12 @@ int fembe_create(FemBE** out, int nodes_per_side, double h, int nf, double rho, 
     return 0;
   };
   int rc = body();
+  // the create-time hipMemsets run on the legacy default stream, asynchronously to the host, and do not order against the
+  // non-blocking handle stream: wait for them before anybody launches on it (see fembe_create_model)
+  if (rc == 0 && hipDeviceSynchronize() != hipSuccess) {
+    fb->err = "hipDeviceSynchronize failed at the end of fembe_create";
+    rc = -3;
+  }
   if (rc && err) *err = fb->err;
   return rc;
 }
@@ -1546,17 +1540,22 @@ int fembe_create_model(FemBE** out, int model, int nodes_per_side, double h, con
   fb->u0.u[2] = fb->phi0;
   const size_t nbytes = sizeof(double) * fb->p.nn;
   for (int f = 3; f < nf; ++f) {
-    FB_HIP(fb_malloc_zero(&fb->u.u[f], nbytes));
-    FB_HIP(fb_malloc_zero(&fb->u0.u[f], nbytes));
+    FB_HIP(hipMalloc(&fb->u.u[f], nbytes));
+    FB_HIP(hipMalloc(&fb->u0.u[f], nbytes));
     FB_HIP(hipMemset(fb->u.u[f], 0, nbytes));
     FB_HIP(hipMemset(fb->u0.u[f], 0, nbytes));
   }
   for (int f = nf; f < MAXF; ++f) fb->u.u[f] = fb->u0.u[f] = nullptr;
-  FB_HIP(fb_malloc_zero(&fb->rhs0, sizeof(double) * fb->vec_len));
-  FB_HIP(fb_malloc_zero(&fb->rhs1, sizeof(double) * fb->vec_len));
+  FB_HIP(hipMalloc(&fb->rhs0, sizeof(double) * fb->vec_len));
+  FB_HIP(hipMalloc(&fb->rhs1, sizeof(double) * fb->vec_len));
   // the reference's SNES line search: 'cp' for BM2 (bench2.py:140), 'basic' for BM3 (bench3.py:124)
   fb->line_search = model == 2 ? 1 : 0;
   if (const char* e = getenv("PFHIP_FEM_LINESEARCH")) fb->line_search = std::string(e) == "cp" ? 1 : 0;
+  // hipMemset is asynchronous to the host and runs on the legacy default stream, which does NOT order against fb->stream
+  // (hipStreamNonBlocking): without this wait the memsets above could land AFTER the initial-condition kernel that the
+  // caller launches next -- round 4 saw a BM2 run start from eta_2..4 = 0 (F = 4088.6 instead of 5405.5, C unchanged) when
+  // the allocation pattern of the process changed (profiles/r04/fem_be_order_dependence.log)
+  FB_HIP(hipDeviceSynchronize());
   return 0;
 }
 

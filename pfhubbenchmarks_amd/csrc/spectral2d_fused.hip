@@ -1480,7 +1480,8 @@ int fused2d_create(Fused2D** out, int nx, int ny, int nz, double h, hipStream_t 
   if (f->mixed) f->row512 = f->col512 = false;
   if (f->cube512) {
     if (pf_malloc(&f->queues, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess ||
-        hipMemset(f->queues, 0, sizeof(int) * 2 * 8 * QSTRIDE) != hipSuccess)
+        hipMemsetAsync(f->queues, 0, sizeof(int) * 2 * 8 * QSTRIDE, stream) != hipSuccess)   // (on the handle's stream: a
+                                                // default-stream hipMemset is asynchronous and does not order against it)
       return -3;
     int dev = 0;
     hipDeviceProp_t prop;

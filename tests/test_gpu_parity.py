@@ -980,12 +980,13 @@ def test_no_scheme_reads_memory_that_nobody_wrote(lib):
 
 def test_fem_be_does_not_depend_on_what_the_memory_held_before(lib):
     """A BE-parity run must not depend on the history of the process.  Round 4: the same BM2 run (200 intervals, dt = 0.01,
-    t = 0.02) returned F = 5405.5 in a fresh process and 4088.6 right after explicit-FD handles had used and freed device
-    memory -- hipMalloc recycles memory within a process and the dense levels read tile remainders they never write
-    (zero pages on a fresh process).  Every create-time allocation of csrc/fem_be.hip is zeroed now: the run before and
-    the run after a batch of other handles (FD lattices of two sizes, a spectral box, fields full of ones) agree to
-    1e-12 relative for BM2 and for BM1 (the library GEMMs of the dense levels are not bitwise reproducible from call to
-    call: 1 ulp differences occur; the defect was 25 %)."""
+    t = 0.02) returned F = 5405.5 in a fresh process and 4088.6 (same C) after explicit-FD handles and three smaller BE
+    handles of the same process -- the create-time hipMemsets of csrc/fem_be.hip run on the legacy default stream,
+    asynchronously to the host, and one of them landed AFTER the initial-condition kernel that the caller launches on the
+    handle's non-blocking stream (eta_2..4 = 0).  fembe_create now waits for the device before it returns.  (Filling every
+    array of the mode with garbage changes nothing: it reads no memory it did not write, profiles/r04/fem_be_order_dependence.log.)
+    The run before and the run after a batch of other handles agree to 1e-12 relative for BM2 and for BM1 (the library GEMMs of
+    the dense levels are not bitwise reproducible from call to call: 1 ulp differences occur; the defect was 25 %)."""
     from pfhubbenchmarks_amd import verification as V
     ts = (0.02,)
     before = V.multi_energy("bm2", "fem_be", 200, 0.01, ts)
@@ -994,6 +995,8 @@ def test_fem_be_does_not_depend_on_what_the_memory_held_before(lib):
         s.step(0.1, 1, check=True)
         b1 = np.array(s.diagnostics())
     V.multi_fd_limit("bm2", ts)                                   # explicit-FD handles on 200^2 / 400^2 lattices, created and freed
+    for d in (0.01, 0.005, 0.0025):                               # ... and the sequence that exposed it
+        V.multi_energy("bm2", "fem_be", 100, d, ts)
     for n in (256, 384):
         with PhaseFieldSolver(dim=3, n=(n, 64, 32), h=1.0, scheme="fd") as s:
             s.set_c(np.ones((32, 64, n)))
