@@ -312,6 +312,9 @@ class HipSlabEngine:
         cfg.ext_c[1] = C.c_void_p(self.buffers[1].data_ptr())
         self.cfg = cfg
         self._h = C.c_void_p()
+        # torch.zeros filled the buffers on torch's current stream; the engine's stream is non-blocking and does not order
+        # against it by itself -- without this the fill could land after the library's first writes (initial condition)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
         self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         lay = _lib.PfHaloLayout()
@@ -443,6 +446,7 @@ class IpcHaloTransport:
         self.timeout = _Words(to.value)      # mapped host int32: device address == host address (HIP unified addressing)
         self.tickets = torch.zeros(2, dtype=torch.int32, device=dev)
         self.side = torch.cuda.Stream(device=dev)
+        self.side.wait_stream(torch.cuda.current_stream(dev))     # (the fill above runs on torch's current stream)
         self.seq = 0
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         off1 = (engine.buffers[1].data_ptr() - engine.buffers[0].data_ptr()) // 8
@@ -747,6 +751,9 @@ class HipMultiFieldSlabEngine:
         cfg.ext_c[1] = C.c_void_p(self.buffers[1].data_ptr())
         self.cfg = cfg
         self._h = C.c_void_p()
+        # torch.zeros filled the buffers on torch's current stream; the engine's stream is non-blocking and does not order
+        # against it by itself -- without this the fill could land after the library's first writes (initial condition)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
         self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         lay = _lib.PfHaloLayout()
@@ -962,6 +969,7 @@ class HipFFTSlabEngine(HipSlabEngine):
             self.tensors[self.phi.data_ptr()] = self.phi
         self.cfg = cfg
         self._h = C.c_void_p()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))   # (the torch.zeros fills above; see HipSlabEngine)
         _lib.check(self._lib.pf_create(C.byref(cfg), C.byref(self._h)))
         self.status = (self._lib.pf_status_string(self._h) or b"").decode()   # which kernels / transform path run
         self.rank_lo = (rank - 1) % nranks
