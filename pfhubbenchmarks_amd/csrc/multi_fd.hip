@@ -405,45 +405,56 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
              e_col = wave == 7 && lane < 2 * B2TY;
   // c halo row of this wave: y0-2, y0-1, y0+TY, y0+TY+1 -> ring rows 0, 1, TY+2, TY+3
   const int chr = wave == 0 ? 0 : (wave == 1 ? 1 : (wave == 2 ? B2TY + 2 : B2TY + 3));
-  const int64_t a_crow = (int64_t)wrapm(y0 - 2 + chr, p.ny) * row + xo;
+  const int a_crow = (int)wrapm(y0 - 2 + chr, p.ny) * row + xo;
   // c halo columns: lane -> (ring row 1 .. TY+2, one of x0-2, x0-1, x0+128, x0+129)
   const int ccr = 1 + (c_col ? lane >> 2 : 0), cck = lane & 3;
   const int ccx = cck == 0 ? 0 : (cck == 1 ? 1 : (cck == 2 ? SX + 2 : SX + 3));   // column index in the ring row
-  const int64_t a_ccol = (int64_t)wrapm(y0 - 2 + ccr, p.ny) * row + wrapm(x0 - 2 + ccx, p.nx);
+  const int a_ccol = (int)wrapm(y0 - 2 + ccr, p.ny) * row + wrapm(x0 - 2 + ccx, p.nx);
   // eta halo row (wave 5: y0-1 -> tile row 0; wave 6: y0+TY -> tile row TY+1) and columns (wave 7)
   const int ehr = wave == 5 ? 0 : B2TY + 1;
-  const int64_t a_erow = (int64_t)wrapm(y0 - 1 + ehr, p.ny) * row + xo;
+  const int a_erow = (int)wrapm(y0 - 1 + ehr, p.ny) * row + xo;
   const int ecr = 1 + (e_col ? lane >> 1 : 0), ecx = (lane & 1) ? SX + 2 : 1;
-  const int64_t a_ecol = (int64_t)wrapm(y0 - 1 + ecr, p.ny) * row + wrapm(x0 - 2 + ecx, p.nx);
-  const int64_t a_own = (int64_t)(y0 + wave) * row + xo;
+  const int a_ecol = (int)wrapm(y0 - 1 + ecr, p.ny) * row + wrapm(x0 - 2 + ecx, p.nx);
+  const int a_own = (int)(y0 + wave) * row + xo;
   const int oy = wave + 2;  // own row in the c ring; own row in the mu / eta tiles is wave + 1
 
-  double2 e[4][3], pe[4], eh[4], peh[4];   // eta own: planes z-1, z, z+1; prefetched z+2; halo of z+1 / z+2 (.x only for columns)
-  double2 mu3[3], pc, pch;                 // mu own z-1, z, z+1; c own + halo of the plane about to enter the ring
+  double2 e[4][3], eh[4], peh[4];          // eta own: planes z-1, z, z+1; halo of z+1 / prefetched z+2 (.x only for columns)
+  double2 mu_m1, pch;                      // mu own of plane z-1 (planes z, z+1 are re-read from the LDS mu planes); c halo of the plane about to enter the ring
+  // Prefetch registers: own c of the plane about to enter the ring and own eta, requested one plane step ahead.  The halos
+  // of the same step are requested BEFORE the own cells: loads return in order, so waiting for a halo that was issued after
+  // the own-cell requests would drain those too -- halo first, and the wait for it leaves the five own-cell requests in
+  // flight.  Together with the mu planes re-read from LDS instead of kept in registers and 32-bit in-plane offsets (214 VGPRs,
+  // no spill) this took the step from 2.19 to 2.00 ms (0.61 -> 0.67 of peak; round 4, the three changes were made together).  A second register stage (own cells two
+  // steps ahead, loop unrolled by two) needs 256 VGPRs + spills, and a scratch reload waits for every older load: 2.37 ms.
+  double2 pc, pe[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int j = 0; j < 3; ++j) e[k][j] = make_double2(0.0, 0.0);
-  mu3[0] = mu3[1] = mu3[2] = make_double2(0.0, 0.0);
+  mu_m1 = make_double2(0.0, 0.0);
 
-#define B2_LOAD_C(Z)                                                                                            \
+#define B2_LOAD_C_OWN(PC, Z) PC = *reinterpret_cast<const double2*>(u + (int64_t)zw(Z) * plane + a_own);
+#define B2_LOAD_C_HALO(Z)                                                                                       \
   {                                                                                                             \
     const double* cz_ = u + (int64_t)zw(Z) * plane;                                                             \
-    pc = *reinterpret_cast<const double2*>(cz_ + a_own);                                                        \
     pch = c_row ? *reinterpret_cast<const double2*>(cz_ + a_crow) : make_double2(c_col ? cz_[a_ccol] : 0.0, 0.0); \
   }
-#define B2_STORE_C(Z)                                                                                           \
+#define B2_STORE_C(PC, Z)                                                                                       \
   {                                                                                                             \
     const int sl_ = ((Z) + 3) % 3;                                                                              \
-    *reinterpret_cast<double2*>(&S.cc[sl_][oy][tx]) = pc;                                                       \
+    *reinterpret_cast<double2*>(&S.cc[sl_][oy][tx]) = PC;                                                       \
     if (c_row) *reinterpret_cast<double2*>(&S.cc[sl_][chr][tx]) = pch;                                          \
     if (c_col) S.cc[sl_][ccr][ccx] = pch.x;                                                                     \
   }
-#define B2_LOAD_E(DST, DSTH, Z)                                                                                 \
+#define B2_LOAD_E_OWN(DST, Z)                                                                                   \
+  {                                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                               \
+        DST[k] = *reinterpret_cast<const double2*>(u + (int64_t)(k + 1) * p.fs + (int64_t)zw(Z) * plane + a_own); \
+  }
+#define B2_LOAD_E_HALO(DSTH, Z)                                                                                 \
   {                                                                                                             \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                             \
       const double* ez_ = u + (int64_t)(k + 1) * p.fs + (int64_t)zw(Z) * plane;                                \
-      DST[k] = *reinterpret_cast<const double2*>(ez_ + a_own);                                                  \
       DSTH[k] = e_row ? *reinterpret_cast<const double2*>(ez_ + a_erow) : make_double2(e_col ? ez_[a_ecol] : 0.0, 0.0); \
     }                                                                                                           \
   }
@@ -470,22 +481,26 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
     return make_double2(mu_cell(c.x, xl, c.y, ym.x, yp.x, zm.x, zp.x, h0), mu_cell(c.y, c.x, xr, ym.y, yp.y, zm.y, zp.y, h1));
   };
 
-  // prologue: ring planes zb-2, zb-1; prefetch registers = c(zb), eta(zb-1)
-  B2_LOAD_C(zb - 2)
-  B2_STORE_C(zb - 2)
-  B2_LOAD_C(zb - 1)
-  B2_STORE_C(zb - 1)
-  B2_LOAD_C(zb)
-  B2_LOAD_E(pe, peh, zb - 1)
+  // prologue: ring planes zb-2, zb-1; halos and own cells of c(zb), eta(zb-1)
+  B2_LOAD_C_OWN(pc, zb - 2)
+  B2_LOAD_C_HALO(zb - 2)
+  B2_STORE_C(pc, zb - 2)
+  B2_LOAD_C_OWN(pc, zb - 1)
+  B2_LOAD_C_HALO(zb - 1)
+  B2_STORE_C(pc, zb - 1)
+  B2_LOAD_C_HALO(zb)
+  B2_LOAD_E_HALO(peh, zb - 1)
+  B2_LOAD_C_OWN(pc, zb)
+  B2_LOAD_E_OWN(pe, zb - 1)
 #pragma unroll
   for (int k = 0; k < 4; ++k) eh[k] = make_double2(0.0, 0.0);
   for (int z = zb - 2; z < ze; ++z) {
     // ---- P1 ----
-    B2_STORE_C(z + 2)
+    B2_STORE_C(pc, z + 2)
     __syncthreads();
     // ---- P2: mu(z+1) ----
-    // eta(z+1) was requested one whole plane ago (end of the previous P2) and is taken over only now: consuming it in P4 of
-    // the iteration that requested it gave the loads one P3 to land and left the memory pipe idle for half of every plane
+    // eta(z+1) was requested one whole plane step ago (P2 of the previous step) and is taken over only now: consuming it in P4
+    // of the step that requested it gave the loads one P3 to land and left the memory pipe idle for half of every plane
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       e[k][2] = pe[k];
@@ -497,7 +512,6 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
 #pragma unroll
       for (int k = 0; k < 4; ++k) en[k] = e[k][2];
       const double2 m = mu_pair(sm, sc, sp, oy, en);
-      mu3[2] = m;
       *reinterpret_cast<double2*>(&S.mu[ms][wave + 1][tx]) = m;
       if (e_row) {  // ring rows: eta halo values of this wave give h there
         const int ry = ehr + 1;  // ring row 1 (y0-1) or TY+2 (y0+TY)
@@ -512,10 +526,14 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
                                     S.cc[sc][ry + 1][cx], S.cc[sm][ry][cx], S.cc[sp][ry][cx], h);
       }
     }
-    B2_LOAD_C(z + 3)
-    B2_LOAD_E(pe, peh, z + 2)
+    B2_LOAD_C_HALO(z + 3)          // halos first, then the own cells (see above)
+    B2_LOAD_E_HALO(peh, z + 2)
+    B2_LOAD_C_OWN(pc, z + 3)
+    B2_LOAD_E_OWN(pe, z + 2)
     __syncthreads();
     // ---- P3: outputs of plane z ----
+    const double2 mu_z = *reinterpret_cast<const double2*>(&S.mu[(z + 2) & 1][wave + 1][tx]);   // own mu of plane z (garbage in the
+                                                                                              // first warm-up step: never used)
     if (z >= zb) {
       const int sc = (z + 3) % 3, ms = (z + 2) & 1, ty = wave + 1;
       const double2 c = *reinterpret_cast<const double2*>(&S.cc[sc][oy][tx]);
@@ -524,10 +542,11 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
         const double xl = S.mu[ms][ty][tx - 1], xr = S.mu[ms][ty][tx + 2];
         const double2 ym = *reinterpret_cast<const double2*>(&S.mu[ms][ty - 1][tx]);
         const double2 yp = *reinterpret_cast<const double2*>(&S.mu[ms][ty + 1][tx]);
-        const double2 m = mu3[1];
+        const double2 m = mu_z;
+        const double2 mp = *reinterpret_cast<const double2*>(&S.mu[ms ^ 1][ty][tx]);   // own mu of plane z + 1
         double lx = ((xl + m.y) + (ym.x + yp.x)) - 4.0 * m.x, ly = ((m.x + xr) + (ym.y + yp.y)) - 4.0 * m.y;
-        lx = lx + ((mu3[0].x + mu3[2].x) - 2.0 * m.x);
-        ly = ly + ((mu3[0].y + mu3[2].y) - 2.0 * m.y);
+        lx = lx + ((mu_m1.x + mp.x) - 2.0 * m.x);
+        ly = ly + ((mu_m1.y + mp.y) - 2.0 * m.y);
         st_out<NT>(un + o, make_double2(c.x + (dt * Mob * p.inv_h2) * lx, c.y + (dt * Mob * p.inv_h2) * ly));
       }
       double2 res[4];
@@ -570,12 +589,13 @@ __global__ __launch_bounds__(B2T) void bm2_fused_kernel(const MfdParams p, const
       e[k][0] = e[k][1];
       e[k][1] = e[k][2];
     }
-    mu3[0] = mu3[1];
-    mu3[1] = mu3[2];
+    mu_m1 = mu_z;
   }
-#undef B2_LOAD_C
+#undef B2_LOAD_C_OWN
+#undef B2_LOAD_C_HALO
 #undef B2_STORE_C
-#undef B2_LOAD_E
+#undef B2_LOAD_E_OWN
+#undef B2_LOAD_E_HALO
 }
 
 // diagnostics, raw sums per block: {sum second (BM2: c, BM3: (phi+1)/2), sum f_chem, sum of weighted squared forward
